@@ -1,0 +1,86 @@
+"""CPU: the numpy oracle and the torch restatement reproduce the golden vectors
+captured from the reference itself (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from golden_check import check_case
+from oracle import vae_oracle as vo
+from oracle import torch_ref as tr
+
+
+class NumpyOracleImpl:
+    def __init__(self, dtype=np.float32):
+        self.dtype = dtype
+
+    def load(self, model, dims, params):
+        self.model = model
+        self.p = {k: v.astype(self.dtype) for k, v in params.items()}
+        names = list(self.p)
+        if model == "M2_info":
+            self.opt = vo.AdamState([n for n in names if n.startswith("enc_dec_clf.")])
+            self.opt_aux = vo.AdamState([n for n in names if n.startswith("auxiliary.")])
+        else:
+            self.opt = vo.AdamState(names)
+
+    def step(self, x, y, e):
+        x = x.astype(self.dtype); e = e.astype(self.dtype)
+        y = None if y is None else y.astype(self.dtype)
+        if self.model != "M2_info":
+            out, grads = vo.train_step_vae(self.model, self.p, self.opt, x, y, e)
+            return dict(r=out["r"], mu=out["mu"], logvar=out["logvar"], kl_divergence=out["kl_divergence"],
+                        losses=(out["loss"], out["recon"], out["kl"]), grads=grads)
+        out, g1, g2, aux_total = vo.train_step_m2info(self.p, self.opt, self.opt_aux, x, y, e)
+        g1 = {k: (np.zeros_like(self.p[k]) if isinstance(v, (int, float)) else v) for k, v in g1.items()}
+        return dict(r=out["r"], z=out["z"], mu=out["mu"], logvar=out["logvar"],
+                    y_hat_class_soft=out["y_hat_class_soft"], y_hat_aux_soft=out["y_hat_aux_soft"],
+                    losses=(out["ELBO"], out["recon"], out["kl"], out["enc_loss"], out["classif_loss"],
+                            out["aux_loss"], out["aux_enc_loss"]),
+                    grads_enc=g1, grads_aux_total=aux_total)
+
+    def params(self):
+        return self.p
+
+
+@pytest.mark.parametrize("case", gu.CASES, ids=[c[0] for c in gu.CASES])
+def test_numpy_oracle_matches_reference_vectors(vae_golden, case):
+    check_case(NumpyOracleImpl(np.float32), vae_golden, case)
+
+
+@pytest.mark.parametrize("case", [c for c in gu.CASES if "small" in c[0]], ids=lambda c: c[0])
+def test_numpy_oracle_fp64_within_budget(vae_golden, case):
+    """float64 oracle vs float32 reference: shows the fp32 rounding budget is ~1e-6."""
+    check_case(NumpyOracleImpl(np.float64), vae_golden, case, rtol_param=1e-5, atol_param=3e-6)
+
+
+@pytest.mark.parametrize("name", ["M1_full", "M2_full_y513", "M2info_full"])
+def test_torch_restatement_losses(vae_golden, name):
+    """oracle/torch_ref.py (the cpu_baseline code) replays the reference's loss trajectory."""
+    case = [c for c in gu.CASES if c[0] == name][0]
+    _, model, dims, B, wscale = case
+    seed = 100 + [c[0] for c in gu.CASES].index(name)
+    p = {k: torch.from_numpy(v.copy()).requires_grad_() for k, v in gu.make_params(model, dims, seed, wscale).items()}
+    st = tr.Stepper(model, p)
+    for step in range(1, gu.NSTEPS + 1):
+        x, y, e = gu.make_batch(dims, B, seed * 1000 + step)
+        res = st.step(torch.from_numpy(x), None if y is None else torch.from_numpy(y), torch.from_numpy(e))
+        ref = vae_golden[f"{name}/step{step}/losses"]
+        if model == "M2_info":
+            np.testing.assert_allclose(res, ref[[0, 1, 2, 3, 5]], rtol=2e-6)
+        else:
+            np.testing.assert_allclose(res, ref, rtol=2e-6)
+    for k, v in p.items():
+        gu.compare_summary(k, v.detach().numpy(), vae_golden, f"{name}/step{gu.NSTEPS}/param/{k}", 1e-6, 1e-7)
+
+
+def test_layer_dims_match_torch_ref():
+    for _, model, dims, _, _ in gu.CASES:
+        d = dict(dims)
+        assert gu.layer_dims(model, **d) == tr.layer_dims(model, **d)
+
+
+def test_reference_seeded_known_answer(vae_golden):
+    """SURVEY.md 8c smoke known-answer of the reference (seed 0, torch RNG)."""
+    np.testing.assert_allclose(vae_golden["kat_m1_seed0_elbo"],
+                               [698.5711669921875, 686.7371215820312, 11.834017753601074], rtol=1e-7)
