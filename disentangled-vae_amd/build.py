@@ -1,0 +1,60 @@
+"""Build libdvae_hip.so (gfx950) in-tree with hipcc.
+
+    python disentangled-vae_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the
+GPU box with the gpurun snapshot.  Rebuilds only when a source is newer.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdvae_hip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _newer_than_lib(paths):
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in paths)
+
+
+def build(force=False, verbose=True):
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    if not force and not _newer_than_lib(deps):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                [os.path.getmtime(src)] + [os.path.getmtime(p) for p in deps if p.endswith((".hpp", ".h"))]):
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+               "-Wall", "-Wno-unused-function"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

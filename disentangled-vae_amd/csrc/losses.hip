@@ -1,0 +1,252 @@
+// Reparametrisation, ELBO (Itakura-Saito + KL), BCE family and Adam: the
+// HBM-bound elementwise / reduction kernels of the layer-level path.
+// One wave64 per frame for the 513-bin Itakura-Saito row sum (wavefront
+// shuffle reduction), per-block partials in double, a one-block final pass:
+// deterministic (no atomics), no host sync.
+#include <float.h>
+#include "common.hpp"
+
+namespace dvae {
+
+constexpr int kMaxPartials = 1024;
+
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                           const float* __restrict__ eps, float* __restrict__ z, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = expf(lv[i] * 0.5f);          // models.py:17  std = log_var.mul(0.5).exp_()
+        z[i] = fmaf(s, eps[i], mu[i]);               // models.py:20  mu.addcmul(std, epsilon)
+    }
+}
+
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ lv,
+                                                           const float* __restrict__ eps, float* __restrict__ dmu,
+                                                           float* __restrict__ dlv, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = dz[i];
+        dmu[i] = g;
+        dlv[i] = g * eps[i] * (0.5f * expf(lv[i] * 0.5f));
+    }
+}
+
+// partials: double[2 * gridDim.x] = {sum_b recon_b, sum_b kl_b} per block
+__global__ __launch_bounds__(256) void elbo_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r, int ldr,
+                                                         const float* __restrict__ mu, const float* __restrict__ lv, float eps,
+                                                         int64_t B, int F, int Z, float* __restrict__ kl_b,
+                                                         double* __restrict__ partials) {
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    double s_rec = 0.0, s_kl = 0.0;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += nw) {
+        const float* xr = x + b * ldx;
+        const float* rr = r + b * ldr;
+        float acc = 0.f;
+        for (int f = lane; f < F; f += 64) {
+            const float xv = xr[f], rv = rr[f];
+            acc += xv / rv - logf(xv + eps) + logf(rv) - 1.f;     // utils.py:74
+        }
+        float k = 0.f;
+        for (int j = lane; j < Z; j += 64) {
+            const float m = mu[b * Z + j], l = lv[b * Z + j];
+            k += l - m * m - expf(l);                             // utils.py:75
+        }
+        acc = wave_sum(acc);
+        k = -0.5f * wave_sum(k);
+        if (lane == 0) {
+            s_rec += (double)acc;
+            s_kl += (double)k;
+            if (kl_b) kl_b[b] = k;                                // models.py:165-167
+        }
+    }
+    if (lane == 0) { red[wave][0] = s_rec; red[wave][1] = s_kl; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        partials[2 * blockIdx.x + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void elbo_final_kernel(const double* __restrict__ partials, int nblocks, int64_t B, float* __restrict__ out3) {
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0.0, k = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[2 * i]; k += partials[2 * i + 1]; }
+    a = wave_sum(a); k = wave_sum(k);
+    if (lane == 0) { red[wave][0] = a; red[wave][1] = k; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float recon = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)B);
+        const float kl = (float)((red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (double)B);
+        out3[0] = recon + kl; out3[1] = recon; out3[2] = kl;
+    }
+}
+
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r, int ldr,
+                                                        const float* __restrict__ mu, const float* __restrict__ lv,
+                                                        const float* __restrict__ g2, int64_t B, int F, int Z,
+                                                        float* __restrict__ dr, int lddr, float* __restrict__ dmu, float* __restrict__ dlv) {
+    const float invB = 1.f / (float)B;
+    const float gr = g2[0] * invB, gk = g2[1] * invB;
+    const int64_t total = B * (int64_t)F, nz = B * (int64_t)Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const float xv = x[b * ldx + f], rv = r[b * ldr + f];
+        if (dr) dr[b * lddr + f] = gr / rv - gr * ((xv / rv) / rv);    // d/dr [x/r + log r]
+        if (i < nz) {
+            if (dmu) dmu[i] = gk * mu[i];
+            if (dlv) dlv[i] = -0.5f * gk * (1.f - expf(lv[i]));
+        }
+    }
+}
+
+// flat sum over B*Y elements; partials double[gridDim.x]
+__global__ __launch_bounds__(256) void bce_sum_kernel(const float* __restrict__ r, const float* __restrict__ t, float eps,
+                                                       int64_t n, int variant, double* __restrict__ partials) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float rv = r[i];
+        const float tv = variant == 0 ? t[i] : (variant == 1 ? 0.5f : rv);
+        s += (double)(tv * logf(rv + eps) + (1.f - tv) * logf(1.f - rv + eps));   // utils.py:55-63
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void bce_final_kernel(const double* __restrict__ partials, int nblocks, int64_t B, float* __restrict__ out1) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) a += partials[i];
+    a = wave_sum(a);
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out1[0] = (float)(-(red[0] + red[1] + red[2] + red[3]) / (double)B);
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ r, const float* __restrict__ t, float eps,
+                                                       const float* __restrict__ g, int64_t B, int64_t n, int variant,
+                                                       float* __restrict__ dr, float* __restrict__ dt) {
+    const float s = -g[0] / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float rv = r[i];
+        const float la = logf(rv + eps), lb = logf(1.f - rv + eps);
+        float d;
+        if (variant == 0) {
+            const float tv = t[i];
+            d = tv / (rv + eps) - (1.f - tv) / (1.f - rv + eps);
+            if (dt) dt[i] = s * (la - lb);
+        } else if (variant == 1) {
+            d = 0.5f / (rv + eps) - 0.5f / (1.f - rv + eps);
+        } else {  // d/dr [r log(r+e) + (1-r) log(1-r+e)]
+            d = la + rv / (rv + eps) - lb - (1.f - rv) / (1.f - rv + eps);
+        }
+        dr[i] = s * d;
+    }
+}
+
+// torch.optim.Adam single-tensor update (no weight decay / amsgrad / maximize)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
+                                                    float step_size, float bc2_sqrt, float eps, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] + one_minus_b1 * (gi - m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+static inline int ew_blocks(int64_t n) {
+    int64_t b = cdiv(n, 256);
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace dvae
+
+using namespace dvae;
+
+extern "C" int dvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream) {
+    DVAE_CHECK_ARG(mu && logvar && eps && z && n >= 0, "reparam_fwd: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n);
+    DVAE_LAUNCH_OK("reparam_fwd");
+    return 0;
+}
+
+extern "C" int dvae_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar, int64_t n, void* stream) {
+    DVAE_CHECK_ARG(dz && logvar && eps && dmu && dlogvar && n >= 0, "reparam_bwd: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dz, logvar, eps, dmu, dlogvar, n);
+    DVAE_LAUNCH_OK("reparam_bwd");
+    return 0;
+}
+
+extern "C" size_t dvae_elbo_workspace_bytes(int64_t B) {
+    (void)B;
+    return (size_t)kMaxPartials * 2 * sizeof(double);
+}
+
+extern "C" int dvae_elbo_fwd(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar,
+                             float eps, int64_t B, int F, int Z, float* out3, float* kl_b, void* ws, void* stream) {
+    DVAE_CHECK_ARG(x && r && mu && logvar && out3 && ws && B > 0 && F > 0 && Z > 0 && ldx >= F && ldr >= F, "elbo_fwd: bad argument");
+    int nb = (int)(cdiv(B, 4) < kMaxPartials ? cdiv(B, 4) : kMaxPartials);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(elbo_rows_kernel, dim3(nb), dim3(256), 0, s, x, ldx, r, ldr, mu, logvar, eps, B, F, Z, kl_b, (double*)ws);
+    DVAE_LAUNCH_OK("elbo_rows");
+    hipLaunchKernelGGL(elbo_final_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, nb, B, out3);
+    DVAE_LAUNCH_OK("elbo_final");
+    return 0;
+}
+
+extern "C" int dvae_elbo_bwd(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar,
+                             const float* g2, int64_t B, int F, int Z, float* dr, int lddr, float* dmu, float* dlogvar, void* stream) {
+    DVAE_CHECK_ARG(x && r && mu && logvar && g2 && B > 0 && F > 0 && Z > 0 && ldx >= F && ldr >= F && (!dr || lddr >= F), "elbo_bwd: bad argument");
+    DVAE_CHECK_ARG(Z <= F, "elbo_bwd: latent dim larger than feature dim");
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(ew_blocks(B * (int64_t)F)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, r, ldr, mu, logvar, g2, B, F, Z, dr, lddr, dmu, dlogvar);
+    DVAE_LAUNCH_OK("elbo_bwd");
+    return 0;
+}
+
+extern "C" int dvae_bce_fwd(const float* r, const float* t, float eps, int64_t B, int Y, int variant, float* out1, void* ws, void* stream) {
+    DVAE_CHECK_ARG(r && out1 && ws && B > 0 && Y > 0 && variant >= 0 && variant <= 2 && (variant != 0 || t), "bce_fwd: bad argument");
+    const int64_t n = B * (int64_t)Y;
+    int nb = (int)(cdiv(n, 256) < kMaxPartials ? cdiv(n, 256) : kMaxPartials);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_sum_kernel, dim3(nb), dim3(256), 0, s, r, t, eps, n, variant, (double*)ws);
+    DVAE_LAUNCH_OK("bce_sum");
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, nb, B, out1);
+    DVAE_LAUNCH_OK("bce_final");
+    return 0;
+}
+
+extern "C" int dvae_bce_bwd(const float* r, const float* t, float eps, const float* g, int64_t B, int Y, int variant,
+                            float* dr, float* dt, void* stream) {
+    DVAE_CHECK_ARG(r && g && dr && B > 0 && Y > 0 && variant >= 0 && variant <= 2 && (variant != 0 || t), "bce_bwd: bad argument");
+    const int64_t n = B * (int64_t)Y;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, r, t, eps, g, B, n, variant, dr, dt);
+    DVAE_LAUNCH_OK("bce_bwd");
+    return 0;
+}
+
+extern "C" int dvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                              double eps, int step, double grad_scale, void* stream) {
+    DVAE_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "adam_step: bad argument");
+    if (n == 0) return 0;
+    // bias corrections in double on the host, as torch's python scalars (torch/optim/adam.py)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps, (float)grad_scale);
+    DVAE_LAUNCH_OK("adam");
+    return 0;
+}

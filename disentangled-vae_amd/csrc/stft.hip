@@ -1,0 +1,285 @@
+// STFT / ISTFT for packages/processing/stft.py (librosa semantics restated in
+// oracle/stft_oracle.py).  One workgroup walks frames; per frame the nfft real
+// samples are windowed and packed into an nfft/2-point complex FFT that runs
+// entirely in LDS (double precision: the reference transforms float64 audio
+// and only then casts to complex64), followed by the real-FFT split step.
+// Twiddles and the window are staged in LDS once per workgroup.
+// ISTFT = inverse of the same split + FFT, windowed frames to a scratch
+// buffer, then a gather overlap-add that replays librosa's float32
+// frame-by-frame accumulation order exactly (deterministic, no atomics).
+#include <float.h>
+#include "common.hpp"
+
+namespace dvae {
+
+struct cd { double x, y; };
+__device__ __forceinline__ cd cmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cconj(cd a) { return cd{a.x, -a.y}; }
+
+// in-LDS radix-2 DIT FFT of M = 1 << logM points already stored in bit-reversed order.
+// tw[k] = exp(-2 pi i k / (2M)), k < M.  inverse != 0 conjugates the twiddles.
+__device__ __forceinline__ void fft_lds(cd* z, const cd* tw, int logM, int inverse) {
+    const int M = 1 << logM;
+    for (int s = 1; s <= logM; ++s) {
+        const int half = 1 << (s - 1);
+        for (int j = threadIdx.x; j < (M >> 1); j += blockDim.x) {
+            const int grp = j >> (s - 1), pos = j & (half - 1);
+            const int i0 = (grp << s) + pos, i1 = i0 + half;
+            cd w = tw[2 * pos * (M >> s)];
+            if (inverse) w.y = -w.y;
+            const cd a = z[i0], b = cmul(w, z[i1]);
+            z[i0] = cadd(a, b);
+            z[i1] = csub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void stage_tables(cd* tw, double* win, const double* window, int nfft) {
+    const int M = nfft >> 1;
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)nfft, &s, &c);
+        tw[k] = cd{c, s};
+    }
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) win[i] = window[i];
+}
+
+__device__ __forceinline__ void store_bin(void* out, int layout, int64_t T, int F, int64_t t, int f, cd v) {
+    float* o = (float*)out;
+    const float re = (float)v.x, im = (float)v.y;
+    if (layout == 0) {            // complex64 [F][T]  (column = frame)
+        o[(f * T + t) * 2] = re;
+        o[(f * T + t) * 2 + 1] = im;
+    } else {                      // power [T][F] float32: np.abs(complex64)**2
+        const float a = hypotf(re, im);
+        o[t * F + f] = a * a;
+    }
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void stft_pow2_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window,
+                                                         int nfft, int logM, int hop, int64_t T, void* out, int layout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = nfft >> 1, F = M + 1;
+    cd* z = (cd*)smem;
+    cd* tw = z + M;
+    double* win = (double*)(tw + M);
+    stage_tables(tw, win, window, nfft);
+    __syncthreads();
+    for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+        const int64_t base = t * hop;
+        for (int i = threadIdx.x; i < M; i += blockDim.x) {
+            const int64_t s0 = base + 2 * i;
+            const double a = (s0 < n) ? (double)x[s0] * win[2 * i] : 0.0;
+            const double b = (s0 + 1 < n) ? (double)x[s0 + 1] * win[2 * i + 1] : 0.0;
+            z[__brev((unsigned)i) >> (32 - logM)] = cd{a, b};
+        }
+        __syncthreads();
+        fft_lds(z, tw, logM, 0);
+        // split: X[k] = E + W^k O, X[M-k] = conj(E - W^k O)
+        for (int k = threadIdx.x; k <= (M >> 1); k += blockDim.x) {
+            const cd zk = z[k], zc = cconj(z[(M - k) & (M - 1)]);
+            const cd e = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y)};
+            const cd d = csub(zk, zc);
+            const cd o = cd{0.5 * d.y, -0.5 * d.x};          // -0.5 i (zk - zc)
+            const cd wo = cmul(tw[k], o);
+            store_bin(out, layout, T, F, t, k, cadd(e, wo));
+            store_bin(out, layout, T, F, t, M - k, cconj(csub(e, wo)));
+        }
+        __syncthreads();
+    }
+}
+
+// generic O(N^2) DFT for non power-of-two window lengths (e.g. the wrapper's never-used
+// default 50 ms = 800 samples): API completeness only.
+template <typename TIN>
+__global__ __launch_bounds__(256) void stft_dft_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window,
+                                                        int nfft, int hop, int64_t T, void* out, int layout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cd* tw = (cd*)smem;                 // nfft entries exp(-2 pi i k / nfft)
+    double* fr = (double*)(tw + nfft);  // windowed frame
+    const int F = nfft / 2 + 1;
+    for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)k / (double)nfft, &s, &c);
+        tw[k] = cd{c, s};
+    }
+    for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
+            const int64_t s0 = t * hop + i;
+            fr[i] = (s0 < n) ? (double)x[s0] * window[i] : 0.0;
+        }
+        __syncthreads();
+        for (int f = threadIdx.x; f < F; f += blockDim.x) {
+            double re = 0.0, im = 0.0;
+            int idx = 0;
+            for (int i = 0; i < nfft; ++i) {
+                re += fr[i] * tw[idx].x;
+                im += fr[i] * tw[idx].y;
+                idx += f; if (idx >= nfft) idx -= nfft;
+            }
+            store_bin(out, layout, T, F, t, f, cd{re, im});
+        }
+    }
+}
+
+// frames[t][m] = window[m] * irfft(S[:, t])[m]   (double scratch)
+__global__ __launch_bounds__(256) void istft_frames_pow2_kernel(const float* __restrict__ S, int64_t T, int64_t ldT,
+                                                                 const double* __restrict__ window, int nfft, int logM,
+                                                                 double* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = nfft >> 1;
+    cd* z = (cd*)smem;
+    cd* tw = z + M;
+    double* win = (double*)(tw + M);
+    stage_tables(tw, win, window, nfft);
+    __syncthreads();
+    const double scale = 1.0 / (double)M;
+    for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+        for (int k = threadIdx.x; k <= (M >> 1); k += blockDim.x) {
+            cd xk = cd{(double)S[(k * ldT + t) * 2], (double)S[(k * ldT + t) * 2 + 1]};
+            cd xm = cd{(double)S[((int64_t)(M - k) * ldT + t) * 2], (double)S[((int64_t)(M - k) * ldT + t) * 2 + 1]};
+            if (k == 0) { xk.y = 0.0; xm.y = 0.0; }              // C2R ignores imag of DC / Nyquist
+            const cd xc = cconj(xm);
+            const cd e = cd{0.5 * (xk.x + xc.x), 0.5 * (xk.y + xc.y)};
+            const cd d = csub(xk, xc);
+            const cd o = cmul(cconj(tw[k]), cd{0.5 * d.x, 0.5 * d.y});
+            const cd zk = cd{e.x - o.y, e.y + o.x};              // E + i O
+            const cd zm = cd{e.x + o.y, -e.y + o.x};             // conj(E) + i conj(O)
+            z[__brev((unsigned)k) >> (32 - logM)] = zk;
+            if (k != 0 && k != (M >> 1)) z[__brev((unsigned)(M - k)) >> (32 - logM)] = zm;
+        }
+        __syncthreads();
+        fft_lds(z, tw, logM, 1);
+        for (int i = threadIdx.x; i < M; i += blockDim.x) {
+            const cd v = z[i];
+            frames[t * nfft + 2 * i] = win[2 * i] * (v.x * scale);
+            frames[t * nfft + 2 * i + 1] = win[2 * i + 1] * (v.y * scale);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void istft_frames_dft_kernel(const float* __restrict__ S, int64_t T, int64_t ldT,
+                                                                const double* __restrict__ window, int nfft,
+                                                                double* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cd* tw = (cd*)smem;                  // exp(+2 pi i k / nfft)
+    cd* X = tw + nfft;                   // half spectrum of this frame
+    const int F = nfft / 2 + 1;
+    for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+        double s, c;
+        sincospi(2.0 * (double)k / (double)nfft, &s, &c);
+        tw[k] = cd{c, s};
+    }
+    for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+        __syncthreads();
+        for (int f = threadIdx.x; f < F; f += blockDim.x) {
+            cd v = cd{(double)S[(f * ldT + t) * 2], (double)S[(f * ldT + t) * 2 + 1]};
+            if (f == 0 || (2 * f == nfft)) v.y = 0.0;
+            X[f] = v;
+        }
+        __syncthreads();
+        for (int m = threadIdx.x; m < nfft; m += blockDim.x) {
+            double acc = X[0].x;
+            int idx = 0;
+            for (int f = 1; f < F; ++f) {
+                idx += m; if (idx >= nfft) idx -= nfft;
+                const double term = X[f].x * tw[idx].x - X[f].y * tw[idx].y;
+                acc += (2 * f == nfft) ? term : 2.0 * term;
+            }
+            frames[t * nfft + m] = window[m] * (acc / (double)nfft);
+        }
+    }
+}
+
+// y[i] = sum over frames (float32 accumulation in frame order, as librosa's in-place +=) / wss
+__global__ __launch_bounds__(256) void istft_ola_kernel(const double* __restrict__ frames, const double* __restrict__ window,
+                                                         int64_t T, int nfft, int hop, int64_t start, float* __restrict__ y, int64_t out_len) {
+    const int64_t ntot = (int64_t)nfft + (int64_t)hop * (T - 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = i + start;
+        float acc = 0.f, wss = 0.f;
+        if (src < ntot) {
+            int64_t tlo = (src - nfft + hop) / hop;     // ceil((src - nfft + 1) / hop) for src >= nfft - 1
+            if (src < nfft) tlo = 0;
+            int64_t thi = src / hop;
+            if (thi > T - 1) thi = T - 1;
+            for (int64_t t = tlo; t <= thi; ++t) {
+                const int m = (int)(src - t * hop);
+                acc = (float)((double)acc + frames[t * nfft + m]);
+                wss = (float)((double)wss + window[m] * window[m]);
+            }
+            if (wss > FLT_MIN) acc = acc / wss;
+        }
+        y[i] = acc;
+    }
+}
+
+static inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+}  // namespace dvae
+
+using namespace dvae;
+
+extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* window, int nfft, int hop,
+                         int64_t T, void* out, int layout, void* stream) {
+    DVAE_CHECK_ARG(x && window && out && n > 0 && nfft >= 4 && (nfft % 2) == 0 && hop > 0 && T >= 0, "stft: bad argument");
+    DVAE_CHECK_ARG(layout == 0 || layout == 1, "stft: unknown output layout %d", layout);
+    DVAE_CHECK_ARG(T == 0 || (T - 1) * (int64_t)hop + nfft <= n, "stft: %lld frames do not fit in %lld samples", (long long)T, (long long)n);
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)(T < 2048 ? T : 2048);
+    const int lg = ilog2_exact(nfft);
+    if (lg >= 3 && nfft <= 2048) {
+        const size_t lds = (size_t)(nfft / 2) * 2 * sizeof(cd) + (size_t)nfft * sizeof(double);
+        if (in_f64)
+            hipLaunchKernelGGL((stft_pow2_kernel<double>), dim3(blocks), dim3(256), lds, s, (const double*)x, n, window, nfft, lg - 1, hop, T, out, layout);
+        else
+            hipLaunchKernelGGL((stft_pow2_kernel<float>), dim3(blocks), dim3(256), lds, s, (const float*)x, n, window, nfft, lg - 1, hop, T, out, layout);
+    } else {
+        DVAE_CHECK_ARG(nfft <= 2048, "stft: window length %d not supported (max 2048)", nfft);
+        const size_t lds = (size_t)nfft * sizeof(cd) + (size_t)nfft * sizeof(double);
+        if (in_f64)
+            hipLaunchKernelGGL((stft_dft_kernel<double>), dim3(blocks), dim3(256), lds, s, (const double*)x, n, window, nfft, hop, T, out, layout);
+        else
+            hipLaunchKernelGGL((stft_dft_kernel<float>), dim3(blocks), dim3(256), lds, s, (const float*)x, n, window, nfft, hop, T, out, layout);
+    }
+    DVAE_LAUNCH_OK("stft");
+    return 0;
+}
+
+extern "C" size_t dvae_istft_workspace_bytes(int64_t T, int nfft) {
+    return (size_t)(T > 0 ? T : 0) * (size_t)nfft * sizeof(double);
+}
+
+extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,
+                          int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
+    DVAE_CHECK_ARG(S && window && y && ws && T > 0 && ldT >= T && nfft >= 4 && (nfft % 2) == 0 && hop > 0 && start >= 0 && out_len >= 0,
+                   "istft: bad argument");
+    DVAE_CHECK_ARG(nfft <= 2048, "istft: window length %d not supported (max 2048)", nfft);
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)(T < 2048 ? T : 2048);
+    const int lg = ilog2_exact(nfft);
+    if (lg >= 3) {
+        const size_t lds = (size_t)(nfft / 2) * 2 * sizeof(cd) + (size_t)nfft * sizeof(double);
+        hipLaunchKernelGGL(istft_frames_pow2_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, ldT, window, nfft, lg - 1, (double*)ws);
+    } else {
+        const size_t lds = (size_t)nfft * sizeof(cd) + (size_t)(nfft / 2 + 1) * sizeof(cd);
+        hipLaunchKernelGGL(istft_frames_dft_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, ldT, window, nfft, (double*)ws);
+    }
+    DVAE_LAUNCH_OK("istft_frames");
+    if (out_len == 0) return 0;
+    const int ob = (int)(cdiv(out_len, 256) < 2048 ? cdiv(out_len, 256) : 2048);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(ob), dim3(256), 0, s, (const double*)ws, window, T, nfft, hop, start, y, out_len);
+    DVAE_LAUNCH_OK("istft_ola");
+    return 0;
+}

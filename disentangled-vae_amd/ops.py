@@ -1,0 +1,215 @@
+"""torch.autograd.Function shells over the layer-level HIP kernels.
+
+These are what packages/models/models.py and packages/models/utils.py call
+for CUDA tensors, so the reference's scripts keep using `loss.backward()` and
+stock `torch.optim.Adam` (SURVEY.md 8b "nn.Module protocol").  Every Function
+fails loudly when the library is missing; there is no eager fallback here.
+"""
+import torch
+
+from . import native as N
+
+
+def _new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def linear_act_fwd(x0, x1, W, b, act):
+    lib = N.load()
+    x0_ = N.as_f32_2d(x0, "linear_act: input")
+    x1_ = None if x1 is None else N.as_f32_2d(x1, "linear_act: second input")
+    W_ = N.as_f32_2d(W, "linear_act: weight")
+    B, k0 = x0_.shape
+    k1 = 0 if x1_ is None else x1_.shape[1]
+    if x1_ is not None and x1_.shape[0] != B:
+        raise RuntimeError("linear_act: the two inputs differ in row count")
+    Nout = W_.shape[0]
+    if W_.shape[1] != k0 + k1:
+        raise RuntimeError(f"linear_act: weight fan-in {W_.shape[1]} != {k0}+{k1}")
+    if b is not None:
+        if b.dtype != torch.float32 or not b.is_cuda:
+            raise TypeError("linear_act: bias must be a float32 CUDA tensor")
+        b = b.contiguous()
+    out = _new((B, Nout), x0_)
+    N.check(lib.dvae_linear_act_fwd(N.ptr(x0_), k0, N.ld(x0_), N.ptr(x1_), k1, 0 if x1_ is None else N.ld(x1_),
+                                    N.ptr(W_), N.ld(W_), N.ptr(b), N.ptr(out), Nout, B, Nout, act, N.stream()),
+            "dvae_linear_act_fwd")
+    return out, x0_, x1_, W_
+
+
+class LinearAct(torch.autograd.Function):
+    """out = act([x0 | x1] @ W.T + b)   (models.py:57-63, 102-105, 119-122, 201-202)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, W, b, act):
+        out, x0_, x1_, W_ = linear_act_fwd(x0, x1, W, b, act)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.lead0 = x0.shape[:-1]
+        ctx.lead1 = None if x1 is None else x1.shape[:-1]
+        ctx.save_for_backward(x0_, x1_ if x1_ is not None else torch.empty(0), W_, out)
+        ctx.has_x1 = x1_ is not None
+        return out.reshape(*x0.shape[:-1], W_.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = N.load()
+        x0_, x1_, W_, out = ctx.saved_tensors
+        if not ctx.has_x1:
+            x1_ = None
+        B, Nout = out.shape
+        k0 = x0_.shape[1]
+        k1 = 0 if x1_ is None else x1_.shape[1]
+        dout_ = N.as_f32_2d(dout, "linear_act backward: grad")
+        s = N.stream()
+        if ctx.act == N.ACT_NONE:
+            dpre = dout_
+        else:
+            dpre = _new((B, Nout), out)
+            N.check(lib.dvae_act_bwd(N.ptr(dout_), N.ld(dout_), N.ptr(out), Nout, N.ptr(dpre), Nout, B, Nout, ctx.act, s),
+                    "dvae_act_bwd")
+        dx0 = dx1 = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx0 = _new((B, k0), out)
+            N.check(lib.dvae_linear_bwd_data(N.ptr(dpre), N.ld(dpre), N.ptr(W_), N.ld(W_), 0, N.ptr(dx0), k0, B, Nout, k0, 0, s),
+                    "dvae_linear_bwd_data")
+            dx0 = dx0.reshape(*ctx.lead0, k0)
+        if x1_ is not None and ctx.needs_input_grad[1]:
+            dx1 = _new((B, k1), out)
+            N.check(lib.dvae_linear_bwd_data(N.ptr(dpre), N.ld(dpre), N.ptr(W_), N.ld(W_), k0, N.ptr(dx1), k1, B, Nout, k1, 0, s),
+                    "dvae_linear_bwd_data")
+            dx1 = dx1.reshape(*ctx.lead1, k1)
+        need_w = ctx.needs_input_grad[2]
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        if need_w or need_b:
+            dW = _new((Nout, k0 + k1), out)
+            db = _new((Nout,), out) if ctx.has_bias else None
+            N.check(lib.dvae_linear_bwd_weight(N.ptr(dpre), N.ld(dpre), N.ptr(x0_), k0, N.ld(x0_), N.ptr(x1_), k1,
+                                               0 if x1_ is None else N.ld(x1_), N.ptr(dW), k0 + k1, N.ptr(db), B, Nout, 0, s),
+                    "dvae_linear_bwd_weight")
+            if not need_w:
+                dW = None
+            if not need_b:
+                db = None
+        return dx0, dx1, dW, db, None
+
+
+def linear_act(x0, W, b, act, x1=None):
+    return LinearAct.apply(x0, x1, W, b, act)
+
+
+class Reparam(torch.autograd.Function):
+    """z = mu + exp(0.5 * log_var) * epsilon   (models.py:9-22)."""
+
+    @staticmethod
+    def forward(ctx, mu, log_var, eps):
+        lib = N.load()
+        mu_ = N.as_f32_2d(mu, "reparam: mu").contiguous()
+        lv_ = N.as_f32_2d(log_var, "reparam: log_var").contiguous()
+        eps_ = N.as_f32_2d(eps, "reparam: epsilon").contiguous()
+        if not (mu_.shape == lv_.shape == eps_.shape):
+            raise RuntimeError("reparam: shape mismatch")
+        z = torch.empty_like(mu_)
+        N.check(lib.dvae_reparam_fwd(N.ptr(mu_), N.ptr(lv_), N.ptr(eps_), N.ptr(z), mu_.numel(), N.stream()), "dvae_reparam_fwd")
+        ctx.save_for_backward(lv_, eps_)
+        return z.reshape(mu.shape)
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = N.load()
+        lv_, eps_ = ctx.saved_tensors
+        dz_ = N.as_f32_2d(dz, "reparam backward").contiguous()
+        dmu = torch.empty_like(lv_)
+        dlv = torch.empty_like(lv_)
+        N.check(lib.dvae_reparam_bwd(N.ptr(dz_), N.ptr(lv_), N.ptr(eps_), N.ptr(dmu), N.ptr(dlv), lv_.numel(), N.stream()),
+                "dvae_reparam_bwd")
+        return dmu.reshape(dz.shape), dlv.reshape(dz.shape), None
+
+
+class Elbo(torch.autograd.Function):
+    """(recon + KL, recon, KL) of packages/models/utils.py:73-76 as one [3] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, r, mu, logvar, eps):
+        lib = N.load()
+        x_ = N.as_f32_2d(x, "elbo: x")
+        r_ = N.as_f32_2d(r, "elbo: r")
+        mu_ = N.as_f32_2d(mu, "elbo: mu").contiguous()
+        lv_ = N.as_f32_2d(logvar, "elbo: logvar").contiguous()
+        B, F = x_.shape
+        Z = mu_.shape[1]
+        if r_.shape != x_.shape or mu_.shape[0] != B or lv_.shape != mu_.shape:
+            raise RuntimeError("elbo: shape mismatch")
+        out3 = _new((3,), x_)
+        ws = torch.empty(lib.dvae_elbo_workspace_bytes(B), dtype=torch.uint8, device=x_.device)
+        N.check(lib.dvae_elbo_fwd(N.ptr(x_), N.ld(x_), N.ptr(r_), N.ld(r_), N.ptr(mu_), N.ptr(lv_), float(eps), B, F, Z,
+                                  N.ptr(out3), None, N.ptr(ws), N.stream()), "dvae_elbo_fwd")
+        ctx.save_for_backward(x_, r_, mu_, lv_)
+        ctx.shapes = (r.shape, mu.shape, logvar.shape)
+        return out3
+
+    @staticmethod
+    def backward(ctx, g3):
+        lib = N.load()
+        x_, r_, mu_, lv_ = ctx.saved_tensors
+        B, F = x_.shape
+        Z = mu_.shape[1]
+        g3 = g3.to(torch.float32)
+        g2 = torch.stack((g3[0] + g3[1], g3[0] + g3[2])).contiguous()
+        need_r, need_mu, need_lv = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        dr = _new((B, F), x_) if need_r else None
+        dmu = torch.empty_like(mu_) if need_mu else None
+        dlv = torch.empty_like(lv_) if need_lv else None
+        N.check(lib.dvae_elbo_bwd(N.ptr(x_), N.ld(x_), N.ptr(r_), N.ld(r_), N.ptr(mu_), N.ptr(lv_), N.ptr(g2), B, F, Z,
+                                  N.ptr(dr), F, N.ptr(dmu), N.ptr(dlv), N.stream()), "dvae_elbo_bwd")
+        rs, ms, ls = ctx.shapes
+        return (None, None if dr is None else dr.reshape(rs), None if dmu is None else dmu.reshape(ms),
+                None if dlv is None else dlv.reshape(ls), None)
+
+
+class Bce(torch.autograd.Function):
+    """binary_cross_entropy / _v2 / _v3 of packages/models/utils.py:55-63."""
+
+    @staticmethod
+    def forward(ctx, r, t, eps, variant):
+        lib = N.load()
+        r_ = N.as_f32_2d(r, "bce: r").contiguous()
+        t_ = None
+        if variant == 0:
+            t_ = N.as_f32_2d(t, "bce: target").contiguous()
+            if t_.shape != r_.shape:
+                raise RuntimeError("bce: shape mismatch")
+        B, Y = r_.shape
+        out1 = _new((1,), r_)
+        ws = torch.empty(lib.dvae_elbo_workspace_bytes(B), dtype=torch.uint8, device=r_.device)
+        N.check(lib.dvae_bce_fwd(N.ptr(r_), N.ptr(t_), float(eps), B, Y, variant, N.ptr(out1), N.ptr(ws), N.stream()), "dvae_bce_fwd")
+        ctx.save_for_backward(r_, t_ if t_ is not None else torch.empty(0))
+        ctx.variant, ctx.eps = variant, float(eps)
+        ctx.rshape = r.shape
+        ctx.tshape = None if t is None else t.shape
+        return out1.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = N.load()
+        r_, t_ = ctx.saved_tensors
+        if ctx.variant != 0:
+            t_ = None
+        B, Y = r_.shape
+        g_ = g.to(torch.float32).reshape(1).contiguous()
+        dr = torch.empty_like(r_)
+        need_t = ctx.variant == 0 and ctx.needs_input_grad[1]
+        dt = torch.empty_like(r_) if need_t else None
+        N.check(lib.dvae_bce_bwd(N.ptr(r_), N.ptr(t_), ctx.eps, N.ptr(g_), B, Y, ctx.variant, N.ptr(dr), N.ptr(dt), N.stream()),
+                "dvae_bce_bwd")
+        return dr.reshape(ctx.rshape), (dt.reshape(ctx.tshape) if need_t else None), None, None
+
+
+def adam_step_(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """In-place torch.optim.Adam update on flat fp32 CUDA buffers (scripts/training_M2.py:122)."""
+    lib = N.load()
+    for t in (p, g, m, v):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise TypeError("adam_step_: contiguous float32 CUDA tensors required")
+    N.check(lib.dvae_adam_step(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), p.numel(), lr, betas[0], betas[1], eps, step,
+                               grad_scale, N.stream()), "dvae_adam_step")

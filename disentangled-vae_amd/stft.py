@@ -1,0 +1,133 @@
+"""Host side of STFT / ISTFT: integer / indexing decisions in Python doubles exactly
+as the reference makes them (packages/processing/stft.py:34-50: window length, hop,
+the floating-point end-pad rule, quirk Q6), then the device kernels of
+csrc/stft.hip through the C ABI.  No CPU transform exists here: without the
+library or a GPU these functions raise.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import native as N
+
+
+def sizes(fs, wlen_sec, hop_percent, what="STFT"):
+    """nfft / hop exactly as packages/processing/stft.py:34-37 (raises on non-integer window)."""
+    if wlen_sec * fs != int(wlen_sec * fs):
+        raise ValueError("wlen_sample of %s is not an integer." % what)
+    nfft = int(wlen_sec * fs)
+    hopsamp = int(hop_percent * nfft)
+    return nfft, hopsamp
+
+
+def needs_end_pad(n, fs, wlen_sec, hop_percent):
+    """packages/processing/stft.py:45-47, same operation order in Python doubles (bit-exact
+    frame indexing depends on it: some exact multiples of the hop ARE padded)."""
+    utt_len = n / fs
+    return math.ceil(utt_len / wlen_sec / hop_percent) != int(utt_len / wlen_sec / hop_percent)
+
+
+def frame_count(n_padded, nfft, hop):
+    """librosa.util.frame: 1 + (len - n_fft) // hop."""
+    if n_padded < nfft:
+        raise ValueError("Input signal length=%d is too small to analyze with n_fft=%d" % (n_padded, nfft))
+    return 1 + (n_padded - nfft) // hop
+
+
+_window_cache = {}
+
+
+def window_f64(win, nfft, device):
+    """Periodic window as float64 on `device` (librosa: scipy.signal.get_window(win, n, fftbins=True))."""
+    key = (str(win), int(nfft), str(device))
+    w = _window_cache.get(key)
+    if w is None:
+        from scipy.signal import get_window
+        w = torch.from_numpy(np.ascontiguousarray(get_window(win, nfft, fftbins=True), dtype=np.float64)).to(device)
+        _window_cache[key] = w
+    return w
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("STFT/ISTFT run on the MI355X HIP path only: no GPU is visible (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stft_device(x_dev, window, nfft, hop, T, layout=0):
+    """x_dev: 1-D float32/float64 CUDA tensor already padded.  layout 0 -> complex64 [F, T];
+    layout 1 -> float32 power frames [T, F]."""
+    lib = N.load()
+    if not x_dev.is_cuda or x_dev.dim() != 1 or x_dev.dtype not in (torch.float32, torch.float64):
+        raise TypeError("stft_device: 1-D float32/float64 CUDA tensor required")
+    x_dev = x_dev.contiguous()
+    F = nfft // 2 + 1
+    if layout == 0:
+        out = torch.empty((F, T), dtype=torch.complex64, device=x_dev.device)
+    else:
+        out = torch.empty((T, F), dtype=torch.float32, device=x_dev.device)
+    N.check(lib.dvae_stft(N.ptr(x_dev), 1 if x_dev.dtype == torch.float64 else 0, x_dev.numel(), N.ptr(window), nfft, hop, T,
+                          N.ptr(out), layout, N.stream()), "dvae_stft")
+    return out
+
+
+def istft_device(S_dev, window, nfft, hop, n_frames, start, out_len):
+    """S_dev: complex64 [F, >= n_frames] CUDA tensor -> float32 [out_len]."""
+    lib = N.load()
+    if not S_dev.is_cuda or S_dev.dtype != torch.complex64 or S_dev.dim() != 2 or S_dev.shape[0] != nfft // 2 + 1:
+        raise TypeError("istft_device: complex64 [nfft/2+1, T] CUDA tensor required")
+    S_dev = S_dev.contiguous()
+    y = torch.empty((out_len,), dtype=torch.float32, device=S_dev.device)
+    ws = torch.empty(max(lib.dvae_istft_workspace_bytes(n_frames, nfft), 8), dtype=torch.uint8, device=S_dev.device)
+    N.check(lib.dvae_istft(N.ptr(S_dev), n_frames, S_dev.shape[1], N.ptr(window), nfft, hop, start, N.ptr(y), out_len,
+                           N.ptr(ws), N.stream()), "dvae_istft")
+    return y
+
+
+def stft_numpy(x, fs, wlen_sec, win, hop_percent, center, pad_mode, pad_at_end, dtype, layout=0):
+    """numpy in / numpy out body of packages.processing.stft.stft."""
+    nfft, hop = sizes(fs, wlen_sec, hop_percent, "STFT")
+    x = np.asarray(x)
+    if not np.issubdtype(x.dtype, np.floating):
+        raise TypeError("stft: audio must be floating point (as librosa requires)")
+    x_ = x
+    if pad_at_end and needs_end_pad(len(x), fs, wlen_sec, hop_percent):
+        x_ = np.pad(x, (0, hop), mode="constant")
+    # pad_at_end=False: the reference leaves x_ undefined (quirk Q7); here it means "no end pad"
+    if center:
+        x_ = np.pad(x_, int(nfft // 2), mode=pad_mode)
+    T = frame_count(len(x_), nfft, hop)
+    dev = _device()
+    xin = np.ascontiguousarray(x_, dtype=np.float64 if x_.dtype != np.float32 else np.float32)
+    out = stft_device(torch.from_numpy(xin).to(dev), window_f64(win, nfft, dev), nfft, hop, T, layout)
+    res = out.cpu().numpy()
+    if layout == 0 and np.dtype(dtype) != res.dtype:
+        res = res.astype(dtype)
+    return res
+
+
+def istft_numpy(Sxx, fs, wlen_sec, win, hop_percent, center, dtype, max_len):
+    """numpy in / numpy out body of packages.processing.stft.istft (librosa.istft semantics)."""
+    nfft, hop = sizes(fs, wlen_sec, hop_percent, "iSTFT")
+    S = np.asarray(Sxx)
+    if S.ndim != 2 or S.shape[0] != 1 + nfft // 2:
+        raise ValueError("istft: expected a [%d, T] spectrogram" % (1 + nfft // 2))
+    n_frames = S.shape[1]
+    if max_len:
+        padded = max_len + nfft if center else max_len
+        n_frames = min(n_frames, int(np.ceil(padded / hop)))
+    ntot = nfft + hop * (n_frames - 1)
+    start = nfft // 2 if center else 0
+    if max_len is None:
+        out_len = ntot - 2 * (nfft // 2) if center else ntot
+    else:
+        out_len = int(max_len)
+    dev = _device()
+    S_dev = torch.from_numpy(np.ascontiguousarray(S, dtype=np.complex64)).to(dev)
+    y = istft_device(S_dev, window_f64(win, nfft, dev), nfft, hop, n_frames, start, out_len).cpu().numpy()
+    if np.dtype(dtype) != y.dtype:
+        y = y.astype(dtype)
+    if max_len:
+        y = y[:int(max_len * fs)]      # quirk Q8: max_len is already in samples, so this is a no-op
+    return y

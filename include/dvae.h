@@ -1,0 +1,145 @@
+/* dvae.h -- C ABI of libdvae_hip.so: the MI355X (gfx950) hot path of
+ * sp-uhh/disentangled-vae (VAE train step + STFT/ISTFT).
+ *
+ * The reference has no FFI of its own (pure Python on torch/librosa): the
+ * drop-in boundary is its Python import surface.  Each entry
+ * point below states which reference lines it replaces; the Python shells in
+ * packages/ (same names/signatures as the reference) bind them with ctypes,
+ * see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensor
+ *     storage, passed as data_ptr()), fp32 row-major unless stated;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     kernels are enqueued on it and the call never synchronises;
+ *   - the library allocates no user-visible memory; scratch comes from the
+ *     caller (sizes from the *_workspace_bytes queries);
+ *   - return 0 on success, non-zero (hipError_t or DVAE_E_*) on failure;
+ *     dvae_last_error() returns a thread-local message; no exception crosses.
+ */
+#ifndef DVAE_H
+#define DVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVAE_ABI_VERSION 1
+
+enum { DVAE_E_BADARG = 1001, DVAE_E_WORKSPACE = 1002, DVAE_E_UNSUPPORTED = 1003 };
+
+/* activations of the fused Linear+act kernels */
+enum { DVAE_ACT_NONE = 0, DVAE_ACT_TANH = 1, DVAE_ACT_RELU = 2, DVAE_ACT_SIGMOID = 3, DVAE_ACT_EXP = 4 };
+
+int         dvae_abi_version(void);
+const char* dvae_last_error(void);
+/* number of HIP devices visible to the library (0 when none): lets the host fail loudly */
+int         dvae_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Layer-level ops: what packages/models/models.py modules call per nn.Linear.
+ * ------------------------------------------------------------------------- */
+
+/* out[B,N] = act([x0 | x1] @ W^T + bias)            (x1 may be NULL, k1 = 0)
+ * replaces `x = torch.tanh(layer(x))` / `torch.relu(layer(x))` / `torch.sigmoid(...)` /
+ * `torch.exp(self.reconstruction(x))` and the `torch.cat([x, y], dim=1)` in front of it:
+ * packages/models/models.py:57-63, 102-105, 119-122, 201-202.  W is nn.Linear layout [N, k0+k1]. */
+int dvae_linear_act_fwd(const float* x0, int k0, int ld0, const float* x1, int k1, int ld1,
+                        const float* W, int ldw, const float* bias,
+                        float* out, int ldo, int64_t B, int N, int act, void* stream);
+
+/* dpre[B,N] = dout * act'(out)  (act' expressed through the OUTPUT: tanh 1-o^2, relu o>0,
+ * sigmoid o(1-o), exp o); autograd of the activations above. */
+int dvae_act_bwd(const float* dout, int ldd, const float* out, int ldo, float* dpre, int ldp,
+                 int64_t B, int N, int act, void* stream);
+
+/* din[B,K] (+)= dpre[B,N] @ W[:, koff:koff+K]     (autograd of F.linear wrt its input);
+ * accumulate != 0 adds into din (sum of the mu / log_var heads, models.py:34-36). */
+int dvae_linear_bwd_data(const float* dpre, int ldp, const float* W, int ldw, int koff,
+                         float* din, int ldi, int64_t B, int N, int K, int accumulate, void* stream);
+
+/* dW[N, k0+k1] = dpre^T @ [x0 | x1],  db[N] = colsum(dpre)   (autograd of F.linear wrt W, b).
+ * Reduction over the B frames is split over `ksplit` workgroup slices combined with fp32
+ * atomics when ksplit > 1 (pass 0 to let the library choose).  db may be NULL. */
+int dvae_linear_bwd_weight(const float* dpre, int ldp, const float* x0, int k0, int ld0,
+                           const float* x1, int k1, int ld1, float* dW, int ldw, float* db,
+                           int64_t B, int N, int ksplit, void* stream);
+
+/* z = mu + exp(0.5*logvar) * eps     packages/models/models.py:9-22 (Stochastic.reparametrize) */
+int dvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,
+                     int64_t n, void* stream);
+/* dmu = dz ; dlogvar = dz * eps * 0.5 * exp(0.5*logvar) */
+int dvae_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu,
+                     float* dlogvar, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Losses: packages/models/utils.py
+ * ------------------------------------------------------------------------- */
+
+/* elbo(x, r, mu, logvar, eps) -> out3 = {recon+KL, recon, KL}   utils.py:73-76.
+ * recon = mean_b sum_f (x/r - log(x+eps) + log r - 1); KL = -0.5 mean_b sum_k (lv - mu^2 - e^lv).
+ * Also writes kl_b[B] = per-frame KL (models.py:165-167 `_kld_v2`) when kl_b != NULL.
+ * ws: dvae_elbo_workspace_bytes(B) bytes of scratch. */
+size_t dvae_elbo_workspace_bytes(int64_t B);
+int dvae_elbo_fwd(const float* x, int ldx, const float* r, int ldr, const float* mu,
+                  const float* logvar, float eps, int64_t B, int F, int Z,
+                  float* out3, float* kl_b, void* ws, void* stream);
+/* gradients of g2[0]*recon + g2[1]*KL wrt r, mu, logvar; g2 = DEVICE pointer to
+ * {g_loss + g_recon, g_loss + g_kl} (the upstream grads of the three returned scalars). */
+int dvae_elbo_bwd(const float* x, int ldx, const float* r, int ldr, const float* mu,
+                  const float* logvar, const float* g2, int64_t B, int F, int Z,
+                  float* dr, int lddr, float* dmu, float* dlogvar, void* stream);
+
+/* binary_cross_entropy family, utils.py:55-63: variant 0 = (r, x), 1 = _v2 (targets 0.5),
+ * 2 = _v3 (targets r).  out1 = -mean_b sum_j [t log(r+eps) + (1-t) log(1-r+eps)]. */
+int dvae_bce_fwd(const float* r, const float* t, float eps, int64_t B, int Y, int variant,
+                 float* out1, void* ws, void* stream);
+/* dr = g * d(bce)/dr ; dt (variant 0 only, may be NULL) */
+int dvae_bce_bwd(const float* r, const float* t, float eps, const float* g, int64_t B, int Y,
+                 int variant, float* dr, float* dt, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimiser: torch.optim.Adam(lr, betas) as the scripts construct it
+ * (scripts/training_M2.py:122); op order of torch's single-tensor Adam.
+ * ------------------------------------------------------------------------- */
+int dvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr,
+                   double beta1, double beta2, double eps, int step, double grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * STFT / ISTFT: packages/processing/stft.py:13-60, 63-99 (librosa semantics, center=False
+ * or pre-padded input), periodic Hann.  Indexing (pad rule, frame count) is decided on the
+ * host in double precision by the Python shell; the kernels take the final frame count.
+ * ------------------------------------------------------------------------- */
+
+/* x: n samples (already end-padded / centre-padded by the caller), in_f64 selects double input.
+ * out: layout 0 = [nfft/2+1, T] interleaved complex64 (column = frame, the librosa layout; the
+ *      same bytes are the legacy torch.stft real view [nfft/2+1, T, 2] of stft_pytorch,
+ *      packages/processing/stft.py:145-151);
+ *      layout 1 = [T, nfft/2+1] float32 power |.|^2 (one training frame per row,
+ *      scripts/create_train_set.py:152 / scripts/reconstruct_M2.py:153).
+ * window: nfft doubles (device).  Power-of-two nfft in [8, 2048] runs the LDS FFT; any other
+ * even nfft <= 2048 (e.g. the wrapper's never-used 800-sample default) runs a plain DFT. */
+int dvae_stft(const void* x, int in_f64, int64_t n, const double* window, int nfft, int hop,
+              int64_t T, void* out, int layout, void* stream);
+
+/* S: complex64 [nfft/2+1, ldT] of which the first T columns (frames) are used;
+ * y[out_len] float32 = overlap-add of window * irfft(S[:, t]) (float32 accumulation in frame
+ * order, as librosa), divided by the window sum-square where it exceeds FLT_MIN, read from
+ * sample `start` on, zero padded / trimmed to out_len.  ws: dvae_istft_workspace_bytes(T, nfft). */
+size_t dvae_istft_workspace_bytes(int64_t T, int nfft);
+int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,
+               int64_t start, float* y, int64_t out_len, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused train step (the build's own harness; mirrors scripts/training_M1.py:134-139,
+ * scripts/training_M2.py:142-147, scripts/training_M2_info_vad.py:159-198).
+ * Declared in dvae_train.h.
+ * ------------------------------------------------------------------------- */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVAE_H */

@@ -1,0 +1,136 @@
+"""Drop-in replacement for the reference's packages/models/utils.py (loss zoo).
+
+Hot-path losses -- `elbo` (reference utils.py:73-76) and the `binary_cross_entropy`
+family (:55-63) -- run as HIP reduction kernels with hand-written backward when
+their inputs are CUDA tensors (disentangled-vae_amd/ops.py: Elbo, Bce); host tensors
+take the reference's own ATen expression.  The remaining helpers are not on the hot
+path and stay plain tensor code with the reference's signatures.
+"""
+import torch
+from torch.autograd import Variable
+
+from packages import _native
+
+
+def enumerate_discrete(x, y_dim):
+    """All one-hot labels repeated for x's batch size: [y_dim * B, y_dim] (reference :5-28)."""
+    batch_size = x.size(0)
+    generated = torch.eye(y_dim).repeat_interleave(batch_size, dim=0)
+    if x.is_cuda:
+        generated = generated.cuda()
+    return Variable(generated.float())
+
+
+def onehot(k):
+    """label -> one-hot vector of length k (all zeros when label >= k) (reference :30-42)."""
+    def encode(label):
+        y = torch.zeros(k)
+        if label < k:
+            y[label] = 1
+        return y
+    return encode
+
+
+def log_sum_exp(tensor, dim=-1, sum_op=torch.sum):
+    """max-shifted log(sum_op(exp(.)) + 1e-8) (reference :44-53)."""
+    max, _ = torch.max(tensor, dim=dim, keepdim=True)
+    return torch.log(sum_op(torch.exp(tensor - max), dim=dim, keepdim=True) + 1e-8) + max
+
+
+def _on_gpu(*ts):
+    return any(t is not None and t.is_cuda for t in ts)
+
+
+def binary_cross_entropy(r, x, eps):
+    if _on_gpu(r, x):
+        return _native.ops().Bce.apply(r, x, eps, 0)
+    return -torch.mean(torch.sum(x * torch.log(r + eps) + (1 - x) * torch.log(1 - r + eps), dim=-1))
+
+
+def binary_cross_entropy_v2(r, eps):
+    if _on_gpu(r):
+        return _native.ops().Bce.apply(r, None, eps, 1)
+    return -torch.mean(torch.sum(0.5 * torch.log(r + eps) + 0.5 * torch.log(1 - r + eps), dim=-1))
+
+
+def binary_cross_entropy_v3(r, eps):
+    if _on_gpu(r):
+        return _native.ops().Bce.apply(r, None, eps, 2)
+    return -torch.mean(torch.sum(r * torch.log(r + eps) + (1 - r) * torch.log(1 - r + eps), dim=-1))
+
+
+def binary_cross_entropy_2classes(r1, r2, x, eps):
+    return -torch.mean(torch.sum(x * torch.log(r1 + eps) + (1 - x) * torch.log(r2 + eps), dim=-1))
+
+
+def _is_rows(x, r, eps):
+    # Itakura-Saito divergence per frame; note eps only inside log(x + eps) (reference :68-71)
+    return torch.sum(x / r - torch.log(x + eps) + torch.log(r) - 1, dim=-1)
+
+
+def _kl_rows(mu, logvar):
+    # KL without the "+1" (quirk Q2)
+    return -0.5 * torch.sum(logvar - mu.pow(2) - logvar.exp(), dim=-1)
+
+
+def ikatura_saito_divergence(r, x, eps):
+    return _is_rows(x, r, eps)
+
+
+def elbo(x, r, mu, logvar, eps):
+    """-> (recon + KL, recon, KL), 0-dim tensors (reference utils.py:73-76)."""
+    if _on_gpu(x, r, mu, logvar):
+        out = _native.ops().Elbo.apply(x, r, mu, logvar, eps)
+        return out[0], out[1], out[2]
+    recon = torch.mean(_is_rows(x, r, eps))
+    KL = torch.mean(_kl_rows(mu, logvar))
+    return recon + KL, recon, KL
+
+
+def L_loss(x, r, mu, logvar, eps):
+    recon = _is_rows(x, r, eps)
+    KL = _kl_rows(mu, logvar)
+    return recon + KL, recon, KL
+
+
+def U_loss(x, r, mu, logvar, y_hat_soft, eps):
+    """Unlabelled objective of the M2v3/v4 experiments (reference :83-105)."""
+    recon = _is_rows(x, r, eps)
+    KL = _kl_rows(mu, logvar)
+    L = (recon + KL)[..., None]
+    L_soft = torch.sum(torch.mul(y_hat_soft, L) + torch.mul(1 - y_hat_soft, L), dim=-1)
+    H = -torch.sum(torch.mul(y_hat_soft, torch.log(y_hat_soft + eps))
+                   + torch.mul(1 - y_hat_soft, torch.log(1 - y_hat_soft + eps)), dim=-1)
+    return torch.mean(L_soft + H), torch.mean(L), torch.mean(recon), torch.mean(KL)
+
+
+def mean_square_error_signal(x, y, y_hat):
+    return torch.mean(torch.sum(torch.square(torch.mul(y - y_hat, x)), axis=-1))
+
+
+def mean_square_error_mask(y, y_hat):
+    return torch.mean(torch.sum(torch.square(y - y_hat), axis=-1))
+
+
+def magnitude_spectrum_approxiamation_loss(x, s, y_hat):
+    d = s - y_hat * x
+    return torch.mean(torch.sum(torch.real(d * d.conj()), axis=-1))
+
+
+def f1_loss(y_hat_hard: torch.Tensor, y: torch.Tensor, epsilon=1e-8) -> torch.Tensor:
+    """-> (accuracy, precision, recall, f1) from hard 0/1 predictions (reference :120-159)."""
+    y_pred = y_hat_hard.detach()
+    y_true = y.detach()
+    assert y_true.ndim == 1
+    assert y_pred.ndim == 1 or y_pred.ndim == 2
+    if y_pred.ndim == 2:
+        y_pred = y_pred.argmax(dim=1)
+    tp = (y_true * y_pred).sum().to(torch.float32)
+    tn = ((1 - y_true) * (1 - y_pred)).sum().to(torch.float32)
+    fp = ((1 - y_true) * y_pred).sum().to(torch.float32)
+    fn = (y_true * (1 - y_pred)).sum().to(torch.float32)
+    accuracy = (tp + tn) / (tp + tn + fp + fn + epsilon)
+    precision = tp / (tp + fp + epsilon)
+    recall = tp / (tp + fn + epsilon)
+    f1 = 2 * (precision * recall) / (precision + recall + epsilon)
+    return accuracy, precision, recall, f1

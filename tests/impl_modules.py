@@ -1,0 +1,88 @@
+"""golden_check.StepImpl over the drop-in modules (packages.models) on a given device,
+driven exactly like the reference scripts drive them (stock torch.optim.Adam,
+loss.backward(), zero_grad())."""
+import numpy as np
+import torch
+
+from packages.models import models as M
+from packages.models.utils import elbo, binary_cross_entropy
+
+EPS = 1e-8
+LR = 1e-4
+ALPHA, BETA, GAMMA = 0.0, 10.0, 1.0
+
+
+def build_model(model, dims):
+    h = list(dims["h_dim"])
+    if model == "M1":
+        return M.VariationalAutoencoder([dims["x_dim"], dims["z_dim"], h])
+    if model == "M2":
+        return M.DeepGenerativeModel([dims["x_dim"], dims["y_dim"], dims["z_dim"], h], None)
+    return M.DeepGenerativeModel_v5([dims["x_dim"], dims["y_dim"], dims["z_dim"], h])
+
+
+class ModuleImpl:
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def load(self, model, dims, params):
+        self.model = model
+        self.m = build_model(model, dims)
+        self.m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        self.m.to(self.device)
+        self.named = dict(self.m.named_parameters())
+        if model == "M2_info":
+            self.opt = torch.optim.Adam(self.m.enc_dec_clf.parameters(), lr=LR, betas=(0.9, 0.999))
+            self.opt_aux = torch.optim.Adam(self.m.auxiliary.parameters(), lr=LR, betas=(0.9, 0.999))
+        else:
+            self.opt = torch.optim.Adam(self.m.parameters(), lr=LR, betas=(0.9, 0.999))
+
+    def _t(self, a):
+        return None if a is None else torch.from_numpy(a).to(self.device)
+
+    @staticmethod
+    def _np(t):
+        return t.detach().cpu().numpy().copy()
+
+    def step(self, x, y, e):
+        x, y, e = self._t(x), self._t(y), self._t(e)
+        m = self.m
+        M.Stochastic.epsilon_fn = lambda mu: e
+        try:
+            if self.model != "M2_info":
+                r, mu, lv = m(x) if self.model == "M1" else m(x, y)
+                loss, recon, kl = elbo(x, r, mu, lv, EPS)
+                loss.backward()
+                out = dict(r=self._np(r), mu=self._np(mu), logvar=self._np(lv),
+                           losses=(loss.item(), recon.item(), kl.item()),
+                           grads={k: self._np(p.grad) for k, p in self.named.items()})
+                if self.model == "M1":
+                    out["kl_divergence"] = self._np(m.kl_divergence)
+                self.opt.step(); self.opt.zero_grad()
+                return out
+            y_hat_class_soft = m.classify_fromX(x)
+            r, z, mu, lv = m(x, y)
+            ELBO, recon, kl = elbo(x, r, mu, lv, EPS)
+            classif_loss = ALPHA * binary_cross_entropy(y_hat_class_soft, y, EPS)
+            y_hat_aux_soft = m.classify_fromZ(z)
+            aux_enc_loss = BETA * binary_cross_entropy(y_hat_aux_soft, y, EPS)
+            enc_loss = ELBO + classif_loss - aux_enc_loss
+            y_hat_aux_soft2 = m.classify_fromZ(z.detach())
+            aux_loss = GAMMA * binary_cross_entropy(y_hat_aux_soft2, y, EPS)
+            enc_loss.backward()
+            out = dict(r=self._np(r), z=self._np(z), mu=self._np(mu), logvar=self._np(lv),
+                       y_hat_class_soft=self._np(y_hat_class_soft), y_hat_aux_soft=self._np(y_hat_aux_soft),
+                       losses=(ELBO.item(), recon.item(), kl.item(), enc_loss.item(), classif_loss.item(),
+                               aux_loss.item(), aux_enc_loss.item()),
+                       grads_enc={k: (np.zeros(tuple(p.shape), np.float32) if p.grad is None else self._np(p.grad))
+                                  for k, p in self.named.items()})
+            self.opt.step(); self.opt.zero_grad()
+            aux_loss.backward()
+            out["grads_aux_total"] = {k: self._np(p.grad) for k, p in self.named.items() if k.startswith("auxiliary.")}
+            self.opt_aux.step(); self.opt_aux.zero_grad()
+            return out
+        finally:
+            M.Stochastic.epsilon_fn = None
+
+    def params(self):
+        return {k: self._np(p) for k, p in self.named.items()}
