@@ -150,13 +150,13 @@ def test_adam_kernel_matches_torch_adam():
     opt = torch.optim.Adam([pt], lr=1e-4, betas=(0.9, 0.999))
     p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     for step in range(1, 6):
-        g = rng.standard_normal(n).astype(np.float32) * 10.0 ** rng.integers(-6, 2, n)
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 2, n)).astype(np.float32)
         if step == 3:
             g[:100] = 0.0
         pt.grad = torch.from_numpy(g.copy())
         opt.step()
         ops.adam_step_(p, dev(g), m, v, step)
-        np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=0, atol=3e-8 * step)
+        np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=2e-7, atol=3e-8 * step)
     # oracle too
     po, mo, vo_ = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
     po, mo, vo_ = vo.adam_step(po, g, mo, vo_, 1)
