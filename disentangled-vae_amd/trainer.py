@@ -1,0 +1,246 @@
+"""Fused train-step harness: the loop body of scripts/training_M1.py:134-139 /
+scripts/training_M2.py:142-147 (model forward, elbo, backward, Adam step, zero_grad) as
+three HIP launches over caller-owned flat buffers (include/dvae_train.h).
+
+PyTorch is plumbing here: it owns the device buffers, the stream and (for N > 1) the
+RCCL all-reduce of the flat gradient.  Parameters are exposed under the reference's
+state_dict names so checkpoints move both ways.  No fallback: unsupported geometries
+raise (the layer-level modules in packages/models cover them).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import native as N
+
+MAXT = 32
+
+
+class TrainPlan(ctypes.Structure):
+    _fields_ = [("model", ctypes.c_int32), ("y_dim", ctypes.c_int32), ("precision", ctypes.c_int32), ("ksplit", ctypes.c_int32),
+                ("B", ctypes.c_int64), ("n_tensors", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("n_params", ctypes.c_int64),
+                ("tensor_offset", ctypes.c_int64 * MAXT), ("tensor_rows", ctypes.c_int32 * MAXT), ("tensor_cols", ctypes.c_int32 * MAXT),
+                ("workspace_bytes", ctypes.c_int64), ("grad_offset_bytes", ctypes.c_int64), ("Bp", ctypes.c_int64),
+                ("rows_grid", ctypes.c_int64), ("flops_per_step", ctypes.c_double), ("min_hbm_bytes_per_step", ctypes.c_double)]
+
+
+MODEL_CODE = {"M1": 1, "M2": 2}
+PREC_CODE = {"fp32": 0, "bf16": 1}
+TENSOR_NAMES = ["encoder.hidden.0.weight", "encoder.hidden.0.bias", "encoder.hidden.1.weight", "encoder.hidden.1.bias",
+                "encoder.sample.mu.weight", "encoder.sample.mu.bias", "encoder.sample.log_var.weight", "encoder.sample.log_var.bias",
+                "decoder.hidden.0.weight", "decoder.hidden.0.bias", "decoder.hidden.1.weight", "decoder.hidden.1.bias",
+                "decoder.reconstruction.weight", "decoder.reconstruction.bias"]
+
+def _lib():
+    return N.load()
+
+
+def supported(model, dims):
+    return (model in MODEL_CODE and dims["x_dim"] == 513 and dims["z_dim"] == 16 and tuple(dims["h_dim"]) == (128, 128)
+            and ((model == "M1" and dims.get("y_dim", 0) in (0, None)) or (model == "M2" and dims["y_dim"] in (1, 513))))
+
+
+class Trainer:
+    """One object = one model replica on one GPU.
+
+    step(x, y, eps_noise) enqueues one full train step and returns a device tensor
+    [ELBO, recon, KL] (no host sync).  With `process_group` given (world > 1) the flat
+    gradient is summed over ranks with one RCCL all-reduce and scaled by 1 / world."""
+
+    def __init__(self, model, dims, params=None, batch=128, device="cuda:0", precision="fp32", lr=1e-4, betas=(0.9, 0.999),
+                 adam_eps=1e-8, elbo_eps=1e-8, process_group=None, world=1, ksplit=0, seed=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("Trainer needs the MI355X HIP path (no CPU fallback)")
+        if not supported(model, dims):
+            raise NotImplementedError(f"fused train step covers M1 / M2 at x 513, z 16, h [128,128], y in (0, 1, 513); got {model} {dims}")
+        self.lib = _lib()
+        self.model, self.dims, self.B = model, dict(dims), int(batch)
+        self.device = torch.device(device)
+        self.precision = precision
+        self.lr, self.betas, self.adam_eps, self.elbo_eps = lr, betas, adam_eps, elbo_eps
+        self.pg, self.world = process_group, int(world)
+        self.y_dim = 0 if model == "M1" else int(dims["y_dim"])
+        self.plan = TrainPlan()
+        N.check(self.lib.dvae_train_plan(MODEL_CODE[model], self.y_dim, PREC_CODE[precision], self.B, ksplit, ctypes.byref(self.plan)),
+                "dvae_train_plan")
+        P = self.plan.n_params
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(P, dtype=torch.float32, device=self.device)
+            self.m = torch.zeros(P, dtype=torch.float32, device=self.device)
+            self.v = torch.zeros(P, dtype=torch.float32, device=self.device)
+            self.ws = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
+            self.losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        go = self.plan.grad_offset_bytes
+        self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
+        self.step_count = 0
+        if params is None:
+            params = self._reference_init(seed)
+        self._write_params(params)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.dvae_train_init(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_init")
+
+    # ---- parameters under the reference's state_dict names ----
+    def _reference_init(self, seed):
+        """xavier_normal_ weights / zero bias drawn exactly like the reference constructs the model."""
+        from packages.models import models as M
+        if seed is not None:
+            torch.manual_seed(seed)
+        if self.model == "M1":
+            m = M.VariationalAutoencoder([513, 16, [128, 128]])
+        else:
+            m = M.DeepGenerativeModel([513, self.y_dim, 16, [128, 128]], None)
+        return {k: v.detach() for k, v in m.state_dict().items()}
+
+    def tensor_view(self, i):
+        o, r, c = self.plan.tensor_offset[i], self.plan.tensor_rows[i], self.plan.tensor_cols[i]
+        v = self.params[o:o + r * c]
+        return v.view(r, c) if TENSOR_NAMES[i].endswith("weight") else v
+
+    def _write_params(self, sd):
+        for i, name in enumerate(TENSOR_NAMES):
+            t = sd[name]
+            t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.detach()
+            view = self.tensor_view(i)
+            if tuple(t.shape) != tuple(view.shape):
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(view.shape)}")
+            view.copy_(t.to(torch.float32))
+
+    def load_state_dict(self, sd):
+        self._write_params(sd)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
+
+    def state_dict(self):
+        return {name: self.tensor_view(i).clone() for i, name in enumerate(TENSOR_NAMES)}
+
+    def state_dict_numpy(self):
+        return {k: v.cpu().numpy() for k, v in self.state_dict().items()}
+
+    def grads_numpy(self):
+        """Flat gradient of the last step (sum of the k-split slabs), per tensor, as numpy."""
+        P, ks = self.plan.n_params, self.plan.ksplit
+        go = self.plan.grad_offset_bytes
+        slabs = self.ws[go:go + 4 * P * ks].view(torch.float32).view(ks, P)
+        flat = slabs[:self._used_slabs()].sum(0) if not self._reduced else slabs[0]
+        out = {}
+        for i, name in enumerate(TENSOR_NAMES):
+            o, r, c = self.plan.tensor_offset[i], self.plan.tensor_rows[i], self.plan.tensor_cols[i]
+            g = flat[o:o + r * c].cpu().numpy()
+            out[name] = g.reshape(r, c) if name.endswith("weight") else g
+        return out
+
+    def _used_slabs(self):
+        unit = 4 * (16 if self.precision == "bf16" else 8)
+        per = -(-self.plan.Bp // self.plan.ksplit)
+        kper = -(-per // unit) * unit
+        return -(-self.plan.Bp // kper)
+
+    _reduced = False
+
+    # ---- one train step ----
+    def step(self, x, y=None, eps_noise=None):
+        B = self.B
+        if x.shape != (B, 513) or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError(f"x must be a float32 CUDA tensor [{B}, 513]")
+        if eps_noise is None:
+            eps_noise = torch.randn((B, 16), dtype=torch.float32, device=x.device)
+        if self.y_dim:
+            if y is None or y.shape != (B, self.y_dim) or y.dtype != torch.float32:
+                raise ValueError(f"y must be a float32 CUDA tensor [{B}, {self.y_dim}]")
+        x = x if x.stride(1) == 1 else x.contiguous()
+        eps_noise = eps_noise.contiguous()
+        yp, ldy = (None, 0)
+        if self.y_dim:
+            y = y if y.stride(1) == 1 else y.contiguous()
+            yp, ldy = N.ptr(y), N.ld(y)
+        self.step_count += 1
+        plan = ctypes.byref(self.plan)
+        s = N.stream()
+        if self.world == 1:
+            N.check(self.lib.dvae_train_step(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), N.ptr(x), N.ld(x),
+                                             yp, ldy, N.ptr(eps_noise), self.elbo_eps, self.step_count, self.lr, self.betas[0],
+                                             self.betas[1], self.adam_eps, N.ptr(self.losses), s), "dvae_train_step")
+            self._reduced = False
+        else:
+            import torch.distributed as dist
+            N.check(self.lib.dvae_train_grads(plan, N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
+                                              self.elbo_eps, 1, s), "dvae_train_grads")
+            dist.all_reduce(self.flat_grad, group=self.pg)          # RCCL over xGMI: one flat fp32 buffer per step
+            N.check(self.lib.dvae_train_apply(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), 1, self.step_count,
+                                              self.lr, self.betas[0], self.betas[1], self.adam_eps, 1.0 / self.world,
+                                              N.ptr(self.losses), s), "dvae_train_apply")
+            self._reduced = True
+        return self.losses
+
+    def grads_only(self, x, y, eps_noise, reduce=False):
+        """rows + wgrad kernels without the optimiser (tests / gradient inspection)."""
+        yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
+        N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
+                                          N.ptr(eps_noise.contiguous()), self.elbo_eps, 1 if reduce else 0, N.stream()), "dvae_train_grads")
+        self._reduced = bool(reduce)
+
+    # ---- per-kernel device time (hipEvents on the launch stream) ----
+    def profile(self, enable):
+        self.lib.dvae_train_profile(1 if enable else 0)
+
+    def profile_read(self):
+        ms = (ctypes.c_double * 4)()
+        calls = (ctypes.c_int64 * 4)()
+        N.check(self.lib.dvae_train_profile_read(ctypes.byref(ms), ctypes.byref(calls)), "dvae_train_profile_read")
+        names = ["rows", "wgrad", "reduce", "apply"]
+        return {n: (ms[i], calls[i]) for i, n in enumerate(names)}
+
+
+class BenchImpl:
+    """bench.py adapter: the fused path."""
+
+    def __init__(self, model, dims, B, device, world, precision):
+        pg = None
+        if world > 1:
+            import torch.distributed as dist
+            pg = dist.group.WORLD
+        self.tr = Trainer(model, dims, None, batch=B, device=device, precision=precision, process_group=pg, world=world, seed=0)
+        self.dtype = "bf16" if precision == "bf16" else "f32"
+        self.name = f"fused(rows+wgrad+apply HIP kernels, {precision} MFMA operands, fp32 accumulate/master)"
+        self.model, self.dims, self.B, self.precision = model, dims, B, precision
+
+    def step(self, x, y, e):
+        return self.tr.step(x, y, e)
+
+    def kernel_profile(self, batches, steps):
+        """Per-kernel device time over `steps` steps -> roofline dict for the dominant kernel."""
+        tr = self.tr
+        torch.cuda.synchronize()
+        tr.profile(True)
+        for i in range(steps):
+            tr.step(*batches[i % len(batches)])
+        prof = tr.profile_read()
+        tr.profile(False)
+        avg = {k: (ms / c * 1e3 if c else 0.0) for k, (ms, c) in prof.items()}      # us per launch
+        dom = max(avg, key=lambda k: avg[k])
+        plan = tr.plan
+        B = plan.B
+        y = plan.y_dim
+        ye = y if self.model == "M2" else 0
+        mac = 128 * (513 + ye) + 128 * 128 + 2 * 16 * 128 + 128 * (16 + y) + 128 * 128 + 513 * 128
+        dxm = 128 * 128 + 2 * 16 * 128 + 16 * 128 + 128 * 128 + 513 * 128
+        flops = {"rows": 2.0 * (mac + dxm) * B, "wgrad": 2.0 * mac * B, "apply": 0.0, "reduce": 0.0}
+        # algorithmic bytes: what an ideally fused step must move: x, y, eps once for the
+        # rows kernel; the wgrad operands (activations + their gradients) for the split design
+        esz = 2 if self.precision == "bf16" else 4
+        stash_rows = 513 + y + 6 * 128 + 32 + 16 + 128 * 2 + 513
+        byts = {"rows": 4.0 * (513 + y + 16) * B, "wgrad": float(esz * stash_rows * B), "apply": 16.0 * plan.n_params, "reduce": 0.0}
+        dur = avg[dom] * 1e-6
+        peak_f = 2500.0 if self.precision == "bf16" else 157.3
+        t_m = flops[dom] / (peak_f * 1e12)
+        t_h = byts[dom] / 8.0e12
+        if t_m >= t_h:
+            bound, ach, peak, unit = "mfma", flops[dom] / dur / 1e12, peak_f, "TFLOP/s"
+        else:
+            bound, ach, peak, unit = "hbm", byts[dom] / dur / 1e9, 8000.0, "GB/s"
+        return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+                "kernel": {"rows": "vae_rows_kernel", "wgrad": "wgrad_kernel", "apply": "apply_kernel", "reduce": "slab_reduce_kernel"}[dom],
+                "avg_us": avg, "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
+                "mfma_frac": flops[dom] / dur / 1e12 / peak_f, "hbm_frac": byts[dom] / dur / 8.0e12,
+                "timing": "hipEventElapsedTime around each launch on the launch stream, mean over %d steps" % steps}

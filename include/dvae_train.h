@@ -1,0 +1,94 @@
+/* dvae_train.h -- C ABI of the fused train step (libdvae_hip.so).
+ *
+ * One step = the loop body of the reference's training scripts
+ *   scripts/training_M1.py:134-139   r, mu, logvar = model(x); elbo; backward; Adam.step; zero_grad
+ *   scripts/training_M2.py:142-147   the same with model(x, y)
+ * for the only geometry those scripts use (x_dim 513, z_dim 16, h_dim [128, 128]; y_dim 0, 1 or 513),
+ * in three launches:
+ *   rows kernel  : per 32-frame tile, the whole forward (encoder, reparametrisation, decoder),
+ *                  the Itakura-Saito + KL sums and every backward-data product, on chip;
+ *                  writes the operands of the weight gradients, transposed, to a stash;
+ *   wgrad kernel : dW = dPre^T @ In for all layers (reduction over frames), k-split slabs;
+ *   apply kernel : sums the slabs, torch.optim.Adam update of the fp32 master parameters,
+ *                  refreshes the kernel-layout weight copies, finalises the loss scalars.
+ * All state lives in caller-owned device buffers (PyTorch tensors): parameters / Adam
+ * moments as flat fp32 buffers laid out per dvae_train_plan_t, scratch in `ws`.
+ */
+#ifndef DVAE_TRAIN_H
+#define DVAE_TRAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DVAE_MODEL_M1 = 1, DVAE_MODEL_M2 = 2 };
+enum { DVAE_PREC_F32 = 0, DVAE_PREC_BF16 = 1 };
+#define DVAE_TRAIN_MAX_TENSORS 32
+
+typedef struct {
+    /* inputs (echoed) */
+    int32_t model;            /* DVAE_MODEL_* */
+    int32_t y_dim;            /* 0 (M1), 1 or 513 (M2) */
+    int32_t precision;        /* DVAE_PREC_*: matrix-core operand type (accumulation is always fp32) */
+    int32_t ksplit;           /* frame-axis slices of the weight-gradient reduction */
+    int64_t B;                /* frames per step */
+    /* flat fp32 parameter buffer: the reference's state_dict tensors, in state_dict order,
+       each contiguous in nn.Linear layout [out, in] at a 256-byte aligned offset */
+    int32_t n_tensors;
+    int32_t reserved0;
+    int64_t n_params;                                   /* flat length in floats (with alignment gaps) */
+    int64_t tensor_offset[DVAE_TRAIN_MAX_TENSORS];      /* in floats */
+    int32_t tensor_rows[DVAE_TRAIN_MAX_TENSORS];
+    int32_t tensor_cols[DVAE_TRAIN_MAX_TENSORS];        /* 1 for biases */
+    /* scratch */
+    int64_t workspace_bytes;
+    int64_t grad_offset_bytes;   /* ws + this = ksplit slabs of n_params floats (slab 0 = flat gradient after reduce) */
+    int64_t Bp;                  /* frames padded to the stash row length */
+    int64_t rows_grid;           /* workgroups of the rows kernel */
+    /* algorithmic work per step, for roofline accounting */
+    double  flops_per_step;
+    double  min_hbm_bytes_per_step;
+} dvae_train_plan_t;
+
+/* Fill `plan` for (model, y_dim, precision, B).  ksplit_hint 0 = choose.  Returns DVAE_E_UNSUPPORTED
+ * for geometries the fused kernels do not cover (the layer-level path of dvae.h covers those). */
+int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_hint, dvae_train_plan_t* plan);
+
+/* One-time setup of `ws` (zero fill, tile table, kernel-layout weight copies from `params`).
+ * Synchronises the stream once (host-to-device copy of the tile table). */
+int dvae_train_init(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream);
+
+/* rows kernel + wgrad kernel (+ slab reduction into slab 0 when reduce_slabs != 0).
+ * x [B, 513] (ldx), y [B, y_dim] (ldy, may be NULL for M1), eps_noise [B, 16]: fp32 device tensors.
+ * elbo_eps is the `eps` of elbo(x, r, mu, logvar, eps) (packages/models/utils.py:73). */
+int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                     const float* y, int ldy, const float* eps_noise, float elbo_eps, int reduce_slabs, void* stream);
+
+/* apply kernel: g = grad_scale * sum of n_slabs slabs; Adam(lr, beta1, beta2, adam_eps) at `step` (1-based) on
+ * params/m/v; refresh weight copies; losses3 = {recon + KL, recon, KL} (means over the B local frames). */
+int dvae_train_apply(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws, int n_slabs,
+                     int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale,
+                     float* losses3, void* stream);
+
+/* dvae_train_grads + dvae_train_apply (single-GPU step). */
+int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws,
+                    const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
+                    int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream);
+
+/* Rebuild the kernel-layout weight copies after `params` was written from outside (load_state_dict). */
+int dvae_train_repack(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream);
+
+/* Per-kernel device time of the last `dvae_train_*` calls made with profiling enabled:
+ * enable != 0 brackets each launch with hipEvents on its stream (a few us of host cost each).
+ * dvae_train_profile_read synchronises and returns accumulated ms and launch counts
+ * for {rows, wgrad, reduce, apply}, then clears them. */
+int dvae_train_profile(int enable);
+int dvae_train_profile_read(double ms[4], int64_t calls[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVAE_TRAIN_H */

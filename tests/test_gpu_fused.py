@@ -1,0 +1,136 @@
+"""GPU parity of the fused train step (disentangled-vae_amd/trainer.py -> dvae_train_* C ABI):
+golden vectors from the reference (fp32 operand mode, the parity mode), the numpy oracle at
+BASELINE.json's batch size, ragged batches, determinism, and the bf16 operand mode with its
+measured deviation stated."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from golden_check import check_case
+from oracle import vae_oracle as vo
+
+pytestmark = pytest.mark.gpu
+trainer = importlib.import_module("disentangled-vae_amd.trainer")
+
+FULL = [c for c in gu.CASES if c[0] in ("M1_full", "M2_full_y1", "M2_full_y513", "M2_full_y513_hot")]
+
+
+class FusedImpl:
+    def __init__(self, precision="fp32", ksplit=0):
+        self.precision, self.ksplit = precision, ksplit
+
+    def load(self, model, dims, params):
+        self.model, self.dims, self.p0 = model, dims, params
+        self.tr = None
+
+    def step(self, x, y, e):
+        if self.tr is None:
+            self.tr = trainer.Trainer(self.model, self.dims, self.p0, batch=x.shape[0], precision=self.precision, ksplit=self.ksplit)
+        t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+        losses = self.tr.step(t(x), t(y), t(e)).cpu().numpy().astype(np.float64)
+        return dict(losses=tuple(losses), grads=self.tr.grads_numpy())
+
+    def params(self):
+        return self.tr.state_dict_numpy()
+
+
+@pytest.mark.parametrize("case", FULL, ids=[c[0] for c in FULL])
+def test_fused_fp32_matches_reference_vectors(vae_golden, case):
+    check_case(FusedImpl("fp32"), vae_golden, case)
+
+
+def _oracle_step(model, dims, params, x, y, e):
+    p = {k: v.copy() for k, v in params.items()}
+    opt = vo.AdamState(list(p))
+    out, grads = vo.train_step_vae(model, p, opt, x, y, e)
+    return out, grads, p
+
+
+def _relmax(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M1", 0, 8192), ("M2", 1, 1000), ("M2", 513, 33), ("M1", 0, 1)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_step_vs_oracle(model, y_dim, B, precision):
+    """fp32 operand mode: <= 1e-4 relative (north_star bar) on losses and gradients.
+    bf16 operand mode (throughput mode): bf16 rounding of operands, fp32 accumulation; measured
+    deviation bound stated here: losses 2e-3 relative, gradients 3e-2 of the tensor's max."""
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 11)
+    x, y, e = gu.make_batch(dims, B, 12)
+    out, grads, p_after = _oracle_step(model, dims, params, x.astype(np.float64), None if y is None else y.astype(np.float64),
+                                       e.astype(np.float64))
+    tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+    ref = np.array([out["loss"], out["recon"], out["kl"]])
+    ltol, gtol = (1e-4, 1e-4) if precision == "fp32" else (2e-3, 3e-2)
+    np.testing.assert_allclose(losses, ref, rtol=ltol)
+    g = tr.grads_numpy()
+    for k in grads:
+        assert _relmax(g[k], np.asarray(grads[k], np.float64).reshape(g[k].shape)) < gtol, k
+    pn = tr.state_dict_numpy()
+    for k in params:
+        assert np.max(np.abs(pn[k] - params[k])) <= 1.05e-4          # one Adam step at lr 1e-4
+        assert np.all(np.isfinite(pn[k]))
+
+
+def test_fused_is_deterministic_and_ksplit_invariant():
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 3)
+    x, y, e = gu.make_batch(dims, 4096, 4)
+    t = lambda a: torch.from_numpy(a).cuda()
+    res = []
+    for ks in (0, 0, 1, 3):
+        tr = trainer.Trainer("M2", dims, params, batch=4096, precision="fp32", ksplit=ks)
+        for _ in range(2):
+            losses = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+        res.append((losses, tr.state_dict_numpy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k           # bitwise reproducible run to run
+        for other in res[2:]:
+            assert np.max(np.abs(res[0][1][k] - other[1][k])) <= 2.1e-4   # slab count only reorders fp32 sums
+
+
+def test_fused_matches_layer_level_path_at_full_batch():
+    """The two product paths (fused trainer, drop-in modules + autograd + torch Adam) agree at B = 8192."""
+    from impl_modules import ModuleImpl
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 5)
+    x, y, e = gu.make_batch(dims, 8192, 6)
+    mi = ModuleImpl("cuda")
+    mi.load("M2", dims, {k: v.copy() for k, v in params.items()})
+    out = mi.step(x, y, e)
+    tr = trainer.Trainer("M2", dims, params, batch=8192, precision="fp32")
+    t = lambda a: torch.from_numpy(a).cuda()
+    losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+    np.testing.assert_allclose(losses, out["losses"], rtol=2e-5)
+    g = tr.grads_numpy()
+    for k in params:
+        assert _relmax(g[k], out["grads"][k].astype(np.float64)) < 5e-5, k
+
+
+def test_state_dict_round_trip_and_repack():
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    tr = trainer.Trainer("M2", dims, None, batch=64, precision="bf16", seed=0)
+    sd = tr.state_dict()
+    from packages.models.models import DeepGenerativeModel
+    torch.manual_seed(0)
+    m = DeepGenerativeModel([513, 1, 16, [128, 128]], None)
+    for k, v in m.state_dict().items():
+        assert torch.equal(sd[k].cpu(), v), k                        # same seeded init as the drop-in module
+    m.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    x, y, e = gu.make_batch(dims, 64, 1)
+    t = lambda a: torch.from_numpy(a).cuda()
+    l1 = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+    tr2 = trainer.Trainer("M2", dims, gu.make_params("M2", dims, 99), batch=64, precision="bf16")
+    tr2.load_state_dict({k: v for k, v in sd.items()})
+    l2 = tr2.step(t(x), t(y), t(e)).cpu().numpy()
+    np.testing.assert_array_equal(l1, l2)
+    with pytest.raises(NotImplementedError):
+        trainer.Trainer("M2", dict(x_dim=513, y_dim=7, z_dim=16, h_dim=(128, 128)), None, batch=8)
