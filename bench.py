@@ -126,11 +126,24 @@ class ModulesImpl:
         return None
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(model, dims, B, seconds):
     """The reference's CPU loop body (oracle/torch_ref.py, kind "port") on this node's host cores."""
     from oracle import torch_ref as tr
     import golden_util as gu
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     torch.set_num_threads(ncores)
     d = dict(x_dim=dims["x_dim"], y_dim=max(dims["y_dim"], 1) if model != "M1" else 1, z_dim=dims["z_dim"], h_dim=dims["h_dim"])
     p = tr.init_params(model, seed=0, **d)

@@ -91,37 +91,64 @@ template <typename T> struct Ld {
 
 __device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// acc += W[rows of this lane][k-block] * act^T : NSTEPS fragment pairs, weights prefetched
-// CH steps ahead straight from global memory, activations from LDS.
+// First CH weight fragments of a GEMM, loaded ahead of time (weights never depend on data, so the
+// next layer's first fragments are requested before the current layer's epilogue and barrier).
+template <typename P, int NSTEPS> struct WPre {
+    static constexpr int N = NSTEPS < 4 ? NSTEPS : 4;
+    typename P::Frag a[N > 0 ? N : 1];
+};
+
 template <typename P, int NSTEPS>
-__device__ __forceinline__ void gemm_block(f32x16& acc, const typename P::T* __restrict__ wrow, const typename P::T* brow) {
+__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow) {
     typedef typename P::Frag Frag;
-    constexpr int CH = 8;
+#pragma unroll
+    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = *reinterpret_cast<const Frag*>(wrow + i * 2 * P::E);
+}
+
+// acc += W[rows of this lane][k-block] * act^T : NSTEPS fragment pairs.  Weights stream straight
+// from global memory one chunk (CH steps) ahead of the MFMAs that consume them; activations come
+// from LDS.  The chunk loop is deliberately NOT unrolled: it bounds the live fragment registers.
+template <typename P, int NSTEPS>
+__device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow,
+                                           const typename P::T* brow) {
+    typedef typename P::Frag Frag;
+    constexpr int CH = 4;
     constexpr int STR = 2 * P::E;
-    Frag a[CH], an[CH];
+    constexpr int NFULL = NSTEPS / CH, REM = NSTEPS % CH;
+    Frag a[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i)
-        if (i < NSTEPS) a[i] = *reinterpret_cast<const Frag*>(wrow + i * STR);
+        if (i < WPre<P, NSTEPS>::N) a[i] = w.a[i];
+    if (NFULL > 0) {
+#pragma unroll 1
+        for (int c = 0; c < NFULL; ++c) {
+            Frag an[CH];
 #pragma unroll
-    for (int s0 = 0; s0 < NSTEPS; s0 += CH) {
+            for (int i = 0; i < CH; ++i) {
+                int sn = (c + 1) * CH + i;
+                sn = sn < NSTEPS ? sn : NSTEPS - 1;        // clamp (redundant reload) instead of a branch around the load
+                an[i] = *reinterpret_cast<const Frag*>(wrow + sn * STR);
+            }
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (s0 + CH + i < NSTEPS) an[i] = *reinterpret_cast<const Frag*>(wrow + (s0 + CH + i) * STR);
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (s0 + i < NSTEPS) {
-                const Frag b = *reinterpret_cast<const Frag*>(brow + (s0 + i) * STR);
+            for (int i = 0; i < CH; ++i) {
+                const Frag b = *reinterpret_cast<const Frag*>(brow + (c * CH + i) * STR);
                 P::mma(acc, a[i], b);
             }
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (s0 + CH + i < NSTEPS) a[i] = an[i];
+            for (int i = 0; i < CH; ++i) a[i] = an[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+        const Frag b = *reinterpret_cast<const Frag*>(brow + (NFULL * CH + i) * STR);
+        P::mma(acc, a[i], b);
     }
 }
 
 struct RowsArgs {
     const float* x; const float* y; const float* eps;
     int ldx, ldy, ydim;
+    int fastx, fasty;      // rows are dense (ld == 513) and 16-byte aligned: whole-tile vector loads
     int64_t B, Bp;
     int ntiles;
     float invB, elbo_eps;
@@ -158,7 +185,7 @@ __device__ __forceinline__ void put_tile(const float (&v)[16], typename P::T* ld
     }
 }
 
-// global [32 frames][ncols] fp32 (row stride ld) -> LDS U[frame][col] as T, zero padded to `pcols`
+// generic (edge tile / strided / unaligned input): global [32 frames][ncols] fp32 -> LDS as T, zero padded
 template <typename P>
 __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, int ld, int ncols, int pcols, int64_t b0, int64_t B,
                                                  typename P::T* U, int ldu, int tid) {
@@ -168,6 +195,40 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
         float v = 0.f;
         if (col < ncols && b0 + row < B) v = src[(b0 + row) * ld + col];
         U[row * ldu + col] = P::cvt(v);
+    }
+}
+
+// dense 513-column tile: the 32 rows are ONE contiguous 16-byte aligned block of 4104 float4
+constexpr int NV513 = TB * XD / 4;
+constexpr int NQ513 = (NV513 + 255) / 256;       // 17 float4 per thread
+__device__ __forceinline__ void tile513_issue(const float* __restrict__ tile, f32x4 (&v)[NQ513], int tid) {
+#pragma unroll
+    for (int i = 0; i < NQ513; ++i) {
+        int q = tid + 256 * i;
+        q = q < NV513 ? q : NV513 - 1;            // clamp instead of branching around the load
+        v[i] = reinterpret_cast<const f32x4*>(tile)[q];
+    }
+}
+template <typename P, int PCOLS>
+__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid) {
+#pragma unroll
+    for (int i = 0; i < NQ513; ++i) {
+        const int q = tid + 256 * i;
+        if (q < NV513) {
+            const int base = 4 * q;
+            const int row = base / XD, col = base - row * XD;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                int c = col + jj, r = row;
+                if (c >= XD) { c -= XD; r += 1; }
+                U[r * ldu + c] = P::cvt(v[i][jj]);
+            }
+        }
+    }
+    constexpr int PADC = PCOLS - XD;
+    for (int idx = tid; idx < TB * PADC; idx += 256) {
+        const int r = idx / PADC, c = XD + idx - r * PADC;
+        U[r * ldu + c] = P::cvt(0.f);
     }
 }
 
@@ -189,6 +250,26 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
     }
 }
 
+// x[32 frames][f0 .. f0+127] (fp32) for the loss epilogue: 16 coalesced dwords per thread, addresses clamped
+__device__ __forceinline__ void xt_issue(const float* __restrict__ x, int ldx, int64_t b0, int64_t B, int f0, float (&xr)[16], int tid) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 7, col = idx & 127;
+        int64_t rg = b0 + row; rg = rg < B ? rg : B - 1;
+        int cg = f0 + col; cg = cg < XD ? cg : XD - 1;
+        xr[i] = x[rg * ldx + cg];
+    }
+}
+__device__ __forceinline__ void xt_commit(const float (&xr)[16], float* Xt, int ldxt, int64_t b0, int64_t B, int f0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 7, col = idx & 127;
+        Xt[row * ldxt + col] = (f0 + col < XD && b0 + row < B) ? xr[i] : 0.f;
+    }
+}
+
 template <typename P, int YP, bool YENC>
 __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     typedef typename P::T T;
@@ -197,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     constexpr int LDU = Ld<T>::u, LDH = Ld<T>::hh, LDZ = Ld<T>::z, LDX = Ld<T>::xt;
     constexpr int LD1 = XP + (YENC ? YP : 0);           // W1 shadow row length
     constexpr int LD3 = ZD + YP;                        // W3 shadow row length
+    constexpr bool Y513 = (YP == XP);                   // IBM labels: y has the same 513-column shape as x
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* U = reinterpret_cast<T*>(smem);
     T* Ha = U + TB * LDU;
@@ -208,31 +290,69 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int fb = 32 * wave;                           // this wave's feature block in 128-wide layers
-    const T* const W1s = (const T*)g.W1s; const T* const W2s = (const T*)g.W2s; const T* const Wmvs = (const T*)g.Wmvs;
-    const T* const W3s = (const T*)g.W3s; const T* const W4s = (const T*)g.W4s; const T* const W5s = (const T*)g.W5s;
-    const T* const W5t = (const T*)g.W5t; const T* const W4t = (const T*)g.W4t; const T* const W3zt = (const T*)g.W3zt;
-    const T* const Wmvt = (const T*)g.Wmvt; const T* const W2t = (const T*)g.W2t;
+    const T* const W1r = (const T*)g.W1s + (int64_t)(fb + l31) * LD1 + h * E;
+    const T* const W2r = (const T*)g.W2s + (int64_t)(fb + l31) * HD + h * E;
+    const T* const Wmvr = (const T*)g.Wmvs + (int64_t)l31 * HD + h * E;
+    const T* const W3r = (const T*)g.W3s + (int64_t)(fb + l31) * LD3 + h * E;
+    const T* const W4r = (const T*)g.W4s + (int64_t)(fb + l31) * HD + h * E;
+    const T* const W5s = (const T*)g.W5s;
+    const T* const W5tr = (const T*)g.W5t + (int64_t)(fb + l31) * NO + h * E;
+    const T* const W4tr = (const T*)g.W4t + (int64_t)(fb + l31) * HD + h * E;
+    const T* const W3ztr = (const T*)g.W3zt + (int64_t)l31 * HD + h * E;
+    const T* const Wmvtr = (const T*)g.Wmvt + (int64_t)(fb + l31) * 32 + h * E;
+    const T* const W2tr = (const T*)g.W2t + (int64_t)(fb + l31) * HD + h * E;
+    const T* const Ur = U + l31 * LDU + h * E;
+    const T* const Har = Ha + l31 * LDH + h * E;
+    const T* const Hbr = Hb + l31 * LDH + h * E;
+    const T* const Zbr = Zb + l31 * LDZ + h * E;
 
     double tot_rec = 0.0, tot_kl = 0.0;
 
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t b0 = (int64_t)tile * TB;
         const bool live = (b0 + l31) < g.B;             // this lane's frame exists
+        const bool full = (b0 + TB) <= g.B;
         float rec_lane = 0.f, kl_lane = 0.f;
+        // per-iteration opaque copy of the thread id: stops the compiler from hoisting the ~70 per-thread
+        // staging addresses out of the tile loop (they would live across the whole loop and spill)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
 
         // ---------------- encoder layer 1: [x | y] -> h1 ----------------
-        load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tid);
+        WPre<P, XP / KS> w1x;
+        wprefetch<P, XP / KS>(w1x, W1r);
+        if (g.fastx && full) {
+            f32x4 xv[NQ513];
+            tile513_issue(g.x + b0 * XD, xv, tl);
+            tile513_commit<P, XP>(xv, U, LDU, tl);
+        } else {
+            load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl);
+        }
         __syncthreads();
-        stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tid);
+        const bool yfast = Y513 && g.fasty && full;
+        stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
         f32x16 acc;
         zero_acc<P>(acc);
-        gemm_block<P, XP / KS>(acc, W1s + (int64_t)(fb + l31) * LD1 + h * E, U + l31 * LDU + h * E);
+        gemm_block<P, XP / KS>(acc, w1x, W1r, Ur);
+        WPre<P, HD / KS> w2;
+        WPre<P, (YENC ? YP : 0) / KS> w1y;
+        if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, W1r + XP);
+        else wprefetch<P, HD / KS>(w2, W2r);
         if (YP > 0) {
             __syncthreads();
-            load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tid);
+            if (Y513 && yfast) {
+                f32x4 yv[NQ513];
+                tile513_issue(g.y + b0 * XD, yv, tl);
+                tile513_commit<P, XP>(yv, U, LDU, tl);
+            } else {
+                load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl);
+            }
             __syncthreads();
-            stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tid);
-            if (YENC) gemm_block<P, YP / KS>(acc, W1s + (int64_t)(fb + l31) * LD1 + XP + h * E, U + l31 * LDU + h * E);
+            stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
+            if (YENC) {
+                gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, W1r + XP, Ur);
+                wprefetch<P, HD / KS>(w2, W2r);
+            }
         }
         float h1r[16];
 #pragma unroll
@@ -242,7 +362,11 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- encoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, W2s + (int64_t)(fb + l31) * HD + h * E, Ha + l31 * LDH + h * E);
+        gemm_block<P, HD / KS>(acc, w2, W2r, Har);
+        WPre<P, HD / KS> wmv;
+        WPre<P, ZD / KS> w3z;
+        if (wave == 0) wprefetch<P, HD / KS>(wmv, Wmvr);
+        wprefetch<P, ZD / KS>(w3z, W3r);
         float h2r[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + g.b2[fb + feat_of(r, h)]);
@@ -253,14 +377,15 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         float mu_r[8], lv_r[8], ep_r[8], sd_r[8];
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, Wmvs + (int64_t)l31 * HD + h * E, Hb + l31 * LDH + h * E);
+            gemm_block<P, HD / KS>(acc, wmv, Wmvr, Hbr);
             float zv[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int j = feat_of(r, h);                       // latent index 0..15
                 mu_r[r] = acc[r] + g.bmu[j];
                 lv_r[r] = acc[r + 8] + g.blv[j];
-                ep_r[r] = live ? g.eps[(b0 + l31) * ZD + j] : 0.f;
+                int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1;
+                ep_r[r] = live ? g.eps[br * ZD + j] : 0.f;
                 sd_r[r] = P::exp_(0.5f * lv_r[r]);                 // models.py:17
                 zv[r] = fmaf(sd_r[r], ep_r[r], mu_r[r]);           // models.py:20
                 zv[r + 8] = 0.f;
@@ -276,8 +401,14 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, ZD / KS>(acc, W3s + (int64_t)(fb + l31) * LD3 + h * E, Zb + l31 * LDZ + h * E);
-        if (YP > 0) gemm_block<P, YP / KS>(acc, W3s + (int64_t)(fb + l31) * LD3 + ZD + h * E, U + l31 * LDU + h * E);
+        gemm_block<P, ZD / KS>(acc, w3z, W3r, Zbr);
+        WPre<P, HD / KS> w4;
+        if (YP > 0) {
+            WPre<P, YP / KS> w3y;
+            wprefetch<P, YP / KS>(w3y, W3r + ZD);
+            gemm_block<P, YP / KS>(acc, w3y, W3r + ZD, Ur);
+        }
+        wprefetch<P, HD / KS>(w4, W4r);
         float d1r[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + g.b3[fb + feat_of(r, h)]);
@@ -286,7 +417,11 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- decoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, W4s + (int64_t)(fb + l31) * HD + h * E, Ha + l31 * LDH + h * E);
+        gemm_block<P, HD / KS>(acc, w4, W4r, Har);
+        WPre<P, HD / KS> w5;
+        wprefetch<P, HD / KS>(w5, W5s + (int64_t)(32 * wave + l31) * HD + h * E);
+        float xr[16];
+        xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
         float d2r[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + g.b4[fb + feat_of(r, h)]);
@@ -294,26 +429,26 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         __syncthreads();
 
         // ---------------- output layer a = W5 d2 + b5, Itakura-Saito terms, da -> U ----------------
+        WPre<P, NO / KS> w5t;
+#pragma unroll 1
         for (int it = 0; it < (NT_OUT + 3) / 4; ++it) {
-            const int f0 = 128 * it;
-            for (int idx = tid; idx < TB * 128; idx += 256) {      // x[32 frames][f0 .. f0+127] -> Xt
-                const int row = idx >> 7, col = idx & 127;
-                float v = 0.f;
-                if (f0 + col < XD && b0 + row < g.B) v = g.x[(b0 + row) * g.ldx + f0 + col];
-                Xt[row * LDX + col] = v;
-            }
+            xt_commit(xr, Xt, LDX, b0, g.B, 128 * it, tl);
             __syncthreads();
+            if (it + 1 < (NT_OUT + 3) / 4) xt_issue(g.x, g.ldx, b0, g.B, 128 * (it + 1), xr, tl);
             const int t = 4 * it + wave;
             if (t < NT_OUT) {
                 zero_acc<P>(acc);
-                gemm_block<P, HD / KS>(acc, W5s + (int64_t)(32 * t + l31) * HD + h * E, Hb + l31 * LDH + h * E);
+                const T* wr = W5s + (int64_t)(32 * t + l31) * HD + h * E;
+                gemm_block<P, HD / KS>(acc, w5, wr, Hbr);
+                if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wr + (int64_t)128 * HD);
+                else wprefetch<P, NO / KS>(w5t, W5tr);
                 float da[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int fl = feat_of(r, h);
                     const int f = 32 * t + fl;
                     const bool ok = live && f < XD;
-                    const float a = acc[r] + (f < XD ? g.b5[f] : 0.f);
+                    const float a = acc[r] + g.b5[f < XD ? f : XD - 1];
                     const float xv = Xt[l31 * LDX + 32 * wave + fl];
                     const float xe = xv * P::exp_(-a);               // x / r,  r = exp(a)  (models.py:122)
                     if (ok) rec_lane += xe - P::log_(xv + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
@@ -326,7 +461,9 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- backward: d2 <- da ----------------
         zero_acc<P>(acc);
-        gemm_block<P, NO / KS>(acc, W5t + (int64_t)(fb + l31) * NO + h * E, U + l31 * LDU + h * E);
+        gemm_block<P, NO / KS>(acc, w5t, W5tr, Ur);
+        WPre<P, HD / KS> w4t;
+        wprefetch<P, HD / KS>(w4t, W4tr);
         float dv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d2r[r] * d2r[r]);
@@ -335,7 +472,11 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- backward: d1 <- dpre_d2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, W4t + (int64_t)(fb + l31) * HD + h * E, Ha + l31 * LDH + h * E);
+        gemm_block<P, HD / KS>(acc, w4t, W4tr, Har);
+        WPre<P, HD / KS> w3zt;
+        WPre<P, 32 / KS> wmvt;
+        if (wave == 0) wprefetch<P, HD / KS>(w3zt, W3ztr);
+        wprefetch<P, 32 / KS>(wmvt, Wmvtr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d1r[r] * d1r[r]);
         put_tile<P>(dv, Hb, LDH, fb, (T*)g.dd1T, g.Bp, b0, l31, h);
@@ -344,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, W3zt + (int64_t)l31 * HD + h * E, Hb + l31 * LDH + h * E);
+            gemm_block<P, HD / KS>(acc, w3zt, W3ztr, Hbr);
             float dml[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -358,7 +499,9 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
         zero_acc<P>(acc);
-        gemm_block<P, 32 / KS>(acc, Wmvt + (int64_t)(fb + l31) * 32 + h * E, Zb + l31 * LDZ + h * E);
+        gemm_block<P, 32 / KS>(acc, wmvt, Wmvtr, Zbr);
+        WPre<P, HD / KS> w2t;
+        wprefetch<P, HD / KS>(w2t, W2tr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);
         put_tile<P>(dv, Ha, LDH, fb, (T*)g.dh2T, g.Bp, b0, l31, h);
@@ -366,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, W2t + (int64_t)(fb + l31) * HD + h * E, Ha + l31 * LDH + h * E);
+        gemm_block<P, HD / KS>(acc, w2t, W2tr, Har);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
         put_tile<P>(dv, nullptr, 0, fb, (T*)g.dh1T, g.Bp, b0, l31, h);
@@ -388,68 +531,112 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-struct TileDesc {
-    const void* A;       // stash rows of dPre^T for this tile's 32 output features
-    const void* Bm;      // stash rows of In^T for this tile's 32 input features
-    int64_t out_off;     // float offset of element (row 0, col 0) of this tile in a gradient slab
-    int64_t bias_off;    // float offset of the bias gradient rows, -1 = none
-    int32_t ldo, mvalid, nvalid, pad;
+// One wave = one 2x2 group of 32x32 MFMA tiles (64 output features x 64 input features of one
+// layer): per k-step it loads 2 + 2 operand fragments and issues 4 MFMAs, halving the bytes per
+// FLOP of a single-tile wave.  Missing halves (odd tile counts, 16-row heads) are null.
+struct GroupDesc {
+    const void* A[2];        // stash rows of dPre^T (32 output features each); A[1] may be null
+    const void* Bm[2];       // stash rows of In^T (32 input features each); Bm[1] may be null
+    int64_t out_off[2][2];   // float offset of tile (i, j) element (0, 0) in a gradient slab
+    int64_t bias_off[2];     // float offset of the bias gradient rows of A block i, -1 = none
+    int32_t ldo[2];          // row stride of the destination tensor of A block i
+    int32_t mvalid[2];
+    int32_t nvalid[2];
+    int32_t pad[2];
 };
 
-template <typename P>
-__global__ __launch_bounds__(256) void wgrad_kernel(const TileDesc* __restrict__ tiles, int ntiles, int64_t Bp, int64_t kper,
-                                                    float* __restrict__ slabs, int64_t slab_stride) {
+template <typename P, bool A1, bool B1>
+__device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int64_t kend, int64_t Bp, float* __restrict__ slab,
+                                           int l31, int h) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
-    constexpr int E = P::E, KS = P::KSTEP, CH = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int ti = blockIdx.x * 4 + wave;
-    if (ti >= ntiles) return;
-    const TileDesc d = tiles[ti];
-    const int64_t kbeg = (int64_t)blockIdx.y * kper;
-    int64_t kend = kbeg + kper;
-    if (kend > Bp) kend = Bp;
-    const T* arow = (const T*)d.A + (int64_t)l31 * Bp + h * E;
-    const T* brow = (const T*)d.Bm + (int64_t)l31 * Bp + h * E;
-    const bool bias = d.bias_off >= 0;
-    f32x16 acc, accb;
+    constexpr int E = P::E, KS = P::KSTEP, CH = 2;
+    const T* a0p = (const T*)d.A[0] + (int64_t)l31 * Bp + h * E;
+    const T* a1p = A1 ? (const T*)d.A[1] + (int64_t)l31 * Bp + h * E : a0p;
+    const T* b0p = (const T*)d.Bm[0] + (int64_t)l31 * Bp + h * E;
+    const T* b1p = B1 ? (const T*)d.Bm[1] + (int64_t)l31 * Bp + h * E : b0p;
+    const bool bias0 = d.bias_off[0] >= 0, bias1 = A1 && d.bias_off[1] >= 0;
+    f32x16 c00, c01, c10, c11, cb0, cb1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; accb[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; cb0[i] = 0.f; cb1[i] = 0.f; }
     const Frag one = P::ones();
-    Frag a[CH], b[CH], an[CH], bn[CH];
+    Frag a0[CH], a1[CH], b0[CH], b1[CH];
     if (kbeg < kend) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            a[i] = *reinterpret_cast<const Frag*>(arow + kbeg + i * KS);
-            b[i] = *reinterpret_cast<const Frag*>(brow + kbeg + i * KS);
+            a0[i] = *reinterpret_cast<const Frag*>(a0p + kbeg + i * KS);
+            b0[i] = *reinterpret_cast<const Frag*>(b0p + kbeg + i * KS);
+            if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + kbeg + i * KS);
+            if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + kbeg + i * KS);
         }
     }
+#pragma unroll 1
     for (int64_t k = kbeg; k < kend; k += CH * KS) {
         int64_t kn = k + CH * KS;
         if (kn >= kend) kn = k;                 // last pass: harmless reload instead of a branch around the loads
+        Frag a0n[CH], a1n[CH], b0n[CH], b1n[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            an[i] = *reinterpret_cast<const Frag*>(arow + kn + i * KS);
-            bn[i] = *reinterpret_cast<const Frag*>(brow + kn + i * KS);
+            a0n[i] = *reinterpret_cast<const Frag*>(a0p + kn + i * KS);
+            b0n[i] = *reinterpret_cast<const Frag*>(b0p + kn + i * KS);
+            if (A1) a1n[i] = *reinterpret_cast<const Frag*>(a1p + kn + i * KS);
+            if (B1) b1n[i] = *reinterpret_cast<const Frag*>(b1p + kn + i * KS);
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            P::mma(acc, a[i], b[i]);
-            if (bias) P::mma(accb, a[i], one);
+            P::mma(c00, a0[i], b0[i]);
+            if (B1) P::mma(c01, a0[i], b1[i]);
+            if (A1) P::mma(c10, a1[i], b0[i]);
+            if (A1 && B1) P::mma(c11, a1[i], b1[i]);
+            if (bias0) P::mma(cb0, a0[i], one);
+            if (A1) { if (bias1) P::mma(cb1, a1[i], one); }
         }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+        for (int i = 0; i < CH; ++i) {
+            a0[i] = a0n[i]; b0[i] = b0n[i];
+            if (A1) a1[i] = a1n[i];
+            if (B1) b1[i] = b1n[i];
+        }
     }
-    float* slab = slabs + (int64_t)blockIdx.y * slab_stride;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = feat_of(r, h);
-        if (row < d.mvalid) {
-            if (l31 < d.nvalid) slab[d.out_off + (int64_t)row * d.ldo + l31] = acc[r];
-            if (bias && l31 == 0) slab[d.bias_off + row] = accb[r];
+        if (row < d.mvalid[0]) {
+            if (l31 < d.nvalid[0]) slab[d.out_off[0][0] + (int64_t)row * d.ldo[0] + l31] = c00[r];
+            if (B1) { if (l31 < d.nvalid[1]) slab[d.out_off[0][1] + (int64_t)row * d.ldo[0] + l31] = c01[r]; }
+            if (bias0 && l31 == 0) slab[d.bias_off[0] + row] = cb0[r];
+        }
+        if (A1) {
+            if (row < d.mvalid[1]) {
+                if (l31 < d.nvalid[0]) slab[d.out_off[1][0] + (int64_t)row * d.ldo[1] + l31] = c10[r];
+                if (B1) { if (l31 < d.nvalid[1]) slab[d.out_off[1][1] + (int64_t)row * d.ldo[1] + l31] = c11[r]; }
+                if (bias1 && l31 == 0) slab[d.bias_off[1] + row] = cb1[r];
+            }
         }
     }
+}
+
+// grid.x = workgroups * ksplit with the k-slice as the FAST index: consecutive workgroups (dealt
+// round-robin to the 8 XCDs) work on different frame slices, so each XCD's L2 mostly holds one
+// slice of the stash.  blockDim.x / 64 groups per workgroup.
+template <typename P>
+__global__ __launch_bounds__(128) void wgrad_kernel(const GroupDesc* __restrict__ groups, int ngroups, int ksplit, int64_t Bp,
+                                                    int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int slice = blockIdx.x % ksplit, wg = blockIdx.x / ksplit;
+    const int gi = wg * (blockDim.x >> 6) + wave;
+    if (gi >= ngroups) return;
+    const GroupDesc d = groups[gi];
+    const int64_t kbeg = (int64_t)slice * kper;
+    int64_t kend = kbeg + kper;
+    if (kend > Bp) kend = Bp;
+    float* slab = slabs + (int64_t)slice * slab_stride;
+    const bool a1 = d.A[1] != nullptr, b1 = d.Bm[1] != nullptr;
+    if (a1 && b1) wgrad_body<P, true, true>(d, kbeg, kend, Bp, slab, l31, h);
+    else if (a1) wgrad_body<P, true, false>(d, kbeg, kend, Bp, slab, l31, h);
+    else if (b1) wgrad_body<P, false, true>(d, kbeg, kend, Bp, slab, l31, h);
+    else wgrad_body<P, false, false>(d, kbeg, kend, Bp, slab, l31, h);
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride) {
@@ -554,12 +741,13 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.dmlvT = rows(32); L.zT = rows(32); L.d1T = rows(HD); L.d2T = rows(HD); L.dd1T = rows(HD); L.dd2T = rows(HD); L.daT = rows(NO);
     rows(32);   // slack: the second head job reads 16 rows past dmlvT's 32 (masked on store)
     L.stash_rows = r;
-    // tiles: L1x 4x17, L1y 4x(ye/32), L2 4x4, heads 2x4, L3z 4x1, L3y 4x(yd/32), L4 4x4, L5 17x4
+    // 2x2 groups of 32x32 tiles per job: (pairs of A blocks) x (pairs of B blocks)
     const int nty = L.yp ? (int)(al(L.yp, 32) / 32) : 0;
-    L.ntiles = 4 * NT_OUT + (L.ye ? 4 * nty : 0) + 16 + 8 + 4 + (L.yd ? 4 * nty : 0) + 16 + NT_OUT * 4;
+    auto pr = [](int n) { return (n + 1) / 2; };
+    L.ntiles = 2 * pr(NT_OUT + (L.ye ? nty : 0)) + 2 * 2 + 1 * 2 + 2 * pr(1 + (L.yd ? nty : 0)) + 2 * 2 + pr(NT_OUT) * 2;
     int64_t b = 0;
     auto bytes = [&](int64_t n) { int64_t q = b; b += al(n, 256); return q; };
-    L.o_tiles = bytes((int64_t)L.ntiles * sizeof(TileDesc));
+    L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_partials = bytes(p.rows_grid * 2 * sizeof(double));
     L.o_wcopy = bytes(L.wcopy_elems * esz);
@@ -636,34 +824,59 @@ static int64_t kper_of(const dvae_train_plan_t* p) {
     return al((p->Bp + p->ksplit - 1) / p->ksplit, unit);
 }
 
+struct ABlock { int64_t row; int mvalid; int tensor; int m0; int bias_tensor; };
+struct BBlock { int64_t row; int nvalid; int col; };
+
 template <typename T>
-static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, TileDesc* tiles, TensorDesc* td) {
+static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, GroupDesc* groups, TensorDesc* td) {
     const int64_t Bp = p->Bp;
     T* stash = (T*)(ws_dev + L.o_stash);
     auto S = [&](int64_t row) { return (const void*)(stash + row * Bp); };
     int n = 0;
-    auto job = [&](int64_t Arow, int M, int64_t Brow, int N, int tensor, int col0, int bias_tensor) {
-        const int ldo = p->tensor_cols[tensor];
-        for (int m0 = 0; m0 < M; m0 += 32)
-            for (int n0 = 0; n0 < N; n0 += 32) {
-                TileDesc d;
-                d.A = S(Arow + m0); d.Bm = S(Brow + n0);
-                d.out_off = p->tensor_offset[tensor] + (int64_t)m0 * ldo + col0 + n0;
-                d.bias_off = (bias_tensor >= 0 && n0 == 0) ? p->tensor_offset[bias_tensor] + m0 : -1;
-                d.ldo = ldo; d.mvalid = M - m0 < 32 ? M - m0 : 32; d.nvalid = N - n0 < 32 ? N - n0 : 32; d.pad = 0;
-                tiles[n++] = d;
+    ABlock ab[64];
+    BBlock bb[64];
+    int na = 0, nb = 0;
+    auto addA = [&](int64_t row0, int M, int tensor, int bias_tensor) {
+        for (int m0 = 0; m0 < M; m0 += 32) ab[na++] = ABlock{row0 + m0, M - m0 < 32 ? M - m0 : 32, tensor, m0, bias_tensor};
+    };
+    auto addB = [&](int64_t row0, int N, int col0) {
+        for (int n0 = 0; n0 < N; n0 += 32) bb[nb++] = BBlock{row0 + n0, N - n0 < 32 ? N - n0 : 32, col0 + n0};
+    };
+    auto emit = [&]() {
+        for (int i = 0; i < na; i += 2)
+            for (int j = 0; j < nb; j += 2) {
+                GroupDesc d;
+                memset(&d, 0, sizeof(d));
+                for (int ii = 0; ii < 2; ++ii) {
+                    d.bias_off[ii] = -1;
+                    if (i + ii >= na) continue;
+                    const ABlock& a = ab[i + ii];
+                    d.A[ii] = S(a.row);
+                    d.ldo[ii] = p->tensor_cols[a.tensor];
+                    d.mvalid[ii] = a.mvalid;
+                    if (a.bias_tensor >= 0 && j == 0) d.bias_off[ii] = p->tensor_offset[a.bias_tensor] + a.m0;
+                    for (int jj = 0; jj < 2; ++jj) {
+                        if (j + jj >= nb) continue;
+                        d.out_off[ii][jj] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * d.ldo[ii] + bb[j + jj].col;
+                    }
+                }
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (j + jj >= nb) continue;
+                    d.Bm[jj] = S(bb[j + jj].row);
+                    d.nvalid[jj] = bb[j + jj].nvalid;
+                }
+                groups[n++] = d;
             }
+        na = 0; nb = 0;
     };
     const int ye = p->model == DVAE_MODEL_M2 ? p->y_dim : 0, yd = p->y_dim;
-    job(L.dh1T, HD, L.xT, XD, 0, 0, 1);
-    if (ye) job(L.dh1T, HD, L.yT, ye, 0, XD, -1);
-    job(L.dh2T, HD, L.h1T, HD, 2, 0, 3);
-    job(L.dmlvT, ZD, L.h2T, HD, 4, 0, 5);
-    job(L.dmlvT + ZD, ZD, L.h2T, HD, 6, 0, 7);
-    job(L.dd1T, HD, L.zT, ZD, 8, 0, 9);
-    if (yd) job(L.dd1T, HD, L.yT, yd, 8, ZD, -1);
-    job(L.dd2T, HD, L.d1T, HD, 10, 0, 11);
-    job(L.daT, XD, L.d2T, HD, 12, 0, 13);
+    addA(L.dh1T, HD, 0, 1); addB(L.xT, XD, 0); if (ye) addB(L.yT, ye, XD); emit();
+    addA(L.dh2T, HD, 2, 3); addB(L.h1T, HD, 0); emit();
+    ab[na++] = ABlock{L.dmlvT, ZD, 4, 0, 5}; ab[na++] = ABlock{L.dmlvT + ZD, ZD, 6, 0, 7}; addB(L.h2T, HD, 0); emit();
+    addA(L.dd1T, HD, 8, 9); addB(L.zT, ZD, 0); if (yd) addB(L.yT, yd, ZD); emit();
+    addA(L.dd2T, HD, 10, 11); addB(L.d1T, HD, 0); emit();
+    addA(L.daT, XD, 12, 13); addB(L.d2T, HD, 0); emit();
+    if (n != L.ntiles) { fprintf(stderr, "dvae: internal group count mismatch %d vs %d\n", n, L.ntiles); }
     // tensors -> kernel-layout copies
     for (int i = 0; i < 14; ++i) {
         TensorDesc t;
@@ -696,7 +909,12 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
         a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)adam_eps; a.gscale = (float)grad_scale;
     }
     a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3;
-    const dim3 grid(64, plan->n_tensors + 1);
+    int64_t maxn = 1;
+    for (int i = 0; i < plan->n_tensors; ++i) {
+        const int64_t ne = (int64_t)plan->tensor_rows[i] * plan->tensor_cols[i];
+        if (ne > maxn) maxn = ne;
+    }
+    const dim3 grid((unsigned)((maxn + 255) / 256), plan->n_tensors + 1);   // one element per thread: all loads independent
     if (plan->precision == DVAE_PREC_BF16) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((apply_kernel<__bf16, false>), grid, dim3(256), 0, s, a);
@@ -724,12 +942,12 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)ws;
     DVAE_HIP(hipMemsetAsync(w, 0, (size_t)L.total, s));
-    TileDesc* tiles = new TileDesc[L.ntiles + 8];
+    GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
     TensorDesc td[DVAE_TRAIN_MAX_TENSORS];
     memset(td, 0, sizeof(td));
     if (plan->precision == DVAE_PREC_BF16) fill_tables<__bf16>(plan, L, w, tiles, td);
     else fill_tables<float>(plan, L, w, tiles, td);
-    hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(TileDesc), hipMemcpyHostToDevice, s);
+    hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(GroupDesc), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
     hipError_t e3 = hipStreamSynchronize(s);
     delete[] tiles;
@@ -764,6 +982,8 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     RowsArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.eps = eps_noise; a.ldx = ldx; a.ldy = plan->y_dim ? ldy : 0; a.ydim = plan->y_dim;
+    a.fastx = (ldx == XD) && (((uintptr_t)x & 15) == 0);
+    a.fasty = (plan->y_dim == XD) && (ldy == XD) && (((uintptr_t)y & 15) == 0);
     a.B = plan->B; a.Bp = plan->Bp; a.ntiles = (int)((plan->B + TB - 1) / TB);
     a.invB = (float)(1.0 / (double)plan->B); a.elbo_eps = elbo_eps;
     char* wc = w + L.o_wcopy;
@@ -797,12 +1017,13 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     const int64_t kper = kper_of(plan);
     const int ks = (int)((plan->Bp + kper - 1) / kper);
     DVAE_CHECK_ARG(ks <= plan->ksplit, "train_grads: internal k-split mismatch");
-    const dim3 g2((unsigned)((L.ntiles + 3) / 4), (unsigned)ks);
+    constexpr int GPW = 2;                                  // groups (waves) per workgroup
+    const dim3 g2((unsigned)(((L.ntiles + GPW - 1) / GPW) * ks));
     float* slabs = (float*)(w + L.o_grads);
     {
         ProfScope ps(s, 1);
-        if (bf) hipLaunchKernelGGL((wgrad_kernel<PolBF16>), g2, dim3(256), 0, s, (const TileDesc*)(w + L.o_tiles), L.ntiles, plan->Bp, kper, slabs, plan->n_params);
-        else hipLaunchKernelGGL((wgrad_kernel<PolF32>), g2, dim3(256), 0, s, (const TileDesc*)(w + L.o_tiles), L.ntiles, plan->Bp, kper, slabs, plan->n_params);
+        if (bf) hipLaunchKernelGGL((wgrad_kernel<PolBF16>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, kper, slabs, plan->n_params);
+        else hipLaunchKernelGGL((wgrad_kernel<PolF32>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, kper, slabs, plan->n_params);
     }
     DVAE_LAUNCH_OK("wgrad_kernel");
     if (reduce_slabs && ks > 1) {
