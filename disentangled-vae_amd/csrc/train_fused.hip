@@ -22,6 +22,7 @@
 // (deterministic: no atomics anywhere).  Bias gradients ride along as one extra MFMA against a
 // constant-one fragment.
 #include <math.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/dvae_train.h"
 
@@ -43,6 +44,9 @@ struct PolF32 {
     typedef f32x4 Pack4;
     static constexpr int E = 4;        // elements per 16-byte fragment
     static constexpr int KSTEP = 8;    // reduction depth per fragment pair
+    static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
+    static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
+    static constexpr bool XFULL = false;   // fp32 x tile does not fit LDS next to fp32 activations: streamed in 128-column slices
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
@@ -62,6 +66,9 @@ struct PolBF16 {
     typedef bf16x4 Pack4;
     static constexpr int E = 8;
     static constexpr int KSTEP = 16;
+    static constexpr int PD = 16;
+    static constexpr int PRE = 6;
+    static constexpr bool XFULL = true;    // whole fp32 x tile stays in LDS for the loss epilogue
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
@@ -86,15 +93,19 @@ template <typename T> struct Ld {
     static constexpr int hh = HD + per16;         // [frame][128]
     static constexpr int z = 32 + per16;          // [frame][32]              (z | pad, dmu | dlv)
     static constexpr int xt = 129;                // fp32 [frame][128] slice of x for the loss epilogue
-    static constexpr size_t bytes = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)TB * xt * sizeof(float) + 64;
+    static constexpr int nbias = 4 * HD + 32 + NO;   // b1 b2 [bmu|blv] b3 b4 b5(padded): fp32 copies for the epilogues
+    static constexpr int xf_floats = (TB * XD + 63) / 64 * 64;
+    static constexpr int xt_floats = (TB * xt + 63) / 64 * 64;
+    static constexpr size_t bytes_slices = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xt_floats + nbias) * sizeof(float) + 64;
+    static constexpr size_t bytes_full = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xf_floats + nbias) * sizeof(float) + 64;
 };
 
 __device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// First CH weight fragments of a GEMM, loaded ahead of time (weights never depend on data, so the
-// next layer's first fragments are requested before the current layer's epilogue and barrier).
+// First weight fragments of a GEMM, requested ahead of time (weights never depend on data, so the
+// next layer's first fragments are in flight across the current layer's epilogue and barrier).
 template <typename P, int NSTEPS> struct WPre {
-    static constexpr int N = NSTEPS < 4 ? NSTEPS : 4;
+    static constexpr int N = NSTEPS < P::PRE ? NSTEPS : P::PRE;
     typename P::Frag a[N > 0 ? N : 1];
 };
 
@@ -103,44 +114,54 @@ __device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::
     typedef typename P::Frag Frag;
 #pragma unroll
     for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = *reinterpret_cast<const Frag*>(wrow + i * 2 * P::E);
+    // hipcc otherwise sinks these loads down to their first use (after the epilogue and barrier)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc += W[rows of this lane][k-block] * act^T : NSTEPS fragment pairs.  Weights stream straight
-// from global memory one chunk (CH steps) ahead of the MFMAs that consume them; activations come
-// from LDS.  The chunk loop is deliberately NOT unrolled: it bounds the live fragment registers.
+// acc += W[rows of this lane][k-block] * act^T : NSTEPS fragment pairs.  Weights stream straight from
+// L2 into a ring of D = min(PD, NSTEPS) fragment registers: the slot an MFMA has just consumed is
+// re-requested D steps ahead, so D loads per wave stay in flight (an L2 round trip under load is
+// ~1000 cycles, an MFMA step 32).  Activations come from LDS.  Only the outer loop is rolled.
 template <typename P, int NSTEPS>
 __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow,
                                            const typename P::T* brow) {
     typedef typename P::Frag Frag;
-    constexpr int CH = 4;
     constexpr int STR = 2 * P::E;
-    constexpr int NFULL = NSTEPS / CH, REM = NSTEPS % CH;
-    Frag a[CH];
+    constexpr int D = NSTEPS < P::PD ? NSTEPS : P::PD;
+    constexpr int NIT = D > 0 ? NSTEPS / D : 0, REM = D > 0 ? NSTEPS % D : 0;
+    Frag a[D > 0 ? D : 1];
 #pragma unroll
-    for (int i = 0; i < CH; ++i)
+    for (int i = 0; i < D; ++i) {
         if (i < WPre<P, NSTEPS>::N) a[i] = w.a[i];
-    if (NFULL > 0) {
+        else a[i] = *reinterpret_cast<const Frag*>(wrow + i * STR);
+    }
+    // Order pins: without them hipcc moves every weight load down to just above the MFMA that
+    // consumes it (one exposed L2 round trip per k-step, measured 150 ns/step instead of ~30).
+    __builtin_amdgcn_sched_barrier(0);
+    if (NIT > 1) {
 #pragma unroll 1
-        for (int c = 0; c < NFULL; ++c) {
-            Frag an[CH];
+        for (int c = 0; c < NIT - 1; ++c) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                int sn = (c + 1) * CH + i;
-                sn = sn < NSTEPS ? sn : NSTEPS - 1;        // clamp (redundant reload) instead of a branch around the load
-                an[i] = *reinterpret_cast<const Frag*>(wrow + sn * STR);
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const Frag b = *reinterpret_cast<const Frag*>(brow + (c * CH + i) * STR);
+            for (int i = 0; i < D; ++i) {
+                const Frag b = *reinterpret_cast<const Frag*>(brow + (c * D + i) * STR);
                 P::mma(acc, a[i], b);
+                a[i] = *reinterpret_cast<const Frag*>(wrow + ((c + 1) * D + i) * STR);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+    if (NIT > 0) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) a[i] = an[i];
+        for (int i = 0; i < D; ++i) {
+            const Frag b = *reinterpret_cast<const Frag*>(brow + ((NIT - 1) * D + i) * STR);
+            P::mma(acc, a[i], b);
+            if (i < REM) a[i] = *reinterpret_cast<const Frag*>(wrow + (NIT * D + i) * STR);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
-        const Frag b = *reinterpret_cast<const Frag*>(brow + (NFULL * CH + i) * STR);
+        const Frag b = *reinterpret_cast<const Frag*>(brow + (NIT * D + i) * STR);
         P::mma(acc, a[i], b);
     }
 }
@@ -156,11 +177,24 @@ struct RowsArgs {
     const float *b1, *b2, *bmu, *blv, *b3, *b4, *b5;
     void *xT, *yT, *h1T, *h2T, *dh1T, *dh2T, *dmlvT, *zT, *d1T, *d2T, *dd1T, *dd2T, *daT;
     double* partials;
+    unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
+    int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
 };
+
+#define DVAE_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
 template <typename P> __device__ __forceinline__ void zero_acc(f32x16& a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = 0.f;
+}
+
+// 16 bias values of this lane's C-tile rows (features fbase + 8g + 4h + 0..3) from the LDS bias table
+__device__ __forceinline__ void bias16(const float* bl, int fbase, int h, float (&b)[16]) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bl + fbase + 8 * gq + 4 * h);
+        b[4 * gq] = v[0]; b[4 * gq + 1] = v[1]; b[4 * gq + 2] = v[2]; b[4 * gq + 3] = v[3];
+    }
 }
 
 // write a 32-feature x 32-frame tile (values v[r], feature = fbase + feat_of(r,h), frame = l31)
@@ -188,13 +222,14 @@ __device__ __forceinline__ void put_tile(const float (&v)[16], typename P::T* ld
 // generic (edge tile / strided / unaligned input): global [32 frames][ncols] fp32 -> LDS as T, zero padded
 template <typename P>
 __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, int ld, int ncols, int pcols, int64_t b0, int64_t B,
-                                                 typename P::T* U, int ldu, int tid) {
+                                                 typename P::T* U, int ldu, int tid, float* xf = nullptr) {
     const int total = TB * pcols;
     for (int idx = tid; idx < total; idx += 256) {
         const int row = idx / pcols, col = idx - row * pcols;
         float v = 0.f;
         if (col < ncols && b0 + row < B) v = src[(b0 + row) * ld + col];
         U[row * ldu + col] = P::cvt(v);
+        if (xf && col < ncols) xf[row * ncols + col] = v;
     }
 }
 
@@ -208,13 +243,15 @@ __device__ __forceinline__ void tile513_issue(const float* __restrict__ tile, f3
         q = q < NV513 ? q : NV513 - 1;            // clamp instead of branching around the load
         v[i] = reinterpret_cast<const f32x4*>(tile)[q];
     }
+    __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
 }
 template <typename P, int PCOLS>
-__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid) {
+__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr) {
 #pragma unroll
     for (int i = 0; i < NQ513; ++i) {
         const int q = tid + 256 * i;
         if (q < NV513) {
+            if (xf) reinterpret_cast<f32x4*>(xf)[q] = v[i];       // dense [frame][513] fp32 copy
             const int base = 4 * q;
             const int row = base / XD, col = base - row * XD;
 #pragma unroll
@@ -260,6 +297,7 @@ __device__ __forceinline__ void xt_issue(const float* __restrict__ x, int ldx, i
         int cg = f0 + col; cg = cg < XD ? cg : XD - 1;
         xr[i] = x[rg * ldx + cg];
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void xt_commit(const float (&xr)[16], float* Xt, int ldxt, int64_t b0, int64_t B, int f0, int tid) {
 #pragma unroll
@@ -284,7 +322,9 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     T* Ha = U + TB * LDU;
     T* Hb = Ha + TB * LDH;
     T* Zb = Hb + TB * LDH;
-    float* Xt = reinterpret_cast<float*>(Zb + TB * LDZ);
+    float* Xt = reinterpret_cast<float*>(Zb + TB * LDZ);     // XFULL: dense [32][513] fp32 x tile; else [32][129] slice
+    float* Bias = Xt + (P::XFULL ? Ld<T>::xf_floats : Ld<T>::xt_floats);
+    constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
     __shared__ float red[8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -308,6 +348,20 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
     double tot_rec = 0.0, tot_kl = 0.0;
 
+    // fp32 bias table -> LDS once (epilogues must not queue global loads behind the weight prefetch)
+    for (int i = tid; i < Ld<T>::nbias; i += 256) {
+        float v;
+        if (i < OB2) v = g.b1[i];
+        else if (i < OBMV) v = g.b2[i - OB2];
+        else if (i < OBMV + ZD) v = g.bmu[i - OBMV];
+        else if (i < OB3) v = g.blv[i - OBMV - ZD];
+        else if (i < OB4) v = g.b3[i - OB3];
+        else if (i < OB5) v = g.b4[i - OB4];
+        else v = (i - OB5 < XD) ? g.b5[i - OB5] : 0.f;
+        Bias[i] = v;
+    }
+    __syncthreads();
+
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t b0 = (int64_t)tile * TB;
         const bool live = (b0 + l31) < g.B;             // this lane's frame exists
@@ -318,22 +372,35 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         int tl = tid;
         asm volatile("" : "+v"(tl));
 
+        DVAE_STAMP(0);
+        // reparametrisation noise of this lane's frame (wave 0 owns the latent tile): requested first,
+        // long before it is needed
+        float ep_r[8];
+        if (wave == 0) {
+            int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1;
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 4 * h);
+            const f32x4 e1 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 8 + 4 * h);
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) { ep_r[jq] = live ? e0[jq] : 0.f; ep_r[4 + jq] = live ? e1[jq] : 0.f; }
+        }
         // ---------------- encoder layer 1: [x | y] -> h1 ----------------
         WPre<P, XP / KS> w1x;
         wprefetch<P, XP / KS>(w1x, W1r);
+        const bool yfast = Y513 && g.fasty && full;
         if (g.fastx && full) {
             f32x4 xv[NQ513];
             tile513_issue(g.x + b0 * XD, xv, tl);
-            tile513_commit<P, XP>(xv, U, LDU, tl);
+            tile513_commit<P, XP>(xv, U, LDU, tl, P::XFULL ? Xt : nullptr);
         } else {
-            load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl);
+            load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, P::XFULL ? Xt : nullptr);
         }
         __syncthreads();
-        const bool yfast = Y513 && g.fasty && full;
-        stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
+        if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
+        DVAE_STAMP(1);
         f32x16 acc;
         zero_acc<P>(acc);
         gemm_block<P, XP / KS>(acc, w1x, W1r, Ur);
+        DVAE_STAMP(2);
         WPre<P, HD / KS> w2;
         WPre<P, (YENC ? YP : 0) / KS> w1y;
         if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, W1r + XP);
@@ -348,18 +415,21 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl);
             }
             __syncthreads();
-            stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
+            if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
             if (YENC) {
                 gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, W1r + XP, Ur);
                 wprefetch<P, HD / KS>(w2, W2r);
             }
         }
-        float h1r[16];
+        float h1r[16], bv[16];
+        DVAE_STAMP(3);
+        bias16(Bias + OB1, fb, h, bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1r[r] = P::tanh_(acc[r] + g.b1[fb + feat_of(r, h)]);
-        put_tile<P>(h1r, Ha, LDH, fb, (T*)g.h1T, g.Bp, b0, l31, h);
+        for (int r = 0; r < 16; ++r) h1r[r] = P::tanh_(acc[r] + bv[r]);
+        put_tile<P>(h1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(4);
         // ---------------- encoder layer 2 ----------------
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w2, W2r, Har);
@@ -368,24 +438,24 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (wave == 0) wprefetch<P, HD / KS>(wmv, Wmvr);
         wprefetch<P, ZD / KS>(w3z, W3r);
         float h2r[16];
+        bias16(Bias + OB2, fb, h, bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + g.b2[fb + feat_of(r, h)]);
-        put_tile<P>(h2r, Hb, LDH, fb, (T*)g.h2T, g.Bp, b0, l31, h);
+        for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + bv[r]);
+        put_tile<P>(h2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(5);
         // ---------------- heads + reparametrisation (wave 0): rows 0-15 mu, 16-31 log_var ----------------
-        float mu_r[8], lv_r[8], ep_r[8], sd_r[8];
+        float mu_r[8], lv_r[8], sd_r[8];
         if (wave == 0) {
             zero_acc<P>(acc);
             gemm_block<P, HD / KS>(acc, wmv, Wmvr, Hbr);
             float zv[16];
+            bias16(Bias + OBMV, 0, h, bv);                          // rows 0-15 bmu, 16-31 blv
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int j = feat_of(r, h);                       // latent index 0..15
-                mu_r[r] = acc[r] + g.bmu[j];
-                lv_r[r] = acc[r + 8] + g.blv[j];
-                int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1;
-                ep_r[r] = live ? g.eps[br * ZD + j] : 0.f;
+                mu_r[r] = acc[r] + bv[r];
+                lv_r[r] = acc[r + 8] + bv[r + 8];
                 sd_r[r] = P::exp_(0.5f * lv_r[r]);                 // models.py:17
                 zv[r] = fmaf(sd_r[r], ep_r[r], mu_r[r]);           // models.py:20
                 zv[r + 8] = 0.f;
@@ -399,6 +469,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         }
         __syncthreads();
 
+        DVAE_STAMP(6);
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
         gemm_block<P, ZD / KS>(acc, w3z, W3r, Zbr);
@@ -410,55 +481,72 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         }
         wprefetch<P, HD / KS>(w4, W4r);
         float d1r[16];
+        bias16(Bias + OB3, fb, h, bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + g.b3[fb + feat_of(r, h)]);
-        put_tile<P>(d1r, Ha, LDH, fb, (T*)g.d1T, g.Bp, b0, l31, h);
+        for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + bv[r]);
+        put_tile<P>(d1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(7);
         // ---------------- decoder layer 2 ----------------
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w4, W4r, Har);
         WPre<P, HD / KS> w5;
         wprefetch<P, HD / KS>(w5, W5s + (int64_t)(32 * wave + l31) * HD + h * E);
         float xr[16];
-        xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
+        if (!P::XFULL) xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
         float d2r[16];
+        bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + g.b4[fb + feat_of(r, h)]);
-        put_tile<P>(d2r, Hb, LDH, fb, (T*)g.d2T, g.Bp, b0, l31, h);
+        for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + bv[r]);
+        put_tile<P>(d2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(8);
         // ---------------- output layer a = W5 d2 + b5, Itakura-Saito terms, da -> U ----------------
         WPre<P, NO / KS> w5t;
-#pragma unroll 1
-        for (int it = 0; it < (NT_OUT + 3) / 4; ++it) {
-            xt_commit(xr, Xt, LDX, b0, g.B, 128 * it, tl);
-            __syncthreads();
-            if (it + 1 < (NT_OUT + 3) / 4) xt_issue(g.x, g.ldx, b0, g.B, 128 * (it + 1), xr, tl);
-            const int t = 4 * it + wave;
-            if (t < NT_OUT) {
-                zero_acc<P>(acc);
-                const T* wr = W5s + (int64_t)(32 * t + l31) * HD + h * E;
-                gemm_block<P, HD / KS>(acc, w5, wr, Hbr);
-                if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wr + (int64_t)128 * HD);
-                else wprefetch<P, NO / KS>(w5t, W5tr);
-                float da[16];
+        // one 32-feature tile t of the output layer for this wave: GEMM, loss terms, da
+        auto out_tile = [&](int t, const float* xsrc, int xld, int xcol0, int xcmax) {
+            zero_acc<P>(acc);
+            const T* wr = W5s + (int64_t)(32 * t + l31) * HD + h * E;
+            gemm_block<P, HD / KS>(acc, w5, wr, Hbr);
+            if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wr + (int64_t)128 * HD);
+            else wprefetch<P, NO / KS>(w5t, W5tr);
+            float da[16], b5v[16];
+            bias16(Bias + OB5, 32 * t, h, b5v);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int fl = feat_of(r, h);
-                    const int f = 32 * t + fl;
-                    const bool ok = live && f < XD;
-                    const float a = acc[r] + g.b5[f < XD ? f : XD - 1];
-                    const float xv = Xt[l31 * LDX + 32 * wave + fl];
-                    const float xe = xv * P::exp_(-a);               // x / r,  r = exp(a)  (models.py:122)
-                    if (ok) rec_lane += xe - P::log_(xv + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
-                    da[r] = ok ? (1.f - xe) * g.invB : 0.f;          // d recon / d a
-                }
-                put_tile<P>(da, U, LDU, 32 * t, (T*)g.daT, g.Bp, b0, l31, h);
+            for (int r = 0; r < 16; ++r) {
+                const int fl = feat_of(r, h);
+                const int f = 32 * t + fl;
+                const bool ok = live && f < XD;
+                const float a = acc[r] + b5v[r];
+                int xc = xcol0 + fl; xc = xc < xcmax ? xc : xcmax;    // clamped, unconditional LDS read
+                const float xv = xsrc[l31 * xld + xc];
+                const float xe = xv * P::exp_(-a);               // x / r,  r = exp(a)  (models.py:122)
+                const float term = xe - P::log_(xv + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
+                rec_lane += ok ? term : 0.f;
+                da[r] = ok ? (1.f - xe) * g.invB : 0.f;          // d recon / d a
             }
+            put_tile<P>(da, U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT, g.Bp, b0, l31, h);
+        };
+        if (P::XFULL) {
+            // the fp32 x tile is resident in LDS ([frame][513], odd stride: conflict-free): no barriers here
+#pragma unroll 1
+            for (int t = wave; t < NT_OUT; t += 4) out_tile(t, Xt, XD, 32 * t, XD - 1);
             __syncthreads();
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < (NT_OUT + 3) / 4; ++it) {
+                xt_commit(xr, Xt, LDX, b0, g.B, 128 * it, tl);
+                __syncthreads();
+                if (it + 1 < (NT_OUT + 3) / 4) xt_issue(g.x, g.ldx, b0, g.B, 128 * (it + 1), xr, tl);
+                const int t = 4 * it + wave;
+                if (t < NT_OUT) out_tile(t, Xt, LDX, 32 * wave, 127);
+                __syncthreads();
+            }
         }
 
+        DVAE_STAMP(9);
         // ---------------- backward: d2 <- da ----------------
         zero_acc<P>(acc);
         gemm_block<P, NO / KS>(acc, w5t, W5tr, Ur);
@@ -467,9 +555,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         float dv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d2r[r] * d2r[r]);
-        put_tile<P>(dv, Ha, LDH, fb, (T*)g.dd2T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(10);
         // ---------------- backward: d1 <- dpre_d2 ----------------
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w4t, W4tr, Har);
@@ -479,9 +568,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         wprefetch<P, 32 / KS>(wmvt, Wmvtr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d1r[r] * d1r[r]);
-        put_tile<P>(dv, Hb, LDH, fb, (T*)g.dd1T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(11);
         // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
         if (wave == 0) {
             zero_acc<P>(acc);
@@ -497,6 +587,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         }
         __syncthreads();
 
+        DVAE_STAMP(12);
         // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
         zero_acc<P>(acc);
         gemm_block<P, 32 / KS>(acc, wmvt, Wmvtr, Zbr);
@@ -504,16 +595,18 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         wprefetch<P, HD / KS>(w2t, W2tr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);
-        put_tile<P>(dv, Ha, LDH, fb, (T*)g.dh2T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T, g.Bp, b0, l31, h);
         __syncthreads();
 
+        DVAE_STAMP(13);
         // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w2t, W2tr, Har);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
-        put_tile<P>(dv, nullptr, 0, fb, (T*)g.dh1T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, nullptr, 0, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T, g.Bp, b0, l31, h);
 
+        DVAE_STAMP(14);
         // ---------------- per-tile loss sums ----------------
         const float rs = wave_sum(rec_lane), ks = wave_sum(kl_lane);
         if (lane == 0) { red[wave] = rs; red[4 + wave] = ks; }
@@ -524,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         }
         __syncthreads();
     }
+    DVAE_STAMP(15);
     if (tid == 0) {
         g.partials[2 * blockIdx.x] = tot_rec;
         g.partials[2 * blockIdx.x + 1] = tot_kl;
@@ -582,6 +676,7 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
             if (A1) a1n[i] = *reinterpret_cast<const Frag*>(a1p + kn + i * KS);
             if (B1) b1n[i] = *reinterpret_cast<const Frag*>(b1p + kn + i * KS);
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the next chunk's loads above this chunk's MFMAs
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             P::mma(c00, a0[i], b0[i]);
@@ -758,6 +853,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
 }
 
 static bool g_prof = false;
+static unsigned long long* g_dbg = nullptr;   // set by dvae_train_debug_stamps
 static double g_ms[4] = {0, 0, 0, 0};
 static int64_t g_calls[4] = {0, 0, 0, 0};
 struct PendingEv { hipEvent_t a, b; int which; };
@@ -957,7 +1053,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
 
 template <typename P, int YP, bool YENC>
 static int launch_rows(const RowsArgs& a, int grid, hipStream_t s) {
-    const size_t lds = Ld<typename P::T>::bytes;
+    const size_t lds = P::XFULL ? Ld<typename P::T>::bytes_full : Ld<typename P::T>::bytes_slices;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)vae_rows_kernel<P, YP, YENC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -994,6 +1090,8 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.bmu = params + plan->tensor_offset[5]; a.blv = params + plan->tensor_offset[7];
     a.b3 = params + plan->tensor_offset[9]; a.b4 = params + plan->tensor_offset[11]; a.b5 = params + plan->tensor_offset[13];
     a.partials = (double*)(w + L.o_partials);
+    a.dbg = g_dbg;
+    { const char* ab = getenv("DVAE_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     char* st = w + L.o_stash;
     auto ST = [&](int64_t row) { return (void*)(st + row * plan->Bp * esz); };
     a.xT = ST(L.xT); a.yT = ST(L.yT); a.h1T = ST(L.h1T); a.h2T = ST(L.h2T); a.dh1T = ST(L.dh1T); a.dh2T = ST(L.dh2T);
@@ -1058,6 +1156,11 @@ extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, flo
     int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, elbo_eps, 0, stream);
     if (rc) return rc;
     return dvae_train_apply(plan, params, m, v, ws, 0, step, lr, beta1, beta2, adam_eps, 1.0, losses3, stream);
+}
+
+extern "C" int dvae_train_debug_stamps(void* buf) {
+    g_dbg = (unsigned long long*)buf;
+    return 0;
 }
 
 extern "C" int dvae_train_profile(int enable) {

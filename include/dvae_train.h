@@ -86,6 +86,9 @@ int dvae_train_repack(const dvae_train_plan_t* plan, const float* params, void* 
  * dvae_train_profile_read synchronises and returns accumulated ms and launch counts
  * for {rows, wgrad, reduce, apply}, then clears them. */
 int dvae_train_profile(int enable);
+/* Diagnostic builds only: buf = device array of rows_grid * 32 uint64, filled with 100 MHz wall-clock stamps at the
+ * phase boundaries of the rows kernel (NULL switches it off).  Never enabled by bench.py's timed region. */
+int dvae_train_debug_stamps(void* buf);
 int dvae_train_profile_read(double ms[4], int64_t calls[4]);
 
 #ifdef __cplusplus
