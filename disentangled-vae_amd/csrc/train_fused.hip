@@ -34,6 +34,12 @@ constexpr int XP = 528;   // 513 input features padded to a multiple of 16
 constexpr int NO = 544;   // 513 output features padded to 17 row tiles of 32
 constexpr int TB = 32;    // frames per tile
 constexpr int NT_OUT = 17;
+// Weight-copy layout.  false: row-major [out][in_padded] (each wave load touches 32 rows x 32 B; the 4 k-steps
+// that share a 128-B line hit L1).  true: fragment-major [k-step][row tile][lane][E] (one contiguous 1 KB per
+// wave load).  Measured on MI355X (B = 8192, 256 workgroups in lockstep): fragment-major weights made the wide
+// GEMM phases 3-4x SLOWER (L1 x-block 8.4 us vs 2.3 us) in both block orders, so row-major is used; the stash
+// (written and read once, by different kernels) is fragment-major, which cut the wgrad kernel from 37 to 23 us.
+constexpr bool WFRAG = false;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -110,10 +116,10 @@ template <typename P, int NSTEPS> struct WPre {
 };
 
 template <typename P, int NSTEPS>
-__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow) {
+__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow, int WSTR) {
     typedef typename P::Frag Frag;
 #pragma unroll
-    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = *reinterpret_cast<const Frag*>(wrow + i * 2 * P::E);
+    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = *reinterpret_cast<const Frag*>(wrow + i * WSTR);
     // hipcc otherwise sinks these loads down to their first use (after the epilogue and barrier)
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -124,16 +130,16 @@ __device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::
 // ~1000 cycles, an MFMA step 32).  Activations come from LDS.  Only the outer loop is rolled.
 template <typename P, int NSTEPS>
 __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow,
-                                           const typename P::T* brow) {
+                                           const typename P::T* brow, int WSTR) {
     typedef typename P::Frag Frag;
-    constexpr int STR = 2 * P::E;
+    constexpr int STR = 2 * P::E;        // LDS activations: k-step = 2E consecutive features of a frame row
     constexpr int D = NSTEPS < P::PD ? NSTEPS : P::PD;
     constexpr int NIT = D > 0 ? NSTEPS / D : 0, REM = D > 0 ? NSTEPS % D : 0;
     Frag a[D > 0 ? D : 1];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         if (i < WPre<P, NSTEPS>::N) a[i] = w.a[i];
-        else a[i] = *reinterpret_cast<const Frag*>(wrow + i * STR);
+        else a[i] = *reinterpret_cast<const Frag*>(wrow + i * WSTR);
     }
     // Order pins: without them hipcc moves every weight load down to just above the MFMA that
     // consumes it (one exposed L2 round trip per k-step, measured 150 ns/step instead of ~30).
@@ -145,7 +151,7 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w
             for (int i = 0; i < D; ++i) {
                 const Frag b = *reinterpret_cast<const Frag*>(brow + (c * D + i) * STR);
                 P::mma(acc, a[i], b);
-                a[i] = *reinterpret_cast<const Frag*>(wrow + ((c + 1) * D + i) * STR);
+                a[i] = *reinterpret_cast<const Frag*>(wrow + ((c + 1) * D + i) * WSTR);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -155,7 +161,7 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w
         for (int i = 0; i < D; ++i) {
             const Frag b = *reinterpret_cast<const Frag*>(brow + ((NIT - 1) * D + i) * STR);
             P::mma(acc, a[i], b);
-            if (i < REM) a[i] = *reinterpret_cast<const Frag*>(wrow + (NIT * D + i) * STR);
+            if (i < REM) a[i] = *reinterpret_cast<const Frag*>(wrow + (NIT * D + i) * WSTR);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -197,25 +203,38 @@ __device__ __forceinline__ void bias16(const float* bl, int fbase, int h, float 
     }
 }
 
-// write a 32-feature x 32-frame tile (values v[r], feature = fbase + feat_of(r,h), frame = l31)
-// to LDS [frame][feature] and/or to the transposed stash [feature][Bp]
+// Stash layout ("fragment-major"): a matrix of R features x Bp frames is stored as
+//   [feature tile (32)][k-step (KSTEP frames)][lane = h*32 + feature%32][E frames]
+// i.e. exactly the order in which one wgrad wave-instruction consumes it: every operand load of
+// the wgrad kernel and every store here is one contiguous 1 KB block.  A 32-feature tile block
+// starts at element 32 * tile * Bp, as in a plain [feature][Bp] matrix.
+//
+// put_tile: values v[r] of a 32-feature x 32-frame C tile (feature = fbase + feat_of(r,h), frame = l31)
+// go to LDS [frame][feature] (the next layer's B operand); the same wave then reads its own 32
+// columns back transposed (E consecutive frames of one feature = one fragment) for the stash.
 template <typename P>
 __device__ __forceinline__ void put_tile(const float (&v)[16], typename P::T* lds, int ldl, int fbase,
-                                         typename P::T* stash, int64_t Bp, int64_t bcol, int l31, int h) {
+                                         typename P::T* stash_tile, int64_t Bp, int64_t b0, int l31, int h) {
     typedef typename P::T T;
     typedef typename P::Pack4 Pack4;
-    if (lds) {
+    typedef typename P::Frag Frag;
+    constexpr int E = P::E;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            Pack4 p;
-            p[0] = P::cvt(v[4 * gq]); p[1] = P::cvt(v[4 * gq + 1]); p[2] = P::cvt(v[4 * gq + 2]); p[3] = P::cvt(v[4 * gq + 3]);
-            *reinterpret_cast<Pack4*>(lds + l31 * ldl + fbase + 8 * gq + 4 * h) = p;
-        }
+    for (int gq = 0; gq < 4; ++gq) {
+        Pack4 p;
+        p[0] = P::cvt(v[4 * gq]); p[1] = P::cvt(v[4 * gq + 1]); p[2] = P::cvt(v[4 * gq + 2]); p[3] = P::cvt(v[4 * gq + 3]);
+        *reinterpret_cast<Pack4*>(lds + l31 * ldl + fbase + 8 * gq + 4 * h) = p;
     }
-    if (stash) {
-        T* s = stash + bcol + l31;
+    if (stash_tile) {
+        T* dst = stash_tile + (b0 / P::KSTEP) * (64 * E) + l31 * E;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[(int64_t)(fbase + feat_of(r, h)) * Bp] = P::cvt(v[r]);
+        for (int i = 0; i < TB / (2 * E); ++i) {
+            const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
+            Frag f;
+#pragma unroll
+            for (int j = 0; j < E; ++j) f[j] = lds[(gq * E + j) * ldl + fbase + l31];
+            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
+        }
     }
 }
 
@@ -269,8 +288,8 @@ __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename
     }
 }
 
-// LDS U[frame][col] -> stash [col][Bp] (transposed), 16 bytes (E frames) per store; rows up to `srows`
-// (multiple of 32) are written, columns >= pcols as zeros
+// LDS U[frame][col] -> fragment-major stash (see put_tile), 16 bytes (E frames of one feature) per
+// store; feature rows up to `srows` (multiple of 32) are written, columns >= pcols as zeros
 template <typename P>
 __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, int pcols, int srows, typename P::T* stash,
                                                int64_t Bp, int64_t b0, int tid) {
@@ -283,7 +302,7 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
         Frag p;
 #pragma unroll
         for (int j = 0; j < E; ++j) p[j] = (f < pcols) ? U[(gi * E + j) * ldu + f] : P::cvt(0.f);
-        *reinterpret_cast<Frag*>(stash + (int64_t)f * Bp + b0 + gi * E) = p;
+        *reinterpret_cast<Frag*>(stash + (int64_t)(f >> 5) * 32 * Bp + (b0 / P::KSTEP) * (64 * E) + (gi * 32 + (f & 31)) * E) = p;
     }
 }
 
@@ -330,17 +349,28 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int fb = 32 * wave;                           // this wave's feature block in 128-wide layers
-    const T* const W1r = (const T*)g.W1s + (int64_t)(fb + l31) * LD1 + h * E;
-    const T* const W2r = (const T*)g.W2s + (int64_t)(fb + l31) * HD + h * E;
-    const T* const Wmvr = (const T*)g.Wmvs + (int64_t)l31 * HD + h * E;
-    const T* const W3r = (const T*)g.W3s + (int64_t)(fb + l31) * LD3 + h * E;
-    const T* const W4r = (const T*)g.W4s + (int64_t)(fb + l31) * HD + h * E;
-    const T* const W5s = (const T*)g.W5s;
-    const T* const W5tr = (const T*)g.W5t + (int64_t)(fb + l31) * NO + h * E;
-    const T* const W4tr = (const T*)g.W4t + (int64_t)(fb + l31) * HD + h * E;
-    const T* const W3ztr = (const T*)g.W3zt + (int64_t)l31 * HD + h * E;
-    const T* const Wmvtr = (const T*)g.Wmvt + (int64_t)(fb + l31) * 32 + h * E;
-    const T* const W2tr = (const T*)g.W2t + (int64_t)(fb + l31) * HD + h * E;
+    // fragment-major weight copies: [k-step][row tile][lane][E] (k-step major: the fragments a wave keeps in
+    // flight then sit >= 4 KB apart and spread over the L2 channels); this wave's tile = wave in 128-row layers
+    constexpr int FB = 64 * E;                          // elements per (tile, k-step) block
+    // per-lane base of this wave's row tile in each weight copy, and the element stride between k-steps
+    auto wbase = [&](const void* Wp, int tile, int ld) -> const T* {
+        return WFRAG ? (const T*)Wp + tile * FB + lane * E : (const T*)Wp + (int64_t)(32 * tile + l31) * ld + h * E;
+    };
+    constexpr int S4 = WFRAG ? 4 * FB : 2 * E, S1 = WFRAG ? FB : 2 * E, S17 = WFRAG ? NT_OUT * FB : 2 * E;
+    constexpr int TSTEP = WFRAG ? FB : 32 * HD;         // W5s: next row tile
+    constexpr int KB1 = WFRAG ? (XP / KS) * 4 * FB : XP; // W1: start of the y k-block
+    constexpr int KB3 = WFRAG ? (ZD / KS) * 4 * FB : ZD; // W3: start of the y k-block
+    const T* const W1r = wbase(g.W1s, wave, LD1);
+    const T* const W2r = wbase(g.W2s, wave, HD);
+    const T* const Wmvr = wbase(g.Wmvs, 0, HD);
+    const T* const W3r = wbase(g.W3s, wave, LD3);
+    const T* const W4r = wbase(g.W4s, wave, HD);
+    const T* const W5s = wbase(g.W5s, 0, HD);
+    const T* const W5tr = wbase(g.W5t, wave, NO);
+    const T* const W4tr = wbase(g.W4t, wave, HD);
+    const T* const W3ztr = wbase(g.W3zt, 0, HD);
+    const T* const Wmvtr = wbase(g.Wmvt, wave, 32);
+    const T* const W2tr = wbase(g.W2t, wave, HD);
     const T* const Ur = U + l31 * LDU + h * E;
     const T* const Har = Ha + l31 * LDH + h * E;
     const T* const Hbr = Hb + l31 * LDH + h * E;
@@ -385,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         }
         // ---------------- encoder layer 1: [x | y] -> h1 ----------------
         WPre<P, XP / KS> w1x;
-        wprefetch<P, XP / KS>(w1x, W1r);
+        wprefetch<P, XP / KS>(w1x, W1r, S4);
         const bool yfast = Y513 && g.fasty && full;
         if (g.fastx && full) {
             f32x4 xv[NQ513];
@@ -399,12 +429,12 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(1);
         f32x16 acc;
         zero_acc<P>(acc);
-        gemm_block<P, XP / KS>(acc, w1x, W1r, Ur);
+        gemm_block<P, XP / KS>(acc, w1x, W1r, Ur, S4);
         DVAE_STAMP(2);
         WPre<P, HD / KS> w2;
         WPre<P, (YENC ? YP : 0) / KS> w1y;
-        if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, W1r + XP);
-        else wprefetch<P, HD / KS>(w2, W2r);
+        if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, W1r + KB1, S4);
+        else wprefetch<P, HD / KS>(w2, W2r, S4);
         if (YP > 0) {
             __syncthreads();
             if (Y513 && yfast) {
@@ -417,8 +447,8 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             __syncthreads();
             if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
             if (YENC) {
-                gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, W1r + XP, Ur);
-                wprefetch<P, HD / KS>(w2, W2r);
+                gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, W1r + KB1, Ur, S4);
+                wprefetch<P, HD / KS>(w2, W2r, S4);
             }
         }
         float h1r[16], bv[16];
@@ -426,22 +456,22 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         bias16(Bias + OB1, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(h1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T, g.Bp, b0, l31, h);
+        put_tile<P>(h1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(4);
         // ---------------- encoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2, W2r, Har);
+        gemm_block<P, HD / KS>(acc, w2, W2r, Har, S4);
         WPre<P, HD / KS> wmv;
         WPre<P, ZD / KS> w3z;
-        if (wave == 0) wprefetch<P, HD / KS>(wmv, Wmvr);
-        wprefetch<P, ZD / KS>(w3z, W3r);
+        if (wave == 0) wprefetch<P, HD / KS>(wmv, Wmvr, S1);
+        wprefetch<P, ZD / KS>(w3z, W3r, S4);
         float h2r[16];
         bias16(Bias + OB2, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(h2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T, g.Bp, b0, l31, h);
+        put_tile<P>(h2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(5);
@@ -449,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         float mu_r[8], lv_r[8], sd_r[8];
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, wmv, Wmvr, Hbr);
+            gemm_block<P, HD / KS>(acc, wmv, Wmvr, Hbr, S1);
             float zv[16];
             bias16(Bias + OBMV, 0, h, bv);                          // rows 0-15 bmu, 16-31 blv
 #pragma unroll
@@ -462,44 +492,41 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 if (live) kl_lane += lv_r[r] - mu_r[r] * mu_r[r] - P::exp_(lv_r[r]);   // utils.py:75
             }
             // z block of the decoder input: features 0..15 valid, 16..31 zero
-            put_tile<P>(zv, Zb, LDZ, 0, nullptr, g.Bp, b0, l31, h);
-            T* zs = (T*)g.zT + b0 + l31;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) zs[(int64_t)feat_of(r, h) * g.Bp] = P::cvt(zv[r]);
+            put_tile<P>(zv, Zb, LDZ, 0, (T*)g.zT, g.Bp, b0, l31, h);
         }
         __syncthreads();
 
         DVAE_STAMP(6);
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, ZD / KS>(acc, w3z, W3r, Zbr);
+        gemm_block<P, ZD / KS>(acc, w3z, W3r, Zbr, S4);
         WPre<P, HD / KS> w4;
         if (YP > 0) {
             WPre<P, YP / KS> w3y;
-            wprefetch<P, YP / KS>(w3y, W3r + ZD);
-            gemm_block<P, YP / KS>(acc, w3y, W3r + ZD, Ur);
+            wprefetch<P, YP / KS>(w3y, W3r + KB3, S4);
+            gemm_block<P, YP / KS>(acc, w3y, W3r + KB3, Ur, S4);
         }
-        wprefetch<P, HD / KS>(w4, W4r);
+        wprefetch<P, HD / KS>(w4, W4r, S4);
         float d1r[16];
         bias16(Bias + OB3, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(d1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T, g.Bp, b0, l31, h);
+        put_tile<P>(d1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(7);
         // ---------------- decoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w4, W4r, Har);
+        gemm_block<P, HD / KS>(acc, w4, W4r, Har, S4);
         WPre<P, HD / KS> w5;
-        wprefetch<P, HD / KS>(w5, W5s + (int64_t)(32 * wave + l31) * HD + h * E);
+        wprefetch<P, HD / KS>(w5, W5s + wave * TSTEP, S17);
         float xr[16];
         if (!P::XFULL) xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
         float d2r[16];
         bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(d2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T, g.Bp, b0, l31, h);
+        put_tile<P>(d2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(8);
@@ -508,10 +535,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // one 32-feature tile t of the output layer for this wave: GEMM, loss terms, da
         auto out_tile = [&](int t, const float* xsrc, int xld, int xcol0, int xcmax) {
             zero_acc<P>(acc);
-            const T* wr = W5s + (int64_t)(32 * t + l31) * HD + h * E;
-            gemm_block<P, HD / KS>(acc, w5, wr, Hbr);
-            if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wr + (int64_t)128 * HD);
-            else wprefetch<P, NO / KS>(w5t, W5tr);
+            const T* wr = W5s + t * TSTEP;
+            gemm_block<P, HD / KS>(acc, w5, wr, Hbr, S17);
+            if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wr + 4 * TSTEP, S17);
+            else wprefetch<P, NO / KS>(w5t, W5tr, S4);
             float da[16], b5v[16];
             bias16(Bias + OB5, 32 * t, h, b5v);
 #pragma unroll
@@ -527,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 rec_lane += ok ? term : 0.f;
                 da[r] = ok ? (1.f - xe) * g.invB : 0.f;          // d recon / d a
             }
-            put_tile<P>(da, U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT, g.Bp, b0, l31, h);
+            put_tile<P>(da, U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT + (int64_t)(t) * 32 * g.Bp, g.Bp, b0, l31, h);
         };
         if (P::XFULL) {
             // the fp32 x tile is resident in LDS ([frame][513], odd stride: conflict-free): no barriers here
@@ -549,33 +576,33 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(9);
         // ---------------- backward: d2 <- da ----------------
         zero_acc<P>(acc);
-        gemm_block<P, NO / KS>(acc, w5t, W5tr, Ur);
+        gemm_block<P, NO / KS>(acc, w5t, W5tr, Ur, S4);
         WPre<P, HD / KS> w4t;
-        wprefetch<P, HD / KS>(w4t, W4tr);
+        wprefetch<P, HD / KS>(w4t, W4tr, S4);
         float dv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d2r[r] * d2r[r]);
-        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(10);
         // ---------------- backward: d1 <- dpre_d2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w4t, W4tr, Har);
+        gemm_block<P, HD / KS>(acc, w4t, W4tr, Har, S4);
         WPre<P, HD / KS> w3zt;
         WPre<P, 32 / KS> wmvt;
-        if (wave == 0) wprefetch<P, HD / KS>(w3zt, W3ztr);
-        wprefetch<P, 32 / KS>(wmvt, Wmvtr);
+        if (wave == 0) wprefetch<P, HD / KS>(w3zt, W3ztr, S1);
+        wprefetch<P, 32 / KS>(wmvt, Wmvtr, S4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d1r[r] * d1r[r]);
-        put_tile<P>(dv, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(11);
         // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w3zt, W3ztr, Hbr);
+            gemm_block<P, HD / KS>(acc, w3zt, W3ztr, Hbr, S1);
             float dml[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -590,21 +617,21 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(12);
         // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
         zero_acc<P>(acc);
-        gemm_block<P, 32 / KS>(acc, wmvt, Wmvtr, Zbr);
+        gemm_block<P, 32 / KS>(acc, wmvt, Wmvtr, Zbr, S4);
         WPre<P, HD / KS> w2t;
-        wprefetch<P, HD / KS>(w2t, W2tr);
+        wprefetch<P, HD / KS>(w2t, W2tr, S4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);
-        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
         __syncthreads();
 
         DVAE_STAMP(13);
         // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2t, W2tr, Har);
+        gemm_block<P, HD / KS>(acc, w2t, W2tr, Har, S4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
-        put_tile<P>(dv, nullptr, 0, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T, g.Bp, b0, l31, h);
+        put_tile<P>(dv, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
 
         DVAE_STAMP(14);
         // ---------------- per-tile loss sums ----------------
@@ -636,7 +663,10 @@ struct GroupDesc {
     int32_t ldo[2];          // row stride of the destination tensor of A block i
     int32_t mvalid[2];
     int32_t nvalid[2];
-    int32_t pad[2];
+    int32_t split16;         // A block 0 holds two 16-row tensors (mu | log_var heads): rows >= 16 go to the *_hi targets
+    int32_t ldo_hi;
+    int64_t out_off_hi[2];
+    int64_t bias_off_hi;
 };
 
 template <typename P, bool A1, bool B1>
@@ -645,36 +675,39 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP, CH = 2;
-    const T* a0p = (const T*)d.A[0] + (int64_t)l31 * Bp + h * E;
-    const T* a1p = A1 ? (const T*)d.A[1] + (int64_t)l31 * Bp + h * E : a0p;
-    const T* b0p = (const T*)d.Bm[0] + (int64_t)l31 * Bp + h * E;
-    const T* b1p = B1 ? (const T*)d.Bm[1] + (int64_t)l31 * Bp + h * E : b0p;
+    const int lane = h * 32 + l31;
+    constexpr int FB = 64 * E;                              // elements per (feature tile, k-step) block
+    const T* a0p = (const T*)d.A[0] + lane * E;
+    const T* a1p = A1 ? (const T*)d.A[1] + lane * E : a0p;
+    const T* b0p = (const T*)d.Bm[0] + lane * E;
+    const T* b1p = B1 ? (const T*)d.Bm[1] + lane * E : b0p;
     const bool bias0 = d.bias_off[0] >= 0, bias1 = A1 && d.bias_off[1] >= 0;
     f32x16 c00, c01, c10, c11, cb0, cb1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; cb0[i] = 0.f; cb1[i] = 0.f; }
     const Frag one = P::ones();
+    const int64_t sbeg = kbeg / KS, send = kend / KS;       // k-steps of this frame slice
     Frag a0[CH], a1[CH], b0[CH], b1[CH];
-    if (kbeg < kend) {
+    if (sbeg < send) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            a0[i] = *reinterpret_cast<const Frag*>(a0p + kbeg + i * KS);
-            b0[i] = *reinterpret_cast<const Frag*>(b0p + kbeg + i * KS);
-            if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + kbeg + i * KS);
-            if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + kbeg + i * KS);
+            a0[i] = *reinterpret_cast<const Frag*>(a0p + (sbeg + i) * FB);
+            b0[i] = *reinterpret_cast<const Frag*>(b0p + (sbeg + i) * FB);
+            if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + (sbeg + i) * FB);
+            if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + (sbeg + i) * FB);
         }
     }
 #pragma unroll 1
-    for (int64_t k = kbeg; k < kend; k += CH * KS) {
-        int64_t kn = k + CH * KS;
-        if (kn >= kend) kn = k;                 // last pass: harmless reload instead of a branch around the loads
+    for (int64_t sk = sbeg; sk < send; sk += CH) {
+        int64_t sn = sk + CH;
+        if (sn >= send) sn = sk;                // last pass: harmless reload instead of a branch around the loads
         Frag a0n[CH], a1n[CH], b0n[CH], b1n[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            a0n[i] = *reinterpret_cast<const Frag*>(a0p + kn + i * KS);
-            b0n[i] = *reinterpret_cast<const Frag*>(b0p + kn + i * KS);
-            if (A1) a1n[i] = *reinterpret_cast<const Frag*>(a1p + kn + i * KS);
-            if (B1) b1n[i] = *reinterpret_cast<const Frag*>(b1p + kn + i * KS);
+            a0n[i] = *reinterpret_cast<const Frag*>(a0p + (sn + i) * FB);
+            b0n[i] = *reinterpret_cast<const Frag*>(b0p + (sn + i) * FB);
+            if (A1) a1n[i] = *reinterpret_cast<const Frag*>(a1p + (sn + i) * FB);
+            if (B1) b1n[i] = *reinterpret_cast<const Frag*>(b1p + (sn + i) * FB);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the next chunk's loads above this chunk's MFMAs
 #pragma unroll
@@ -697,9 +730,12 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
     for (int r = 0; r < 16; ++r) {
         const int row = feat_of(r, h);
         if (row < d.mvalid[0]) {
-            if (l31 < d.nvalid[0]) slab[d.out_off[0][0] + (int64_t)row * d.ldo[0] + l31] = c00[r];
-            if (B1) { if (l31 < d.nvalid[1]) slab[d.out_off[0][1] + (int64_t)row * d.ldo[0] + l31] = c01[r]; }
-            if (bias0 && l31 == 0) slab[d.bias_off[0] + row] = cb0[r];
+            const bool hi = d.split16 && row >= 16;
+            const int rr = hi ? row - 16 : row;
+            const int ldo = hi ? d.ldo_hi : d.ldo[0];
+            if (l31 < d.nvalid[0]) slab[(hi ? d.out_off_hi[0] : d.out_off[0][0]) + (int64_t)rr * ldo + l31] = c00[r];
+            if (B1) { if (l31 < d.nvalid[1]) slab[(hi ? d.out_off_hi[1] : d.out_off[0][1]) + (int64_t)rr * ldo + l31] = c01[r]; }
+            if (bias0 && l31 == 0) slab[(hi ? d.bias_off_hi : d.bias_off[0]) + rr] = cb0[r];
         }
         if (A1) {
             if (row < d.mvalid[1]) {
@@ -746,26 +782,32 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ sl
 struct TensorDesc {
     int64_t off;          // float offset in the flat parameter buffer
     int32_t rows, cols;
-    int64_t sf_off;       // forward copy: element offset in the weight-copy buffer, -1 = none
-    int32_t sf_ld, sf_split, sf_gap, pad0;   // column c lands at c (c < split) or c + gap
-    int64_t st_off;       // transposed copy (for backward-data), -1 = none
-    int32_t st_ld, st_roff, st_cmax, pad1;   // element (r, c < cmax) lands at [c][r + roff]
+    // kernel-layout ("fragment-major") copies: element (row, col) of a [rows][ns * KSTEP] matrix sits at
+    //   off + (((col / KSTEP) * nt + row / 32) * 64 + ((col % KSTEP) / E) * 32 + row % 32) * E + col % E      (nt = row tiles)
+    int64_t sf_off;       // forward copy (A operand of the layer), -1 = none
+    int32_t sf_nt, sf_split, sf_gap, sf_roff;   // column c -> c (c < split) or c + gap; row r -> r + roff
+    int32_t sf_ld, st_ld;                       // row strides of the row-major variant (WFRAG == false)
+    int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
+    int32_t st_nt, st_roff, st_cmax, pad1;      // element (r, c < cmax) -> row c, column r + roff
 };
 
 struct ApplyArgs {
     float* p; float* m; float* v;
     const float* slabs; int64_t slab_stride; int nslabs;
     const TensorDesc* tensors; int ntensors;
+    const unsigned char* chunk_tensor; int64_t n_params;
     void* wcopy;
     float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
     const double* partials; int npartials; int64_t B; float* losses3;
 };
 
+// One thread per parameter over the flat buffer (every load independent); chunk_tensor maps each
+// 64-float chunk to its tensor (tensors start on 64-float boundaries), 255 = alignment padding.
+// The block after the last parameter block finalises the loss scalars.
 template <typename T, bool ADAM>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
-    const int t = blockIdx.y;
-    if (t == g.ntensors) {                    // loss finalisation block
-        if (!ADAM || blockIdx.x != 0 || g.losses3 == nullptr) return;
+    if (blockIdx.x == gridDim.x - 1) {                    // loss finalisation block
+        if (!ADAM || g.losses3 == nullptr) return;
         __shared__ double red[4][2];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         double a = 0.0, k = 0.0;
@@ -780,25 +822,36 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
         }
         return;
     }
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.n_params) return;
+    const int t = g.chunk_tensor[idx >> 6];
+    if (t == 255) return;
     const TensorDesc d = g.tensors[t];
-    const int64_t n = (int64_t)d.rows * d.cols;
+    const int64_t i = idx - d.off;
+    if (i >= (int64_t)d.rows * d.cols) return;
     T* wc = (T*)g.wcopy;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t idx = d.off + i;
-        float pi = g.p[idx];
-        if (ADAM) {
-            float gi = g.slabs[idx];
-            for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
-            gi *= g.gscale;
-            const float mi = g.m[idx] + g.one_minus_b1 * (gi - g.m[idx]);
-            const float vi = g.v[idx] * g.b2 + g.one_minus_b2 * (gi * gi);
-            const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
-            pi = pi - g.step_size * (mi / denom);
-            g.p[idx] = pi; g.m[idx] = mi; g.v[idx] = vi;
-        }
-        const int r = (int)(i / d.cols), c = (int)(i - (int64_t)r * d.cols);
-        if (d.sf_off >= 0) wc[d.sf_off + (int64_t)r * d.sf_ld + (c < d.sf_split ? c : c + d.sf_gap)] = (T)pi;
-        if (d.st_off >= 0 && c < d.st_cmax) wc[d.st_off + (int64_t)c * d.st_ld + r + d.st_roff] = (T)pi;
+    float pi = g.p[idx];
+    if (ADAM) {
+        float gi = g.slabs[idx];
+        for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
+        gi *= g.gscale;
+        const float mi = g.m[idx] + g.one_minus_b1 * (gi - g.m[idx]);
+        const float vi = g.v[idx] * g.b2 + g.one_minus_b2 * (gi * gi);
+        const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
+        pi = pi - g.step_size * (mi / denom);
+        g.p[idx] = pi; g.m[idx] = mi; g.v[idx] = vi;
+    }
+    const int r = (int)(i / d.cols), c = (int)(i - (int64_t)r * d.cols);
+    constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
+    if (d.sf_off >= 0) {
+        const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
+        if (WFRAG) wc[d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E] = (T)pi;
+        else wc[d.sf_off + (int64_t)rr * d.sf_ld + cc] = (T)pi;
+    }
+    if (d.st_off >= 0 && c < d.st_cmax) {
+        const int rr = c, cc = r + d.st_roff;
+        if (WFRAG) wc[d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E] = (T)pi;
+        else wc[d.st_off + (int64_t)rr * d.st_ld + cc] = (T)pi;
     }
 }
 
@@ -811,7 +864,7 @@ struct Layout {
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
-    int64_t o_tiles, o_tensors, o_partials, o_wcopy, o_stash, o_grads, total;
+    int64_t o_tiles, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
     int ntiles;
 };
 
@@ -844,6 +897,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     auto bytes = [&](int64_t n) { int64_t q = b; b += al(n, 256); return q; };
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
+    L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 2 * sizeof(double));
     L.o_wcopy = bytes(L.wcopy_elems * esz);
     L.o_stash = bytes(L.stash_rows * p.Bp * esz);
@@ -920,7 +974,7 @@ static int64_t kper_of(const dvae_train_plan_t* p) {
     return al((p->Bp + p->ksplit - 1) / p->ksplit, unit);
 }
 
-struct ABlock { int64_t row; int mvalid; int tensor; int m0; int bias_tensor; };
+struct ABlock { int64_t row; int mvalid; int tensor; int m0; int bias_tensor; int tensor_hi; int bias_hi; };
 struct BBlock { int64_t row; int nvalid; int col; };
 
 template <typename T>
@@ -933,7 +987,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     BBlock bb[64];
     int na = 0, nb = 0;
     auto addA = [&](int64_t row0, int M, int tensor, int bias_tensor) {
-        for (int m0 = 0; m0 < M; m0 += 32) ab[na++] = ABlock{row0 + m0, M - m0 < 32 ? M - m0 : 32, tensor, m0, bias_tensor};
+        for (int m0 = 0; m0 < M; m0 += 32) ab[na++] = ABlock{row0 + m0, M - m0 < 32 ? M - m0 : 32, tensor, m0, bias_tensor, -1, -1};
     };
     auto addB = [&](int64_t row0, int N, int col0) {
         for (int n0 = 0; n0 < N; n0 += 32) bb[nb++] = BBlock{row0 + n0, N - n0 < 32 ? N - n0 : 32, col0 + n0};
@@ -954,6 +1008,12 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
                     for (int jj = 0; jj < 2; ++jj) {
                         if (j + jj >= nb) continue;
                         d.out_off[ii][jj] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * d.ldo[ii] + bb[j + jj].col;
+                        if (ii == 0 && a.tensor_hi >= 0) d.out_off_hi[jj] = p->tensor_offset[a.tensor_hi] + bb[j + jj].col;
+                    }
+                    if (ii == 0 && a.tensor_hi >= 0) {
+                        d.split16 = 1;
+                        d.ldo_hi = p->tensor_cols[a.tensor_hi];
+                        d.bias_off_hi = p->tensor_offset[a.bias_hi];
                     }
                 }
                 for (int jj = 0; jj < 2; ++jj) {
@@ -968,7 +1028,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     const int ye = p->model == DVAE_MODEL_M2 ? p->y_dim : 0, yd = p->y_dim;
     addA(L.dh1T, HD, 0, 1); addB(L.xT, XD, 0); if (ye) addB(L.yT, ye, XD); emit();
     addA(L.dh2T, HD, 2, 3); addB(L.h1T, HD, 0); emit();
-    ab[na++] = ABlock{L.dmlvT, ZD, 4, 0, 5}; ab[na++] = ABlock{L.dmlvT + ZD, ZD, 6, 0, 7}; addB(L.h2T, HD, 0); emit();
+    ab[na++] = ABlock{L.dmlvT, 32, 4, 0, 5, 6, 7}; addB(L.h2T, HD, 0); emit();   // one tile: rows 0-15 mu head, 16-31 log_var head
     addA(L.dd1T, HD, 8, 9); addB(L.zT, ZD, 0); if (yd) addB(L.yT, yd, ZD); emit();
     addA(L.dd2T, HD, 10, 11); addB(L.d1T, HD, 0); emit();
     addA(L.daT, XD, 12, 13); addB(L.d2T, HD, 0); emit();
@@ -981,13 +1041,15 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
         t.sf_off = -1; t.st_off = -1; t.sf_split = 1 << 30;
         td[i] = t;
     }
-    td[0].sf_off = L.W1s; td[0].sf_ld = L.ld1; td[0].sf_split = XD; td[0].sf_gap = XP - XD;
-    td[2].sf_off = L.W2s; td[2].sf_ld = HD; td[2].st_off = L.W2t; td[2].st_ld = HD; td[2].st_cmax = HD;
-    td[4].sf_off = L.Wmvs; td[4].sf_ld = HD; td[4].st_off = L.Wmvt; td[4].st_ld = 32; td[4].st_cmax = HD;
-    td[6].sf_off = L.Wmvs + 16 * HD; td[6].sf_ld = HD; td[6].st_off = L.Wmvt; td[6].st_ld = 32; td[6].st_roff = 16; td[6].st_cmax = HD;
-    td[8].sf_off = L.W3s; td[8].sf_ld = L.ld3; td[8].st_off = L.W3zt; td[8].st_ld = HD; td[8].st_cmax = ZD;
-    td[10].sf_off = L.W4s; td[10].sf_ld = HD; td[10].st_off = L.W4t; td[10].st_ld = HD; td[10].st_cmax = HD;
-    td[12].sf_off = L.W5s; td[12].sf_ld = HD; td[12].st_off = L.W5t; td[12].st_ld = NO; td[12].st_cmax = HD;
+    td[0].sf_ld = L.ld1; td[2].sf_ld = HD; td[4].sf_ld = HD; td[6].sf_ld = HD; td[8].sf_ld = L.ld3; td[10].sf_ld = HD; td[12].sf_ld = HD;
+    td[2].st_ld = HD; td[4].st_ld = 32; td[6].st_ld = 32; td[8].st_ld = HD; td[10].st_ld = HD; td[12].st_ld = NO;
+    td[0].sf_off = L.W1s; td[0].sf_nt = 4; td[0].sf_split = XD; td[0].sf_gap = XP - XD;
+    td[2].sf_off = L.W2s; td[2].sf_nt = 4; td[2].st_off = L.W2t; td[2].st_nt = 4; td[2].st_cmax = HD;
+    td[4].sf_off = L.Wmvs; td[4].sf_nt = 1; td[4].st_off = L.Wmvt; td[4].st_nt = 4; td[4].st_cmax = HD;
+    td[6].sf_off = L.Wmvs; td[6].sf_nt = 1; td[6].sf_roff = 16; td[6].st_off = L.Wmvt; td[6].st_nt = 4; td[6].st_roff = 16; td[6].st_cmax = HD;
+    td[8].sf_off = L.W3s; td[8].sf_nt = 4; td[8].st_off = L.W3zt; td[8].st_nt = 1; td[8].st_cmax = ZD;
+    td[10].sf_off = L.W4s; td[10].sf_nt = 4; td[10].st_off = L.W4t; td[10].st_nt = 4; td[10].st_cmax = HD;
+    td[12].sf_off = L.W5s; td[12].sf_nt = NT_OUT; td[12].st_off = L.W5t; td[12].st_nt = 4; td[12].st_cmax = HD;
 }
 
 static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* params, float* m, float* v, char* ws, int n_slabs,
@@ -998,6 +1060,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
     a.p = params; a.m = m; a.v = v;
     a.slabs = (const float*)(ws + L.o_grads); a.slab_stride = plan->n_params; a.nslabs = n_slabs;
     a.tensors = (const TensorDesc*)(ws + L.o_tensors); a.ntensors = plan->n_tensors;
+    a.chunk_tensor = (const unsigned char*)(ws + L.o_chunks); a.n_params = plan->n_params;
     a.wcopy = ws + L.o_wcopy;
     if (adam) {
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -1005,12 +1068,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
         a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)adam_eps; a.gscale = (float)grad_scale;
     }
     a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3;
-    int64_t maxn = 1;
-    for (int i = 0; i < plan->n_tensors; ++i) {
-        const int64_t ne = (int64_t)plan->tensor_rows[i] * plan->tensor_cols[i];
-        if (ne > maxn) maxn = ne;
-    }
-    const dim3 grid((unsigned)((maxn + 255) / 256), plan->n_tensors + 1);   // one element per thread: all loads independent
+    const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
     if (plan->precision == DVAE_PREC_BF16) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((apply_kernel<__bf16, false>), grid, dim3(256), 0, s, a);
@@ -1045,9 +1103,18 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     else fill_tables<float>(plan, L, w, tiles, td);
     hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(GroupDesc), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
+    const int64_t nchunks = plan->n_params / 64;
+    unsigned char* ct = new unsigned char[nchunks + 64];
+    memset(ct, 255, (size_t)nchunks + 64);
+    for (int t = 0; t < plan->n_tensors; ++t) {
+        const int64_t c0 = plan->tensor_offset[t] / 64, ne = (int64_t)plan->tensor_rows[t] * plan->tensor_cols[t];
+        for (int64_t c = c0; c < c0 + (ne + 63) / 64; ++c) ct[c] = (unsigned char)t;
+    }
+    hipError_t e4 = hipMemcpyAsync(w + L.o_chunks, ct, (size_t)nchunks, hipMemcpyHostToDevice, s);
     hipError_t e3 = hipStreamSynchronize(s);
     delete[] tiles;
-    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e3);
+    delete[] ct;
+    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e3);
     return dvae_train_repack(plan, params, ws, stream);
 }
 

@@ -1,18 +1,21 @@
-"""Diagnostic: phase shares of the rows kernel from in-kernel wall-clock stamps (100 MHz)."""
+"""Diagnostic: phase shares of the rows kernel from in-kernel wall-clock stamps (100 MHz).
+usage: stamp_rows.py [bf16|fp32] [B] [noapply]"""
 import importlib, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 import numpy as np, torch
 import golden_util as gu
 T = importlib.import_module("disentangled-vae_amd.trainer"); N = importlib.import_module("disentangled-vae_amd.native")
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"; B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+noapply = len(sys.argv) > 3 and sys.argv[3] == "noapply"
 dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
 tr = T.Trainer("M2", dims, None, batch=B, precision=prec, seed=0)
 x, y, e = (torch.from_numpy(a).cuda() for a in gu.make_batch(dims, B, 1))
-for _ in range(5): tr.step(x, y, e)
+run = (lambda: tr.grads_only(x, y, e)) if noapply else (lambda: tr.step(x, y, e))
+for _ in range(5): run()
 buf = torch.zeros(tr.plan.rows_grid * 32, dtype=torch.int64, device="cuda")
-N.load().dvae_train_debug_stamps(N.ptr(buf)); tr.step(x, y, e); torch.cuda.synchronize(); N.load().dvae_train_debug_stamps(None)
+N.load().dvae_train_debug_stamps(N.ptr(buf)); run(); torch.cuda.synchronize(); N.load().dvae_train_debug_stamps(None)
 s = buf.cpu().numpy().reshape(-1, 32)[:, :16].astype(np.float64) * 0.01      # us
-names = ["x load+stage", "x stash", "L1 x gemm", "y load+stash+gemm", "h1 epilogue", "L2", "heads", "dec L1", "dec L2", "out layer", "bwd d2", "bwd d1", "bwd z", "bwd h2", "bwd h1", ]
+names = ["x load+commit+stash", "L1 x gemm", "y load+stash+L1 y gemm", "h1 epilogue", "L2", "heads", "dec L1", "dec L2", "out layer", "bwd d2", "bwd d1", "bwd z", "bwd h2", "bwd h1", "loss sums"]
 d = np.diff(s, axis=1)
-print(f"{prec} B={B}: kernel span {s[:,15].max()-s[:,0].min():.1f} us; per-WG total median {np.median(s[:,15]-s[:,0]):.1f} us; start skew {s[:,0].max()-s[:,0].min():.1f} us")
-for i, n in enumerate(names): print(f"  {n:22s} median {np.median(d[:, i]):7.2f} us   max {d[:, i].max():7.2f}")
+print(f"{prec} B={B} {'grads only' if noapply else 'full step'}: kernel span {s[:,15].max()-s[:,0].min():.1f} us; per-WG median {np.median(s[:,15]-s[:,0]):.1f} us; start skew {s[:,0].max()-s[:,0].min():.1f} us")
+print("  " + "  ".join(f"{n}={np.median(d[:, i]):.2f}" for i, n in enumerate(names)))
