@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import native as N
+from . import dp
 
 MAXT = 32
 
@@ -163,10 +164,9 @@ class Trainer:
                                              self.betas[1], self.adam_eps, N.ptr(self.losses), s), "dvae_train_step")
             self._reduced = False
         else:
-            import torch.distributed as dist
             N.check(self.lib.dvae_train_grads(plan, N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
                                               self.elbo_eps, 1, s), "dvae_train_grads")
-            dist.all_reduce(self.flat_grad, group=self.pg)          # RCCL over xGMI: one flat fp32 buffer per step
+            dp.allreduce_flat_(self.flat_grad, self.pg)              # RCCL over xGMI: one flat fp32 buffer per step
             N.check(self.lib.dvae_train_apply(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), 1, self.step_count,
                                               self.lr, self.betas[0], self.betas[1], self.adam_eps, 1.0 / self.world,
                                               N.ptr(self.losses), s), "dvae_train_apply")

@@ -140,3 +140,53 @@ def test_state_dict_round_trip_and_repack():
     np.testing.assert_array_equal(l1, l2)
     with pytest.raises(NotImplementedError):
         trainer.Trainer("M2", dict(x_dim=513, y_dim=7, z_dim=16, h_dim=(128, 128)), None, batch=8)
+
+
+def _dp_worker(rank, world, port, q):
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import importlib, numpy as np, torch, torch.distributed as dist
+    import golden_util as gu
+    tr_mod = importlib.import_module("disentangled-vae_amd.trainer")
+    dp = importlib.import_module("disentangled-vae_amd.dp")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    Bg = 512
+    lo, hi = dp.shard_rows(Bg, rank, world)
+    tr = tr_mod.Trainer("M2", dims, gu.make_params("M2", dims, 21), batch=hi - lo, precision="fp32",
+                        process_group=dist.group.WORLD, world=world)
+    for step in range(2):
+        x, y, e = gu.make_batch(dims, Bg, 30 + step)
+        t = lambda a: torch.from_numpy(a[lo:hi].copy()).cuda()
+        losses = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+    q.put((rank, tr.state_dict_numpy(), losses))
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_single_process():
+    """2 ranks (sharing the one GPU, gloo in place of RCCL) == 1 rank on the concatenated batch."""
+    import torch.multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    tr = trainer.Trainer("M2", dims, gu.make_params("M2", dims, 21), batch=512, precision="fp32")
+    for step in range(2):
+        x, y, e = gu.make_batch(dims, 512, 30 + step)
+        t = lambda a: torch.from_numpy(a).cuda()
+        losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+    ref = tr.state_dict_numpy()
+    for k in ref:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k                      # replicas identical
+        assert np.max(np.abs(res[0][1][k] - ref[k])) <= 2e-6, k                   # == single process (fp32 sum order)
+    np.testing.assert_allclose(0.5 * (res[0][2] + res[1][2]), losses, rtol=1e-5)
