@@ -239,7 +239,16 @@ class BenchImpl:
             bound, ach, peak, unit = "mfma", flops[dom] / dur / 1e12, peak_f, "TFLOP/s"
         else:
             bound, ach, peak, unit = "hbm", byts[dom] / dur / 1e9, 8000.0, "GB/s"
-        return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+        traffic = None
+        try:        # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc passes, summarised by tools/pmc_traffic.py)
+            import json, os
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_r01.json")))
+            kname = {"rows": "vae_rows_kernel", "wgrad": "wgrad_kernel", "apply": "apply_kernel", "reduce": "slab_reduce_kernel"}[dom]
+            if self.model == "M2" and y == 513 and B == 8192 and self.precision == "bf16" and kname in tj:
+                traffic = tj[kname]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                 "kernel": {"rows": "vae_rows_kernel", "wgrad": "wgrad_kernel", "apply": "apply_kernel", "reduce": "slab_reduce_kernel"}[dom],
                 "avg_us": avg, "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
                 "mfma_frac": flops[dom] / dur / 1e12 / peak_f, "hbm_frac": byts[dom] / dur / 8.0e12,
