@@ -39,7 +39,7 @@ constexpr int NT_OUT = 17;
 // wave load).  Measured on MI355X (B = 8192, 256 workgroups in lockstep): fragment-major weights made the wide
 // GEMM phases 3-4x SLOWER (L1 x-block 8.4 us vs 2.3 us) in both block orders, so row-major is used; the stash
 // (written and read once, by different kernels) is fragment-major, which cut the wgrad kernel from 37 to 23 us.
-constexpr bool WFRAG = false;
+constexpr bool WFRAG = true;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -52,6 +52,7 @@ struct PolF32 {
     static constexpr int KSTEP = 8;    // reduction depth per fragment pair
     static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
     static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
+    static constexpr int WRING = 4;    // wgrad: k-steps of operand fragments in flight per wave
     static constexpr bool XFULL = false;   // fp32 x tile does not fit LDS next to fp32 activations: streamed in 128-column slices
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
@@ -74,6 +75,7 @@ struct PolBF16 {
     static constexpr int KSTEP = 16;
     static constexpr int PD = 16;
     static constexpr int PRE = 6;
+    static constexpr int WRING = 8;
     static constexpr bool XFULL = true;    // whole fp32 x tile stays in LDS for the loss epilogue
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
@@ -115,11 +117,24 @@ template <typename P, int NSTEPS> struct WPre {
     typename P::Frag a[N > 0 ? N : 1];
 };
 
+// Weight fragments are fetched with buffer loads: one resource descriptor for the whole weight-copy
+// buffer, the per-lane byte offset in ONE VGPR and the (matrix, row tile, k-step) offset in an SGPR.
+// With plain 64-bit global addresses hipcc materialises one VGPR address pair per in-flight fragment
+// whenever the k-step stride exceeds the 4 KB immediate range, spills them, and reloads each from
+// scratch behind an s_waitcnt vmcnt(0) in front of every weight load (measured: 600 cycles per k-step).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct WRef { int voff; unsigned soff; };      // per-lane byte offset (VGPR), wave-uniform byte offset (SGPR)
+
+template <typename P>
+__device__ __forceinline__ typename P::Frag wload(__amdgpu_buffer_rsrc_t rs, WRef r, unsigned step_bytes) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, r.voff, r.soff + step_bytes, 0);
+    return __builtin_bit_cast(typename P::Frag, v);
+}
+
 template <typename P, int NSTEPS>
-__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow, int WSTR) {
-    typedef typename P::Frag Frag;
+__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, __amdgpu_buffer_rsrc_t rs, WRef wr, unsigned WSTR) {
 #pragma unroll
-    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = *reinterpret_cast<const Frag*>(wrow + i * WSTR);
+    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = wload<P>(rs, wr, i * WSTR);
     // hipcc otherwise sinks these loads down to their first use (after the epilogue and barrier)
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -128,30 +143,48 @@ __device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, const typename P::
 // L2 into a ring of D = min(PD, NSTEPS) fragment registers: the slot an MFMA has just consumed is
 // re-requested D steps ahead, so D loads per wave stay in flight (an L2 round trip under load is
 // ~1000 cycles, an MFMA step 32).  Activations come from LDS.  Only the outer loop is rolled.
-template <typename P, int NSTEPS>
-__device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, const typename P::T* __restrict__ wrow,
-                                           const typename P::T* brow, int WSTR) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_fill` runs once the ring is requested and before the first MFMA: the place for global STORES
+// (the previous layer's stash tile).  vmcnt retires loads and stores in issue order, so a store issued
+// right before a load that the next MFMA needs exposes a full write-acknowledge round trip; issued
+// here, the store acks overlap the D k-steps the ring already covers.
+template <typename P, int NSTEPS, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, __amdgpu_buffer_rsrc_t rs, WRef wr,
+                                           const typename P::T* brow, unsigned WSTR, Hook after_fill = Hook()) {
     typedef typename P::Frag Frag;
     constexpr int STR = 2 * P::E;        // LDS activations: k-step = 2E consecutive features of a frame row
     constexpr int D = NSTEPS < P::PD ? NSTEPS : P::PD;
     constexpr int NIT = D > 0 ? NSTEPS / D : 0, REM = D > 0 ? NSTEPS % D : 0;
+    // activation fragments are read from LDS BD k-steps ahead; BD divides D so ring slots are static across laps
+    constexpr int BD = D % 4 == 0 ? 4 : (D % 3 == 0 ? 3 : (D % 2 == 0 ? 2 : 1));
+    static_assert(NIT <= 1 || D % BD == 0, "B ring must divide the weight ring");
     Frag a[D > 0 ? D : 1];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         if (i < WPre<P, NSTEPS>::N) a[i] = w.a[i];
-        else a[i] = *reinterpret_cast<const Frag*>(wrow + i * WSTR);
+        else a[i] = wload<P>(rs, wr, i * WSTR);
     }
     // Order pins: without them hipcc moves every weight load down to just above the MFMA that
     // consumes it (one exposed L2 round trip per k-step, measured 150 ns/step instead of ~30).
     __builtin_amdgcn_sched_barrier(0);
+    after_fill();
+    __builtin_amdgcn_sched_barrier(0);
+    // B ring: with the order pinned, an LDS read issued right before its MFMA exposes the full LDS
+    // latency every k-step (measured ~250 cycles/step on an idle chip); keep BD reads in flight instead.
+    Frag bq[BD];
+#pragma unroll
+    for (int i = 0; i < BD; ++i)
+        if (i < NSTEPS) bq[i] = *reinterpret_cast<const Frag*>(brow + i * STR);
     if (NIT > 1) {
 #pragma unroll 1
         for (int c = 0; c < NIT - 1; ++c) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                const Frag b = *reinterpret_cast<const Frag*>(brow + (c * D + i) * STR);
-                P::mma(acc, a[i], b);
-                a[i] = *reinterpret_cast<const Frag*>(wrow + ((c + 1) * D + i) * WSTR);
+                P::mma(acc, a[i], bq[i % BD]);
+                // D is a multiple of BD whenever NIT > 1, so slot i % BD is static across laps
+                bq[i % BD] = *reinterpret_cast<const Frag*>(brow + (c * D + i + BD) * STR);
+                a[i] = wload<P>(rs, wr, ((c + 1) * D + i) * WSTR);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -159,16 +192,19 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w
     if (NIT > 0) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const Frag b = *reinterpret_cast<const Frag*>(brow + ((NIT - 1) * D + i) * STR);
-            P::mma(acc, a[i], b);
-            if (i < REM) a[i] = *reinterpret_cast<const Frag*>(wrow + (NIT * D + i) * WSTR);
+            constexpr int base = (NIT - 1) * D;
+            P::mma(acc, a[i], bq[(base + i) % BD]);
+            if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
+            if (i < REM) a[i] = wload<P>(rs, wr, (NIT * D + i) * WSTR);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
-        const Frag b = *reinterpret_cast<const Frag*>(brow + (NIT * D + i) * STR);
-        P::mma(acc, a[i], b);
+        constexpr int base = NIT * D;
+        P::mma(acc, a[i], bq[(base + i) % BD]);
+        if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -182,6 +218,7 @@ struct RowsArgs {
     const void *W1s, *W2s, *Wmvs, *W3s, *W4s, *W5s, *W5t, *W4t, *W3zt, *Wmvt, *W2t;
     const float *b1, *b2, *bmu, *blv, *b3, *b4, *b5;
     void *xT, *yT, *h1T, *h2T, *dh1T, *dh2T, *dmlvT, *zT, *d1T, *d2T, *dd1T, *dd2T, *daT;
+    const void* wcopy; int64_t wcopy_bytes;   // whole weight-copy buffer (L2 warm-up)
     double* partials;
     unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
@@ -213,28 +250,33 @@ __device__ __forceinline__ void bias16(const float* bl, int fbase, int h, float 
 // go to LDS [frame][feature] (the next layer's B operand); the same wave then reads its own 32
 // columns back transposed (E consecutive frames of one feature = one fragment) for the stash.
 template <typename P>
-__device__ __forceinline__ void put_tile(const float (&v)[16], typename P::T* lds, int ldl, int fbase,
-                                         typename P::T* stash_tile, int64_t Bp, int64_t b0, int l31, int h) {
-    typedef typename P::T T;
+__device__ __forceinline__ void put_lds(const float (&v)[16], typename P::T* lds, int ldl, int fbase, int l31, int h) {
     typedef typename P::Pack4 Pack4;
-    typedef typename P::Frag Frag;
-    constexpr int E = P::E;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         Pack4 p;
         p[0] = P::cvt(v[4 * gq]); p[1] = P::cvt(v[4 * gq + 1]); p[2] = P::cvt(v[4 * gq + 2]); p[3] = P::cvt(v[4 * gq + 3]);
         *reinterpret_cast<Pack4*>(lds + l31 * ldl + fbase + 8 * gq + 4 * h) = p;
     }
-    if (stash_tile) {
-        T* dst = stash_tile + (b0 / P::KSTEP) * (64 * E) + l31 * E;
+}
+
+// LDS tile [32 frames][features fbase .. fbase+31] -> fragment-major stash tile (E consecutive frames of
+// one feature = one 16-byte fragment).  Called by the wave that wrote those LDS columns.
+template <typename P>
+__device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr,
+                                           int64_t b0, int l31, int h) {
+    typedef typename P::T T;
+    typedef typename P::Frag Frag;
+    constexpr int E = P::E;
+    if (stash_tile_ptr == nullptr) return;
+    T* dst = stash_tile_ptr + (b0 / P::KSTEP) * (64 * E) + l31 * E;
 #pragma unroll
-        for (int i = 0; i < TB / (2 * E); ++i) {
-            const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
-            Frag f;
+    for (int i = 0; i < TB / (2 * E); ++i) {
+        const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
+        Frag f;
 #pragma unroll
-            for (int j = 0; j < E; ++j) f[j] = lds[(gq * E + j) * ldl + fbase + l31];
-            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
-        }
+        for (int j = 0; j < E; ++j) f[j] = lds[(gq * E + j) * ldl + fbase + l31];
+        *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
     }
 }
 
@@ -352,25 +394,33 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     // fragment-major weight copies: [k-step][row tile][lane][E] (k-step major: the fragments a wave keeps in
     // flight then sit >= 4 KB apart and spread over the L2 channels); this wave's tile = wave in 128-row layers
     constexpr int FB = 64 * E;                          // elements per (tile, k-step) block
-    // per-lane base of this wave's row tile in each weight copy, and the element stride between k-steps
-    auto wbase = [&](const void* Wp, int tile, int ld) -> const T* {
-        return WFRAG ? (const T*)Wp + tile * FB + lane * E : (const T*)Wp + (int64_t)(32 * tile + l31) * ld + h * E;
+    // weight copies through ONE buffer descriptor: per-lane byte offset + wave-uniform (matrix, tile) offset
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr unsigned SZ = sizeof(T);
+    auto wbase = [&](const void* Wp, int tile, int ld) -> WRef {
+        const unsigned m = (unsigned)((const char*)Wp - (const char*)g.wcopy);
+        if (WFRAG) return WRef{lane * 16, m + (unsigned)tile * (FB * SZ)};
+        return WRef{(int)((l31 * ld + h * E) * SZ), m + (unsigned)(32 * tile * ld) * SZ};
     };
-    constexpr int S4 = WFRAG ? 4 * FB : 2 * E, S1 = WFRAG ? FB : 2 * E, S17 = WFRAG ? NT_OUT * FB : 2 * E;
-    constexpr int TSTEP = WFRAG ? FB : 32 * HD;         // W5s: next row tile
-    constexpr int KB1 = WFRAG ? (XP / KS) * 4 * FB : XP; // W1: start of the y k-block
-    constexpr int KB3 = WFRAG ? (ZD / KS) * 4 * FB : ZD; // W3: start of the y k-block
-    const T* const W1r = wbase(g.W1s, wave, LD1);
-    const T* const W2r = wbase(g.W2s, wave, HD);
-    const T* const Wmvr = wbase(g.Wmvs, 0, HD);
-    const T* const W3r = wbase(g.W3s, wave, LD3);
-    const T* const W4r = wbase(g.W4s, wave, HD);
-    const T* const W5s = wbase(g.W5s, 0, HD);
-    const T* const W5tr = wbase(g.W5t, wave, NO);
-    const T* const W4tr = wbase(g.W4t, wave, HD);
-    const T* const W3ztr = wbase(g.W3zt, 0, HD);
-    const T* const Wmvtr = wbase(g.Wmvt, wave, 32);
-    const T* const W2tr = wbase(g.W2t, wave, HD);
+    // byte strides between k-steps (4-tile, 1-tile and 17-tile matrices), between row tiles of W5s, and the
+    // byte offsets of the y k-blocks inside W1 / W3
+    constexpr unsigned S4 = (WFRAG ? 4 * FB : 2 * E) * SZ, S1 = (WFRAG ? FB : 2 * E) * SZ, S17 = (WFRAG ? NT_OUT * FB : 2 * E) * SZ;
+    constexpr unsigned TSTEP = (WFRAG ? FB : 32 * HD) * SZ;
+    constexpr unsigned KB1 = (WFRAG ? (XP / KS) * 4 * FB : XP) * SZ;
+    constexpr unsigned KB3 = (WFRAG ? (ZD / KS) * 4 * FB : ZD) * SZ;
+    const WRef W1r = wbase(g.W1s, wave_u, LD1);
+    const WRef W2r = wbase(g.W2s, wave_u, HD);
+    const WRef Wmvr = wbase(g.Wmvs, 0, HD);
+    const WRef W3r = wbase(g.W3s, wave_u, LD3);
+    const WRef W4r = wbase(g.W4s, wave_u, HD);
+    const WRef W5s = wbase(g.W5s, 0, HD);
+    const WRef W5tr = wbase(g.W5t, wave_u, NO);
+    const WRef W4tr = wbase(g.W4t, wave_u, HD);
+    const WRef W3ztr = wbase(g.W3zt, 0, HD);
+    const WRef Wmvtr = wbase(g.Wmvt, wave_u, 32);
+    const WRef W2tr = wbase(g.W2t, wave_u, HD);
+    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes}; };
     const T* const Ur = U + l31 * LDU + h * E;
     const T* const Har = Ha + l31 * LDH + h * E;
     const T* const Hbr = Hb + l31 * LDH + h * E;
@@ -378,17 +428,31 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
     double tot_rec = 0.0, tot_kl = 0.0;
 
-    // fp32 bias table -> LDS once (epilogues must not queue global loads behind the weight prefetch)
-    for (int i = tid; i < Ld<T>::nbias; i += 256) {
-        float v;
-        if (i < OB2) v = g.b1[i];
-        else if (i < OBMV) v = g.b2[i - OB2];
-        else if (i < OBMV + ZD) v = g.bmu[i - OBMV];
-        else if (i < OB3) v = g.blv[i - OBMV - ZD];
-        else if (i < OB4) v = g.b3[i - OB3];
-        else if (i < OB5) v = g.b4[i - OB4];
-        else v = (i - OB5 < XD) ? g.b5[i - OB5] : 0.f;
-        Bias[i] = v;
+    // fp32 bias table -> LDS once (epilogues must not queue global loads behind the weight prefetch).
+    // All loads are issued before the first store (clamped addresses instead of branches).
+    {
+        constexpr int NB = (Ld<T>::nbias + 255) / 256;
+        float bvv[NB];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            int i = tid + 256 * it;
+            i = i < Ld<T>::nbias ? i : Ld<T>::nbias - 1;
+            const float* src;
+            int k;
+            if (i < OB2) { src = g.b1; k = i; }
+            else if (i < OBMV) { src = g.b2; k = i - OB2; }
+            else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
+            else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
+            else if (i < OB4) { src = g.b3; k = i - OB3; }
+            else if (i < OB5) { src = g.b4; k = i - OB4; }
+            else { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
+            bvv[it] = src[k];
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int i = tid + 256 * it;
+            if (i < Ld<T>::nbias) Bias[i] = (i >= OB5 + XD) ? 0.f : bvv[it];
+        }
     }
     __syncthreads();
 
@@ -415,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         }
         // ---------------- encoder layer 1: [x | y] -> h1 ----------------
         WPre<P, XP / KS> w1x;
-        wprefetch<P, XP / KS>(w1x, W1r, S4);
+        wprefetch<P, XP / KS>(w1x, wrs, W1r, S4);
         const bool yfast = Y513 && g.fasty && full;
         if (g.fastx && full) {
             f32x4 xv[NQ513];
@@ -425,16 +489,17 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, P::XFULL ? Xt : nullptr);
         }
         __syncthreads();
-        if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
         DVAE_STAMP(1);
         f32x16 acc;
         zero_acc<P>(acc);
-        gemm_block<P, XP / KS>(acc, w1x, W1r, Ur, S4);
+        gemm_block<P, XP / KS>(acc, w1x, wrs, W1r, Ur, S4, [&]() {
+            if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
+        });
         DVAE_STAMP(2);
         WPre<P, HD / KS> w2;
         WPre<P, (YENC ? YP : 0) / KS> w1y;
-        if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, W1r + KB1, S4);
-        else wprefetch<P, HD / KS>(w2, W2r, S4);
+        if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, wrs, woff(W1r, KB1), S4);
+        else wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
         if (YP > 0) {
             __syncthreads();
             if (Y513 && yfast) {
@@ -445,10 +510,13 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl);
             }
             __syncthreads();
-            if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
             if (YENC) {
-                gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, W1r + KB1, Ur, S4);
-                wprefetch<P, HD / KS>(w2, W2r, S4);
+                gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, wrs, woff(W1r, KB1), Ur, S4, [&]() {
+                    if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
+                });
+                wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
+            } else {
+                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
             }
         }
         float h1r[16], bv[16];
@@ -456,22 +524,22 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         bias16(Bias + OB1, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(h1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(h1r, Ha, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(4);
         // ---------------- encoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2, W2r, Har, S4);
+        gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
         WPre<P, HD / KS> wmv;
         WPre<P, ZD / KS> w3z;
-        if (wave == 0) wprefetch<P, HD / KS>(wmv, Wmvr, S1);
-        wprefetch<P, ZD / KS>(w3z, W3r, S4);
+        if (wave == 0) wprefetch<P, HD / KS>(wmv, wrs, Wmvr, S1);
+        wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
         float h2r[16];
         bias16(Bias + OB2, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(h2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(h2r, Hb, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(5);
@@ -479,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         float mu_r[8], lv_r[8], sd_r[8];
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, wmv, Wmvr, Hbr, S1);
+            gemm_block<P, HD / KS>(acc, wmv, wrs, Wmvr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
             float zv[16];
             bias16(Bias + OBMV, 0, h, bv);                          // rows 0-15 bmu, 16-31 blv
 #pragma unroll
@@ -492,41 +560,43 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 if (live) kl_lane += lv_r[r] - mu_r[r] * mu_r[r] - P::exp_(lv_r[r]);   // utils.py:75
             }
             // z block of the decoder input: features 0..15 valid, 16..31 zero
-            put_tile<P>(zv, Zb, LDZ, 0, (T*)g.zT, g.Bp, b0, l31, h);
+            put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+        } else {
+            stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h);
         }
         __syncthreads();
 
         DVAE_STAMP(6);
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, ZD / KS>(acc, w3z, W3r, Zbr, S4);
+        gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h); });
         WPre<P, HD / KS> w4;
         if (YP > 0) {
             WPre<P, YP / KS> w3y;
-            wprefetch<P, YP / KS>(w3y, W3r + KB3, S4);
-            gemm_block<P, YP / KS>(acc, w3y, W3r + KB3, Ur, S4);
+            wprefetch<P, YP / KS>(w3y, wrs, woff(W3r, KB3), S4);
+            gemm_block<P, YP / KS>(acc, w3y, wrs, woff(W3r, KB3), Ur, S4);
         }
-        wprefetch<P, HD / KS>(w4, W4r, S4);
+        wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
         float d1r[16];
         bias16(Bias + OB3, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(d1r, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(d1r, Ha, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(7);
         // ---------------- decoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w4, W4r, Har, S4);
+        gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
         WPre<P, HD / KS> w5;
-        wprefetch<P, HD / KS>(w5, W5s + wave * TSTEP, S17);
+        wprefetch<P, HD / KS>(w5, wrs, woff(W5s, wave_u * TSTEP), S17);
         float xr[16];
         if (!P::XFULL) xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
         float d2r[16];
         bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + bv[r]);
-        put_tile<P>(d2r, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(d2r, Hb, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(8);
@@ -535,10 +605,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // one 32-feature tile t of the output layer for this wave: GEMM, loss terms, da
         auto out_tile = [&](int t, const float* xsrc, int xld, int xcol0, int xcmax) {
             zero_acc<P>(acc);
-            const T* wr = W5s + t * TSTEP;
-            gemm_block<P, HD / KS>(acc, w5, wr, Hbr, S17);
-            if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wr + 4 * TSTEP, S17);
-            else wprefetch<P, NO / KS>(w5t, W5tr, S4);
+            const WRef wr = woff(W5s, (unsigned)t * TSTEP);
+            gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { if (t < 4) stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+            if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
+            else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
             float da[16], b5v[16];
             bias16(Bias + OB5, 32 * t, h, b5v);
 #pragma unroll
@@ -554,12 +624,12 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 rec_lane += ok ? term : 0.f;
                 da[r] = ok ? (1.f - xe) * g.invB : 0.f;          // d recon / d a
             }
-            put_tile<P>(da, U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT + (int64_t)(t) * 32 * g.Bp, g.Bp, b0, l31, h);
+            put_lds<P>(da, U, LDU, 32 * t, l31, h);
         };
         if (P::XFULL) {
             // the fp32 x tile is resident in LDS ([frame][513], odd stride: conflict-free): no barriers here
 #pragma unroll 1
-            for (int t = wave; t < NT_OUT; t += 4) out_tile(t, Xt, XD, 32 * t, XD - 1);
+            for (int t = wave_u; t < NT_OUT; t += 4) out_tile(t, Xt, XD, 32 * t, XD - 1);
             __syncthreads();
         } else {
 #pragma unroll 1
@@ -567,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 xt_commit(xr, Xt, LDX, b0, g.B, 128 * it, tl);
                 __syncthreads();
                 if (it + 1 < (NT_OUT + 3) / 4) xt_issue(g.x, g.ldx, b0, g.B, 128 * (it + 1), xr, tl);
-                const int t = 4 * it + wave;
+                const int t = 4 * it + wave_u;
                 if (t < NT_OUT) out_tile(t, Xt, LDX, 32 * wave, 127);
                 __syncthreads();
             }
@@ -576,33 +646,35 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(9);
         // ---------------- backward: d2 <- da ----------------
         zero_acc<P>(acc);
-        gemm_block<P, NO / KS>(acc, w5t, W5tr, Ur, S4);
+        gemm_block<P, NO / KS>(acc, w5t, wrs, W5tr, Ur, S4, [&]() {
+            for (int t = wave; t < NT_OUT; t += 4) stash_tile<P>(U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT + (int64_t)(t) * 32 * g.Bp, b0, l31, h);
+        });
         WPre<P, HD / KS> w4t;
-        wprefetch<P, HD / KS>(w4t, W4tr, S4);
+        wprefetch<P, HD / KS>(w4t, wrs, W4tr, S4);
         float dv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d2r[r] * d2r[r]);
-        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(dv, Ha, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(10);
         // ---------------- backward: d1 <- dpre_d2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w4t, W4tr, Har, S4);
+        gemm_block<P, HD / KS>(acc, w4t, wrs, W4tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
         WPre<P, HD / KS> w3zt;
         WPre<P, 32 / KS> wmvt;
-        if (wave == 0) wprefetch<P, HD / KS>(w3zt, W3ztr, S1);
-        wprefetch<P, 32 / KS>(wmvt, Wmvtr, S4);
+        if (wave == 0) wprefetch<P, HD / KS>(w3zt, wrs, W3ztr, S1);
+        wprefetch<P, 32 / KS>(wmvt, wrs, Wmvtr, S4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d1r[r] * d1r[r]);
-        put_tile<P>(dv, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(dv, Hb, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(11);
         // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w3zt, W3ztr, Hbr, S1);
+            gemm_block<P, HD / KS>(acc, w3zt, wrs, W3ztr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
             float dml[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -610,28 +682,31 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 dml[r] = live ? dz + mu_r[r] * g.invB : 0.f;                                                   // dmu
                 dml[r + 8] = live ? dz * ep_r[r] * (0.5f * sd_r[r]) - 0.5f * g.invB * (1.f - P::exp_(lv_r[r])) : 0.f;   // dlogvar
             }
-            put_tile<P>(dml, Zb, LDZ, 0, (T*)g.dmlvT, g.Bp, b0, l31, h);
+            put_lds<P>(dml, Zb, LDZ, 0, l31, h);
+        } else {
+            stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h);
         }
         __syncthreads();
 
         DVAE_STAMP(12);
         // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
         zero_acc<P>(acc);
-        gemm_block<P, 32 / KS>(acc, wmvt, Wmvtr, Zbr, S4);
+        gemm_block<P, 32 / KS>(acc, wmvt, wrs, Wmvtr, Zbr, S4, [&]() { if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, b0, l31, h); });
         WPre<P, HD / KS> w2t;
-        wprefetch<P, HD / KS>(w2t, W2tr, S4);
+        wprefetch<P, HD / KS>(w2t, wrs, W2tr, S4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);
-        put_tile<P>(dv, Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(dv, Ha, LDH, fb, l31, h);
         __syncthreads();
 
         DVAE_STAMP(13);
         // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2t, W2tr, Har, S4);
+        gemm_block<P, HD / KS>(acc, w2t, wrs, W2tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
-        put_tile<P>(dv, Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T + (int64_t)(wave) * 32 * g.Bp, g.Bp, b0, l31, h);
+        put_lds<P>(dv, Hb, LDH, fb, l31, h);
+        stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h);
 
         DVAE_STAMP(14);
         // ---------------- per-tile loss sums ----------------
@@ -674,7 +749,7 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
                                            int l31, int h) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
-    constexpr int E = P::E, KS = P::KSTEP, CH = 2;
+    constexpr int E = P::E, KS = P::KSTEP;
     const int lane = h * 32 + l31;
     constexpr int FB = 64 * E;                              // elements per (feature tile, k-step) block
     const T* a0p = (const T*)d.A[0] + lane * E;
@@ -687,43 +762,38 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
     for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; cb0[i] = 0.f; cb1[i] = 0.f; }
     const Frag one = P::ones();
     const int64_t sbeg = kbeg / KS, send = kend / KS;       // k-steps of this frame slice
-    Frag a0[CH], a1[CH], b0[CH], b1[CH];
-    if (sbeg < send) {
+    // The stash was written once by the previous kernel: these are cold HBM/MALL reads (~2 us round trip).
+    // A ring of RD k-steps per operand keeps 4 * RD 1-KB loads in flight per wave; the slot an MFMA group has
+    // consumed is re-requested RD steps ahead (clamped on the last lap: a harmless reload, no branch).
+    constexpr int RD = P::WRING;
+    Frag a0[RD], a1[RD], b0[RD], b1[RD];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            a0[i] = *reinterpret_cast<const Frag*>(a0p + (sbeg + i) * FB);
-            b0[i] = *reinterpret_cast<const Frag*>(b0p + (sbeg + i) * FB);
-            if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + (sbeg + i) * FB);
-            if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + (sbeg + i) * FB);
-        }
+    for (int i = 0; i < RD; ++i) {
+        int64_t sk = sbeg + i; sk = sk < send ? sk : send - 1;
+        a0[i] = *reinterpret_cast<const Frag*>(a0p + sk * FB);
+        b0[i] = *reinterpret_cast<const Frag*>(b0p + sk * FB);
+        if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + sk * FB);
+        if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + sk * FB);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int64_t sk = sbeg; sk < send; sk += CH) {
-        int64_t sn = sk + CH;
-        if (sn >= send) sn = sk;                // last pass: harmless reload instead of a branch around the loads
-        Frag a0n[CH], a1n[CH], b0n[CH], b1n[CH];
+    for (int64_t sk = sbeg; sk < send; sk += RD) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            a0n[i] = *reinterpret_cast<const Frag*>(a0p + (sn + i) * FB);
-            b0n[i] = *reinterpret_cast<const Frag*>(b0p + (sn + i) * FB);
-            if (A1) a1n[i] = *reinterpret_cast<const Frag*>(a1p + (sn + i) * FB);
-            if (B1) b1n[i] = *reinterpret_cast<const Frag*>(b1p + (sn + i) * FB);
-        }
-        __builtin_amdgcn_sched_barrier(0);      // keep the next chunk's loads above this chunk's MFMAs
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            P::mma(c00, a0[i], b0[i]);
-            if (B1) P::mma(c01, a0[i], b1[i]);
-            if (A1) P::mma(c10, a1[i], b0[i]);
-            if (A1 && B1) P::mma(c11, a1[i], b1[i]);
-            if (bias0) P::mma(cb0, a0[i], one);
-            if (A1) { if (bias1) P::mma(cb1, a1[i], one); }
-        }
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            a0[i] = a0n[i]; b0[i] = b0n[i];
-            if (A1) a1[i] = a1n[i];
-            if (B1) b1[i] = b1n[i];
+        for (int i = 0; i < RD; ++i) {
+            if (sk + i < send) {                            // wave-uniform: slices are multiples of RD steps except the tail
+                P::mma(c00, a0[i], b0[i]);
+                if (B1) P::mma(c01, a0[i], b1[i]);
+                if (A1) P::mma(c10, a1[i], b0[i]);
+                if (A1 && B1) P::mma(c11, a1[i], b1[i]);
+                if (bias0) P::mma(cb0, a0[i], one);
+                if (A1) { if (bias1) P::mma(cb1, a1[i], one); }
+            }
+            int64_t sn = sk + RD + i; sn = sn < send ? sn : send - 1;
+            a0[i] = *reinterpret_cast<const Frag*>(a0p + sn * FB);
+            b0[i] = *reinterpret_cast<const Frag*>(b0p + sn * FB);
+            if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + sn * FB);
+            if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + sn * FB);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -1157,6 +1227,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.bmu = params + plan->tensor_offset[5]; a.blv = params + plan->tensor_offset[7];
     a.b3 = params + plan->tensor_offset[9]; a.b4 = params + plan->tensor_offset[11]; a.b5 = params + plan->tensor_offset[13];
     a.partials = (double*)(w + L.o_partials);
+    a.wcopy = wc; a.wcopy_bytes = L.wcopy_elems * esz;
     a.dbg = g_dbg;
     { const char* ab = getenv("DVAE_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     char* st = w + L.o_stash;
