@@ -86,10 +86,13 @@ struct PolBF16 {
         return Frag{o, o, o, o, o, o, o, o};
     }
     // throughput mode: hardware exp2/log2/rcp based transcendentals
-    static __device__ __forceinline__ float exp_(float v) { return __expf(v); }
-    static __device__ __forceinline__ float log_(float v) { return __logf(v); }
+    // raw v_exp_f32 / v_log_f32 (base 2): arguments here are never denormal (x + eps >= 1e-8), so the
+    // denormal-scaling sequence __expf / __logf wrap around them (~10 VALU each) is dropped; at one wave
+    // per SIMD every VALU instruction costs 4 issue cycles and the loss epilogue is VALU-bound
+    static __device__ __forceinline__ float exp_(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+    static __device__ __forceinline__ float log_(float v) { return __builtin_amdgcn_logf(v) * 0.693147180559945309f; }
     static __device__ __forceinline__ float tanh_(float v) {
-        const float e = __expf(2.f * v);
+        const float e = __builtin_amdgcn_exp2f(v * 2.88539008177792681f);
         return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
     }
 };
@@ -609,20 +612,32 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { if (t < 4) stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
             if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
             else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
-            float da[16], b5v[16];
-            bias16(Bias + OB5, 32 * t, h, b5v);
+            float da[16], b5v[16], xs[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int fl = feat_of(r, h);
-                const int f = 32 * t + fl;
-                const bool ok = live && f < XD;
-                const float a = acc[r] + b5v[r];
-                int xc = xcol0 + fl; xc = xc < xcmax ? xc : xcmax;    // clamped, unconditional LDS read
-                const float xv = xsrc[l31 * xld + xc];
-                const float xe = xv * P::exp_(-a);               // x / r,  r = exp(a)  (models.py:122)
-                const float term = xe - P::log_(xv + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
-                rec_lane += ok ? term : 0.f;
-                da[r] = ok ? (1.f - xe) * g.invB : 0.f;          // d recon / d a
+            for (int r = 0; r < 16; ++r) {                       // all x reads up front: one LDS wait, not sixteen
+                int xc = xcol0 + feat_of(r, h); xc = xc < xcmax ? xc : xcmax;
+                xs[r] = xsrc[l31 * xld + xc];
+            }
+            bias16(Bias + OB5, 32 * t, h, b5v);
+            const float invB_l = live ? g.invB : 0.f;            // frames past B contribute nothing
+            if (t < NT_OUT - 1) {                                // all 32 features of the tile exist
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = acc[r] + b5v[r];
+                    const float xe = xs[r] * P::exp_(-a);        // x / r,  r = exp(a)  (models.py:122)
+                    rec_lane += xe - P::log_(xs[r] + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
+                    da[r] = (1.f - xe) * invB_l;                 // d recon / d a
+                }
+            } else {                                             // last tile: features >= 513 are padding
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = 32 * t + feat_of(r, h) < XD;
+                    const float a = acc[r] + b5v[r];
+                    const float xe = xs[r] * P::exp_(-a);
+                    const float term = xe - P::log_(xs[r] + g.elbo_eps) + a - 1.f;
+                    rec_lane += ok ? term : 0.f;
+                    da[r] = ok ? (1.f - xe) * invB_l : 0.f;
+                }
             }
             put_lds<P>(da, U, LDU, 32 * t, l31, h);
         };
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
 
         DVAE_STAMP(14);
         // ---------------- per-tile loss sums ----------------
+        if (!live) rec_lane = 0.f;
         const float rs = wave_sum(rec_lane), ks = wave_sum(kl_lane);
         if (lane == 0) { red[wave] = rs; red[4 + wave] = ks; }
         __syncthreads();
