@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool-gb", type=float, default=1.0)
+    ap.add_argument("--ksplit", type=int, default=0, help="frame-axis slices of the weight-gradient kernel (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -197,7 +198,7 @@ def main():
                 raise
         impl_name = "fused" if trainer_mod is not None else "modules"
     if impl_name == "fused":
-        impl = trainer_mod.BenchImpl(a.model, dims, B, device, world, a.precision)
+        impl = trainer_mod.BenchImpl(a.model, dims, B, device, world, a.precision, ksplit=a.ksplit)
     else:
         impl = ModulesImpl(a.model, dims, device, world)
 

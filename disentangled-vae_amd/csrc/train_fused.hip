@@ -53,6 +53,7 @@ struct PolF32 {
     static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
     static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
     static constexpr int WRING = 4;    // wgrad: k-steps of operand fragments in flight per wave
+    static constexpr bool EARLY_Y = false;
     static constexpr bool XFULL = false;   // fp32 x tile does not fit LDS next to fp32 activations: streamed in 128-column slices
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
@@ -76,6 +77,7 @@ struct PolBF16 {
     static constexpr int PD = 16;
     static constexpr int PRE = 6;
     static constexpr int WRING = 8;
+    static constexpr bool EARLY_Y = true;   // request the y tile before the x GEMM (68 VGPRs held across it)
     static constexpr bool XFULL = true;    // whole fp32 x tile stays in LDS for the loss epilogue
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
@@ -484,12 +486,19 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         WPre<P, XP / KS> w1x;
         wprefetch<P, XP / KS>(w1x, wrs, W1r, S4);
         const bool yfast = Y513 && g.fasty && full;
+        f32x4 yv[NQ513];
         if (g.fastx && full) {
             f32x4 xv[NQ513];
             tile513_issue(g.x + b0 * XD, xv, tl);
+            if constexpr (Y513 && P::EARLY_Y) {
+                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);      // y tile in flight under the x GEMM
+            }
             tile513_commit<P, XP>(xv, U, LDU, tl, P::XFULL ? Xt : nullptr);
         } else {
             load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, P::XFULL ? Xt : nullptr);
+            if constexpr (Y513 && P::EARLY_Y) {
+                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);
+            }
         }
         __syncthreads();
         DVAE_STAMP(1);
@@ -506,8 +515,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (YP > 0) {
             __syncthreads();
             if (Y513 && yfast) {
-                f32x4 yv[NQ513];
-                tile513_issue(g.y + b0 * XD, yv, tl);
+                if constexpr (!P::EARLY_Y) tile513_issue(g.y + b0 * XD, yv, tl);
                 tile513_commit<P, XP>(yv, U, LDU, tl);
             } else {
                 load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl);

@@ -195,12 +195,13 @@ class Trainer:
 class BenchImpl:
     """bench.py adapter: the fused path."""
 
-    def __init__(self, model, dims, B, device, world, precision):
+    def __init__(self, model, dims, B, device, world, precision, ksplit=0):
         pg = None
         if world > 1:
             import torch.distributed as dist
             pg = dist.group.WORLD
-        self.tr = Trainer(model, dims, None, batch=B, device=device, precision=precision, process_group=pg, world=world, seed=0)
+        self.tr = Trainer(model, dims, None, batch=B, device=device, precision=precision, process_group=pg, world=world, seed=0,
+                          ksplit=ksplit)
         self.dtype = "bf16" if precision == "bf16" else "f32"
         self.name = f"fused(rows+wgrad+apply HIP kernels, {precision} MFMA operands, fp32 accumulate/master)"
         self.model, self.dims, self.B, self.precision = model, dims, B, precision
