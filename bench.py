@@ -197,6 +197,10 @@ def main():
             if impl_name == "fused":
                 raise
         impl_name = "fused" if trainer_mod is not None else "modules"
+        if trainer_mod is not None and not trainer_mod.supported(a.model, dims):
+            if a.impl == "fused":
+                raise SystemExit(f"fused train step does not cover {a.model} {dims}")
+            impl_name = "modules"        # e.g. M2_info: layer-level HIP kernels + autograd + torch.optim.Adam
     if impl_name == "fused":
         impl = trainer_mod.BenchImpl(a.model, dims, B, device, world, a.precision, ksplit=a.ksplit)
     else:

@@ -107,10 +107,11 @@ template <typename T> struct Ld {
     static constexpr int z = 32 + per16;          // [frame][32]              (z | pad, dmu | dlv)
     static constexpr int xt = 129;                // fp32 [frame][128] slice of x for the loss epilogue
     static constexpr int nbias = 4 * HD + 32 + NO;   // b1 b2 [bmu|blv] b3 b4 b5(padded): fp32 copies for the epilogues
+    static constexpr int ninfo = 6 * HD + 8;         // M2_info: bc1 bc2 wc3 ba1 ba2 wa3, bc3, ba3
     static constexpr int xf_floats = (TB * XD + 63) / 64 * 64;
     static constexpr int xt_floats = (TB * xt + 63) / 64 * 64;
-    static constexpr size_t bytes_slices = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xt_floats + nbias) * sizeof(float) + 64;
-    static constexpr size_t bytes_full = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xf_floats + nbias) * sizeof(float) + 64;
+    static constexpr size_t bytes_slices = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xt_floats + nbias + ninfo) * sizeof(float) + 64;
+    static constexpr size_t bytes_full = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xf_floats + nbias + ninfo) * sizeof(float) + 64;
 };
 
 __device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -223,7 +224,12 @@ struct RowsArgs {
     const void *W1s, *W2s, *Wmvs, *W3s, *W4s, *W5s, *W5t, *W4t, *W3zt, *Wmvt, *W2t;
     const float *b1, *b2, *bmu, *blv, *b3, *b4, *b5;
     void *xT, *yT, *h1T, *h2T, *dh1T, *dh2T, *dmlvT, *zT, *d1T, *d2T, *dd1T, *dd2T, *daT;
-    const void* wcopy; int64_t wcopy_bytes;   // whole weight-copy buffer (L2 warm-up)
+    const void* wcopy; int64_t wcopy_bytes;   // whole weight-copy buffer (one buffer descriptor)
+    // M2_info (DeepGenerativeModel_v5): classifier on x, auxiliary classifier on z (both 128-128-1, relu/relu/sigmoid)
+    const void *Wc1s, *Wc2s, *Wc2t, *Wa1s, *Wa1t, *Wa2s, *Wa2t;
+    const float *bc1, *bc2, *wc3, *bc3, *ba1, *ba2, *wa3, *ba3;
+    void *c1T, *c2T, *dc1T, *dc2T, *dc3T, *a1T, *a2T, *da1T, *da2T, *da3T;
+    float alpha, beta, gamma;
     double* partials;
     unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
@@ -269,7 +275,7 @@ __device__ __forceinline__ void put_lds(const float (&v)[16], typename P::T* lds
 // one feature = one 16-byte fragment).  Called by the wave that wrote those LDS columns.
 template <typename P>
 __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr,
-                                           int64_t b0, int l31, int h) {
+                                           int64_t b0, int l31, int h, float scale = 1.f) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
@@ -280,7 +286,10 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
         const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
         Frag f;
 #pragma unroll
-        for (int j = 0; j < E; ++j) f[j] = lds[(gq * E + j) * ldl + fbase + l31];
+        for (int j = 0; j < E; ++j) {
+            const T v = lds[(gq * E + j) * ldl + fbase + l31];
+            f[j] = scale == 1.f ? v : P::cvt((float)v * scale);
+        }
         *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
     }
 }
@@ -374,7 +383,94 @@ __device__ __forceinline__ void xt_commit(const float (&xr)[16], float* Xt, int 
     }
 }
 
-template <typename P, int YP, bool YENC>
+// "Classifier" (packages/models/models.py:41-63): 128-128-1 relu / relu / sigmoid MLP on the current tile, its
+// binary_cross_entropy against the frame label (utils.py:55-56) and the unit-scale backward, all on chip.
+// Used twice by M2_info (scripts/training_M2_info_vad.py:159-183): classifier on x, auxiliary net on z.
+// Each wave owns 32 hidden features; the 1-wide output layer is a VALU dot product reduced through LDS.
+struct SideArgs {
+    WRef W1, W2, W2t, W1t;          // W1t only when the gradient wrt the input is needed
+    unsigned s1, s1t;               // k-step strides of W1 / W1t
+    const float *b1, *b2, *w3;      // LDS tables
+    float b3;
+    float y, invB, eps;
+    bool live, need_dx;
+    float scale;                    // factor applied to the stashed pre-activation gradients (loss weight)
+    void *h1T, *h2T, *d1T, *d2T, *d3T;
+    int64_t Bp, b0;
+};
+
+template <typename P, int K1STEPS>
+__device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideArgs& a, const typename P::T* in_row,
+                                         typename P::T* Ha, typename P::T* Hb, float* redbuf, int wave, int l31, int h,
+                                         unsigned S4, float& bce_frame, float& p_out, f32x16& dx) {
+    typedef typename P::T T;
+    constexpr int E = P::E, KS = P::KSTEP, LDH = Ld<T>::hh;
+    const int fb = 32 * wave;
+    const T* const Har = Ha + l31 * LDH + h * E;
+    const T* const Hbr = Hb + l31 * LDH + h * E;
+    f32x16 acc;
+    float bv[16], w3v[16], c1r[16], c2r[16], dv[16];
+    // layer 1
+    WPre<P, K1STEPS> w1;
+    wprefetch<P, K1STEPS>(w1, wrs, a.W1, a.s1);
+    zero_acc<P>(acc);
+    gemm_block<P, K1STEPS>(acc, w1, wrs, a.W1, in_row, a.s1);
+    WPre<P, HD / KS> w2;
+    wprefetch<P, HD / KS>(w2, wrs, a.W2, S4);
+    bias16(a.b1, fb, h, bv);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c1r[r] = fmaxf(acc[r] + bv[r], 0.f);
+    put_lds<P>(c1r, Ha, LDH, fb, l31, h);
+    __syncthreads();
+    // layer 2 + output dot product
+    zero_acc<P>(acc);
+    gemm_block<P, HD / KS>(acc, w2, wrs, a.W2, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.h1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h); });
+    WPre<P, HD / KS> w2t;
+    wprefetch<P, HD / KS>(w2t, wrs, a.W2t, S4);
+    bias16(a.b2, fb, h, bv);
+    bias16(a.w3, fb, h, w3v);
+    float pd = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c2r[r] = fmaxf(acc[r] + bv[r], 0.f); pd = fmaf(w3v[r], c2r[r], pd); }
+    put_lds<P>(c2r, Hb, LDH, fb, l31, h);
+    pd += __shfl_xor(pd, 32, 64);
+    if (h == 0) redbuf[wave * 32 + l31] = pd;
+    __syncthreads();
+    const float logit = redbuf[l31] + redbuf[32 + l31] + redbuf[64 + l31] + redbuf[96 + l31] + a.b3;
+    const float p = 1.f / (1.f + P::exp_(-logit));
+    p_out = p;
+    const float lp = P::log_(p + a.eps), lq = P::log_(1.f - p + a.eps);
+    bce_frame = a.live ? -(a.y * lp + (1.f - a.y) * lq) : 0.f;                              // utils.py:55-56, this frame's term
+    const float u = a.live ? -a.invB * (a.y / (p + a.eps) - (1.f - a.y) / (1.f - p + a.eps)) : 0.f;   // d BCE / d p
+    const float dpre3 = u * p * (1.f - p);
+    stash_tile<P>(Hb, LDH, fb, (T*)a.h2T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h);
+    if (wave == 0 && h == 0) {       // output pre-activation gradient: feature row 0 of a 32-row stash tile
+        T* d3 = (T*)a.d3T + (a.b0 / KS) * (64 * E) + (l31 / E) * 32 * E + (l31 % E);
+        *d3 = P::cvt(dpre3 * a.scale);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = c2r[r] > 0.f ? w3v[r] * dpre3 : 0.f;            // dpre2 (unit scale)
+    put_lds<P>(dv, Ha, LDH, fb, l31, h);
+    __syncthreads();
+    // backward through layer 2
+    zero_acc<P>(acc);
+    gemm_block<P, HD / KS>(acc, w2t, wrs, a.W2t, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.d2T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h, a.scale); });
+    WPre<P, HD / KS> w1t;
+    if (a.need_dx && wave == 0) wprefetch<P, HD / KS>(w1t, wrs, a.W1t, a.s1t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = c1r[r] > 0.f ? acc[r] : 0.f;                      // dpre1 (unit scale)
+    put_lds<P>(dv, Hb, LDH, fb, l31, h);
+    __syncthreads();
+    zero_acc<P>(dx);
+    if (a.need_dx && wave == 0) {
+        gemm_block<P, HD / KS>(dx, w1t, wrs, a.W1t, Hbr, a.s1t, [&]() { stash_tile<P>(Hb, LDH, fb, (T*)a.d1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h, a.scale); });
+    } else {
+        stash_tile<P>(Hb, LDH, fb, (T*)a.d1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h, a.scale);
+    }
+    __syncthreads();
+}
+
+template <typename P, int YP, bool YENC, bool INFO>
 __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     typedef typename P::T T;
     constexpr int E = P::E;
@@ -391,7 +487,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     float* Xt = reinterpret_cast<float*>(Zb + TB * LDZ);     // XFULL: dense [32][513] fp32 x tile; else [32][129] slice
     float* Bias = Xt + (P::XFULL ? Ld<T>::xf_floats : Ld<T>::xt_floats);
     constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
-    __shared__ float red[8];
+    // M2_info tables behind the VAE biases: bc1 bc2 wc3 ba1 ba2 wa3 (128 each), then bc3, ba3
+    constexpr int OI = Ld<T>::nbias, OBC1 = OI, OBC2 = OI + HD, OWC3 = OI + 2 * HD, OBA1 = OI + 3 * HD, OBA2 = OI + 4 * HD, OWA3 = OI + 5 * HD, OS3 = OI + 6 * HD;
+    __shared__ float red[16];
+    __shared__ float red2[128];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -431,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     const T* const Hbr = Hb + l31 * LDH + h * E;
     const T* const Zbr = Zb + l31 * LDZ + h * E;
 
-    double tot_rec = 0.0, tot_kl = 0.0;
+    double tot_rec = 0.0, tot_kl = 0.0, tot_bc = 0.0, tot_ba = 0.0;
 
     // fp32 bias table -> LDS once (epilogues must not queue global loads behind the weight prefetch).
     // All loads are issued before the first store (clamped addresses instead of branches).
@@ -459,13 +558,26 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             if (i < Ld<T>::nbias) Bias[i] = (i >= OB5 + XD) ? 0.f : bvv[it];
         }
     }
+    if (INFO) {
+        for (int i = tid; i < 6 * HD + 2; i += 256) {
+            float v;
+            const int q = i / HD, k = i - q * HD;
+            if (q == 0) v = g.bc1[k]; else if (q == 1) v = g.bc2[k]; else if (q == 2) v = g.wc3[k];
+            else if (q == 3) v = g.ba1[k]; else if (q == 4) v = g.ba2[k]; else if (q == 5) v = g.wa3[k];
+            else v = k == 0 ? g.bc3[0] : g.ba3[0];
+            Bias[OI + i] = v;
+        }
+    }
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t b0 = (int64_t)tile * TB;
         const bool live = (b0 + l31) < g.B;             // this lane's frame exists
         const bool full = (b0 + TB) <= g.B;
-        float rec_lane = 0.f, kl_lane = 0.f;
+        float rec_lane = 0.f, kl_lane = 0.f, bce_c = 0.f, bce_a = 0.f;
+        float y_l = 0.f;
+        if (INFO) { int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1; y_l = g.y[br * g.ldy]; }
+        f32x16 dzu;                                      // M2_info: d BCE_aux / d z (unit scale), wave 0
         // per-iteration opaque copy of the thread id: stops the compiler from hoisting the ~70 per-thread
         // staging addresses out of the tile loop (they would live across the whole loop and spill)
         int tl = tid;
@@ -508,6 +620,17 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
         });
         DVAE_STAMP(2);
+        if (INFO) {
+            const f32x16 acc_keep = acc;
+            SideArgs sa;
+            sa.W1 = wbase(g.Wc1s, wave_u, XP); sa.W2 = wbase(g.Wc2s, wave_u, HD); sa.W2t = wbase(g.Wc2t, wave_u, HD); sa.W1t = sa.W2t;
+            sa.s1 = S4; sa.s1t = S4; sa.b1 = Bias + OBC1; sa.b2 = Bias + OBC2; sa.w3 = Bias + OWC3; sa.b3 = Bias[OS3];
+            sa.y = y_l; sa.invB = g.invB; sa.eps = g.elbo_eps; sa.live = live; sa.need_dx = false; sa.scale = g.alpha;
+            sa.h1T = g.c1T; sa.h2T = g.c2T; sa.d1T = g.dc1T; sa.d2T = g.dc2T; sa.d3T = g.dc3T; sa.Bp = g.Bp; sa.b0 = b0;
+            float pc; f32x16 dxc;
+            side_mlp<P, XP / KS>(wrs, sa, Ur, Ha, Hb, red2, wave, l31, h, S4, bce_c, pc, dxc);
+            acc = acc_keep;
+        }
         WPre<P, HD / KS> w2;
         WPre<P, (YENC ? YP : 0) / KS> w1y;
         if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, wrs, woff(W1r, KB1), S4);
@@ -578,9 +701,19 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         __syncthreads();
 
         DVAE_STAMP(6);
+        if (INFO) {
+            SideArgs sa;
+            sa.W1 = wbase(g.Wa1s, wave_u, ZD); sa.W2 = wbase(g.Wa2s, wave_u, HD); sa.W2t = wbase(g.Wa2t, wave_u, HD); sa.W1t = wbase(g.Wa1t, 0, HD);
+            sa.s1 = S4; sa.s1t = S1; sa.b1 = Bias + OBA1; sa.b2 = Bias + OBA2; sa.w3 = Bias + OWA3; sa.b3 = Bias[OS3 + 1];
+            sa.y = y_l; sa.invB = g.invB; sa.eps = g.elbo_eps; sa.live = live; sa.need_dx = true; sa.scale = g.gamma - g.beta;
+            sa.h1T = g.a1T; sa.h2T = g.a2T; sa.d1T = g.da1T; sa.d2T = g.da2T; sa.d3T = g.da3T; sa.Bp = g.Bp; sa.b0 = b0;
+            float pa;
+            if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h);
+            side_mlp<P, ZD / KS>(wrs, sa, Zbr, Ha, Hb, red2, wave, l31, h, S4, bce_a, pa, dzu);
+        }
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h); });
+        gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (!INFO && wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h); });
         WPre<P, HD / KS> w4;
         if (YP > 0) {
             WPre<P, YP / KS> w3y;
@@ -701,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             float dml[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float dz = acc[r];
+                const float dz = INFO ? acc[r] - g.beta * dzu[r] : acc[r];     // enc_loss = ELBO + alpha*clf - beta*BCE(aux(z), y)
                 dml[r] = live ? dz + mu_r[r] * g.invB : 0.f;                                                   // dmu
                 dml[r + 8] = live ? dz * ep_r[r] * (0.5f * sd_r[r]) - 0.5f * g.invB * (1.f - P::exp_(lv_r[r])) : 0.f;   // dlogvar
             }
@@ -736,17 +869,24 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (!live) rec_lane = 0.f;
         const float rs = wave_sum(rec_lane), ks = wave_sum(kl_lane);
         if (lane == 0) { red[wave] = rs; red[4 + wave] = ks; }
+        if (INFO && wave == 0) {
+            const float bcs = wave_sum(h == 0 ? bce_c : 0.f), bas = wave_sum(h == 0 ? bce_a : 0.f);
+            if (lane == 0) { red[8] = bcs; red[9] = bas; }
+        }
         __syncthreads();
         if (tid == 0) {
             tot_rec += (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
             tot_kl += -0.5 * (double)red[4];
+            if (INFO) { tot_bc += (double)red[8]; tot_ba += (double)red[9]; }
         }
         __syncthreads();
     }
     DVAE_STAMP(15);
     if (tid == 0) {
-        g.partials[2 * blockIdx.x] = tot_rec;
-        g.partials[2 * blockIdx.x + 1] = tot_kl;
+        g.partials[4 * blockIdx.x] = tot_rec;
+        g.partials[4 * blockIdx.x + 1] = tot_kl;
+        g.partials[4 * blockIdx.x + 2] = tot_bc;
+        g.partials[4 * blockIdx.x + 3] = tot_ba;
     }
 }
 
@@ -893,6 +1033,7 @@ struct ApplyArgs {
     void* wcopy;
     float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
     const double* partials; int npartials; int64_t B; float* losses3;
+    int info; float alpha, beta, gamma;
 };
 
 // One thread per parameter over the flat buffer (every load independent); chunk_tensor maps each
@@ -902,17 +1043,29 @@ template <typename T, bool ADAM>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     if (blockIdx.x == gridDim.x - 1) {                    // loss finalisation block
         if (!ADAM || g.losses3 == nullptr) return;
-        __shared__ double red[4][2];
+        __shared__ double red[4][4];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double a = 0.0, k = 0.0;
-        for (int i = threadIdx.x; i < g.npartials; i += 256) { a += g.partials[2 * i]; k += g.partials[2 * i + 1]; }
-        a = wave_sum(a); k = wave_sum(k);
-        if (lane == 0) { red[wave][0] = a; red[wave][1] = k; }
+        double a = 0.0, k = 0.0, c = 0.0, x = 0.0;
+        for (int i = threadIdx.x; i < g.npartials; i += 256) {
+            a += g.partials[4 * i]; k += g.partials[4 * i + 1]; c += g.partials[4 * i + 2]; x += g.partials[4 * i + 3];
+        }
+        a = wave_sum(a); k = wave_sum(k); c = wave_sum(c); x = wave_sum(x);
+        if (lane == 0) { red[wave][0] = a; red[wave][1] = k; red[wave][2] = c; red[wave][3] = x; }
         __syncthreads();
         if (threadIdx.x == 0) {
             const float recon = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)g.B);
             const float kl = (float)((red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (double)g.B);
             g.losses3[0] = recon + kl; g.losses3[1] = recon; g.losses3[2] = kl;
+            if (g.info) {   // scripts/training_M2_info_vad.py:162-183
+                const float bc = (float)((red[0][2] + red[1][2] + red[2][2] + red[3][2]) / (double)g.B);
+                const float ba = (float)((red[0][3] + red[1][3] + red[2][3] + red[3][3]) / (double)g.B);
+                const float classif = g.alpha * bc, aux_enc = g.beta * ba;
+                g.losses3[3] = (recon + kl) + classif - aux_enc;      // enc_loss
+                g.losses3[4] = classif;
+                g.losses3[5] = g.gamma * ba;                          // aux_loss
+                g.losses3[6] = aux_enc;
+                g.losses3[7] = 0.f;
+            }
         }
         return;
     }
@@ -954,6 +1107,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
 struct Layout {
     // weight-copy buffer (elements of T)
     int64_t W1s, W2s, Wmvs, W3s, W4s, W5s, W5t, W4t, W3zt, Wmvt, W2t, wcopy_elems;
+    int64_t Wc1s, Wc2s, Wc2t, Wa1s, Wa1t, Wa2s, Wa2t;                  // M2_info
+    int64_t c1T, c2T, dc1T, dc2T, dc3T, a1T, a2T, da1T, da2T, da3T;     // M2_info stash
+    bool info;
     int ld1, ld3, yp, ye, yd;
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
@@ -968,6 +1124,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     const int esz = p.precision == DVAE_PREC_BF16 ? 2 : 4;
     L.yp = p.y_dim == 0 ? 0 : (p.y_dim + 15) / 16 * 16;
     L.ye = p.model == DVAE_MODEL_M2 ? L.yp : 0;
+    L.info = p.model == DVAE_MODEL_M2_INFO;
     L.yd = L.yp;
     L.ld1 = XP + L.ye;
     L.ld3 = ZD + L.yd;
@@ -976,23 +1133,32 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.W1s = take((int64_t)HD * L.ld1); L.W2s = take(HD * HD); L.Wmvs = take(32 * HD); L.W3s = take((int64_t)HD * L.ld3);
     L.W4s = take(HD * HD); L.W5s = take((int64_t)NO * HD); L.W5t = take((int64_t)HD * NO); L.W4t = take(HD * HD);
     L.W3zt = take(32 * HD); L.Wmvt = take(HD * 32); L.W2t = take(HD * HD);
+    if (L.info) {
+        L.Wc1s = take((int64_t)HD * XP); L.Wc2s = take(HD * HD); L.Wc2t = take(HD * HD);
+        L.Wa1s = take(HD * ZD); L.Wa1t = take(32 * HD); L.Wa2s = take(HD * HD); L.Wa2t = take(HD * HD);
+    }
     L.wcopy_elems = o;
     int64_t r = 0;
     auto rows = [&](int64_t n) { int64_t q = r; r += n; return q; };
     L.xT = rows(NO); L.yT = rows(L.yp ? al(L.yp, 32) : 0); L.h1T = rows(HD); L.h2T = rows(HD); L.dh1T = rows(HD); L.dh2T = rows(HD);
     L.dmlvT = rows(32); L.zT = rows(32); L.d1T = rows(HD); L.d2T = rows(HD); L.dd1T = rows(HD); L.dd2T = rows(HD); L.daT = rows(NO);
-    rows(32);   // slack: the second head job reads 16 rows past dmlvT's 32 (masked on store)
+    if (L.info) {
+        L.c1T = rows(HD); L.c2T = rows(HD); L.dc1T = rows(HD); L.dc2T = rows(HD); L.dc3T = rows(32);
+        L.a1T = rows(HD); L.a2T = rows(HD); L.da1T = rows(HD); L.da2T = rows(HD); L.da3T = rows(32);
+    }
+    rows(32);   // slack
     L.stash_rows = r;
     // 2x2 groups of 32x32 tiles per job: (pairs of A blocks) x (pairs of B blocks)
     const int nty = L.yp ? (int)(al(L.yp, 32) / 32) : 0;
     auto pr = [](int n) { return (n + 1) / 2; };
     L.ntiles = 2 * pr(NT_OUT + (L.ye ? nty : 0)) + 2 * 2 + 1 * 2 + 2 * pr(1 + (L.yd ? nty : 0)) + 2 * 2 + pr(NT_OUT) * 2;
+    if (L.info) L.ntiles += 2 * pr(NT_OUT) + 2 * 2 + 1 * 2 + 2 * 1 + 2 * 2 + 1 * 2;   // clf L1, L2, out; aux L1, L2, out
     int64_t b = 0;
     auto bytes = [&](int64_t n) { int64_t q = b; b += al(n, 256); return q; };
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
-    L.o_partials = bytes(p.rows_grid * 2 * sizeof(double));
+    L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
     L.o_wcopy = bytes(L.wcopy_elems * esz);
     L.o_stash = bytes(L.stash_rows * p.Bp * esz);
     L.o_grads = bytes((int64_t)p.ksplit * p.n_params * sizeof(float));
@@ -1026,8 +1192,9 @@ using namespace dvae::fused;
 
 extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_hint, dvae_train_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr && B > 0, "train_plan: bad argument");
-    if (!((model == DVAE_MODEL_M1 && y_dim == 0) || (model == DVAE_MODEL_M2 && (y_dim == 1 || y_dim == 513)))) {
-        set_error("train_plan: fused kernels cover M1 (y 0) and M2 (y 1 or 513) at x 513 / h [128,128] / z 16; got model %d y_dim %d", model, y_dim);
+    if (!((model == DVAE_MODEL_M1 && y_dim == 0) || (model == DVAE_MODEL_M2 && (y_dim == 1 || y_dim == 513)) ||
+          (model == DVAE_MODEL_M2_INFO && y_dim == 1))) {
+        set_error("train_plan: fused kernels cover M1 (y 0), M2 (y 1 or 513) and M2_info (y 1) at x 513 / h [128,128] / z 16; got model %d y_dim %d", model, y_dim);
         return DVAE_E_UNSUPPORTED;
     }
     DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16, "train_plan: unknown precision %d", precision);
@@ -1035,11 +1202,13 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     plan->model = model; plan->y_dim = y_dim; plan->precision = precision; plan->B = B;
     plan->Bp = al(B, 128);
     const int ye = model == DVAE_MODEL_M2 ? y_dim : 0, yd = y_dim;
-    const int rows[14] = {HD, HD, HD, HD, ZD, ZD, ZD, ZD, HD, HD, HD, HD, XD, XD};
-    const int cols[14] = {XD + ye, 1, HD, 1, HD, 1, HD, 1, ZD + yd, 1, HD, 1, HD, 1};
+    const int rows[26] = {HD, HD, HD, HD, ZD, ZD, ZD, ZD, HD, HD, HD, HD, XD, XD,
+                          HD, HD, HD, HD, 1, 1, HD, HD, HD, HD, 1, 1};
+    const int cols[26] = {XD + ye, 1, HD, 1, HD, 1, HD, 1, ZD + yd, 1, HD, 1, HD, 1,
+                          XD, 1, HD, 1, HD, 1, ZD, 1, HD, 1, HD, 1};
     int64_t off = 0;
-    plan->n_tensors = 14;
-    for (int i = 0; i < 14; ++i) {
+    plan->n_tensors = model == DVAE_MODEL_M2_INFO ? 26 : 14;
+    for (int i = 0; i < plan->n_tensors; ++i) {
         plan->tensor_offset[i] = off; plan->tensor_rows[i] = rows[i]; plan->tensor_cols[i] = cols[i];
         off += al((int64_t)rows[i] * cols[i], 64);
     }
@@ -1057,7 +1226,13 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     plan->grad_offset_bytes = L.o_grads;
     const double mac = (double)HD * (XD + ye) + HD * HD + 2.0 * ZD * HD + (double)HD * (ZD + yd) + HD * HD + (double)XD * HD;
     const double dxm = (double)HD * HD + 2.0 * ZD * HD + (double)ZD * HD + HD * HD + (double)XD * HD;
-    plan->flops_per_step = 2.0 * (2.0 * mac + dxm) * (double)B;
+    double macx = 0.0, dxx = 0.0;
+    if (model == DVAE_MODEL_M2_INFO) {   // classifier fwd once; auxiliary fwd twice in the reference (z and z.detach())
+        macx = ((double)HD * XD + HD * HD + HD) + 2.0 * ((double)HD * ZD + HD * HD + HD);
+        dxx = ((double)HD * HD + HD) + ((double)HD * HD + HD + (double)ZD * HD);
+    }
+    plan->flops_per_step = 2.0 * (2.0 * mac + dxm) * (double)B + 2.0 * (2.0 * macx + dxx) * (double)B;
+    plan->info_alpha = 0.0; plan->info_beta = 10.0; plan->info_gamma = 1.0;
     plan->min_hbm_bytes_per_step = 4.0 * (XD + y_dim + ZD) * (double)B;
     return 0;
 }
@@ -1126,9 +1301,17 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     addA(L.dd1T, HD, 8, 9); addB(L.zT, ZD, 0); if (yd) addB(L.yT, yd, ZD); emit();
     addA(L.dd2T, HD, 10, 11); addB(L.d1T, HD, 0); emit();
     addA(L.daT, XD, 12, 13); addB(L.d2T, HD, 0); emit();
+    if (L.info) {   // classifier (tensors 14-19) and auxiliary net (20-25): scripts/training_M2_info_vad.py:141-143
+        addA(L.dc1T, HD, 14, 15); addB(L.xT, XD, 0); emit();
+        addA(L.dc2T, HD, 16, 17); addB(L.c1T, HD, 0); emit();
+        addA(L.dc3T, 1, 18, 19); addB(L.c2T, HD, 0); emit();
+        addA(L.da1T, HD, 20, 21); addB(L.zT, ZD, 0); emit();
+        addA(L.da2T, HD, 22, 23); addB(L.a1T, HD, 0); emit();
+        addA(L.da3T, 1, 24, 25); addB(L.a2T, HD, 0); emit();
+    }
     if (n != L.ntiles) { fprintf(stderr, "dvae: internal group count mismatch %d vs %d\n", n, L.ntiles); }
     // tensors -> kernel-layout copies
-    for (int i = 0; i < 14; ++i) {
+    for (int i = 0; i < p->n_tensors; ++i) {
         TensorDesc t;
         memset(&t, 0, sizeof(t));
         t.off = p->tensor_offset[i]; t.rows = p->tensor_rows[i]; t.cols = p->tensor_cols[i];
@@ -1144,6 +1327,12 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     td[8].sf_off = L.W3s; td[8].sf_nt = 4; td[8].st_off = L.W3zt; td[8].st_nt = 1; td[8].st_cmax = ZD;
     td[10].sf_off = L.W4s; td[10].sf_nt = 4; td[10].st_off = L.W4t; td[10].st_nt = 4; td[10].st_cmax = HD;
     td[12].sf_off = L.W5s; td[12].sf_nt = NT_OUT; td[12].st_off = L.W5t; td[12].st_nt = 4; td[12].st_cmax = HD;
+    if (L.info) {
+        td[14].sf_off = L.Wc1s; td[14].sf_nt = 4; td[14].sf_ld = XP; td[14].sf_split = XD; td[14].sf_gap = XP - XD;
+        td[16].sf_off = L.Wc2s; td[16].sf_nt = 4; td[16].sf_ld = HD; td[16].st_off = L.Wc2t; td[16].st_nt = 4; td[16].st_ld = HD; td[16].st_cmax = HD;
+        td[20].sf_off = L.Wa1s; td[20].sf_nt = 4; td[20].sf_ld = ZD; td[20].st_off = L.Wa1t; td[20].st_nt = 1; td[20].st_ld = HD; td[20].st_cmax = ZD;
+        td[22].sf_off = L.Wa2s; td[22].sf_nt = 4; td[22].sf_ld = HD; td[22].st_off = L.Wa2t; td[22].st_nt = 4; td[22].st_ld = HD; td[22].st_cmax = HD;
+    }
 }
 
 static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* params, float* m, float* v, char* ws, int n_slabs,
@@ -1162,6 +1351,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
         a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)adam_eps; a.gscale = (float)grad_scale;
     }
     a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3;
+    a.info = plan->model == DVAE_MODEL_M2_INFO; a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
     const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
     if (plan->precision == DVAE_PREC_BF16) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true>), grid, dim3(256), 0, s, a);
@@ -1212,16 +1402,16 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     return dvae_train_repack(plan, params, ws, stream);
 }
 
-template <typename P, int YP, bool YENC>
+template <typename P, int YP, bool YENC, bool INFO = false>
 static int launch_rows(const RowsArgs& a, int grid, hipStream_t s) {
     const size_t lds = P::XFULL ? Ld<typename P::T>::bytes_full : Ld<typename P::T>::bytes_slices;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)vae_rows_kernel<P, YP, YENC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)vae_rows_kernel<P, YP, YENC, INFO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(rows kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    hipLaunchKernelGGL((vae_rows_kernel<P, YP, YENC>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((vae_rows_kernel<P, YP, YENC, INFO>), dim3(grid), dim3(256), lds, s, a);
     DVAE_LAUNCH_OK("vae_rows_kernel");
     return 0;
 }
@@ -1250,6 +1440,12 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.b1 = params + plan->tensor_offset[1]; a.b2 = params + plan->tensor_offset[3];
     a.bmu = params + plan->tensor_offset[5]; a.blv = params + plan->tensor_offset[7];
     a.b3 = params + plan->tensor_offset[9]; a.b4 = params + plan->tensor_offset[11]; a.b5 = params + plan->tensor_offset[13];
+    if (L.info) {
+        a.Wc1s = WC(L.Wc1s); a.Wc2s = WC(L.Wc2s); a.Wc2t = WC(L.Wc2t); a.Wa1s = WC(L.Wa1s); a.Wa1t = WC(L.Wa1t); a.Wa2s = WC(L.Wa2s); a.Wa2t = WC(L.Wa2t);
+        a.bc1 = params + plan->tensor_offset[15]; a.bc2 = params + plan->tensor_offset[17]; a.wc3 = params + plan->tensor_offset[18]; a.bc3 = params + plan->tensor_offset[19];
+        a.ba1 = params + plan->tensor_offset[21]; a.ba2 = params + plan->tensor_offset[23]; a.wa3 = params + plan->tensor_offset[24]; a.ba3 = params + plan->tensor_offset[25];
+        a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
+    }
     a.partials = (double*)(w + L.o_partials);
     a.wcopy = wc; a.wcopy_bytes = L.wcopy_elems * esz;
     a.dbg = g_dbg;
@@ -1258,17 +1454,23 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     auto ST = [&](int64_t row) { return (void*)(st + row * plan->Bp * esz); };
     a.xT = ST(L.xT); a.yT = ST(L.yT); a.h1T = ST(L.h1T); a.h2T = ST(L.h2T); a.dh1T = ST(L.dh1T); a.dh2T = ST(L.dh2T);
     a.dmlvT = ST(L.dmlvT); a.zT = ST(L.zT); a.d1T = ST(L.d1T); a.d2T = ST(L.d2T); a.dd1T = ST(L.dd1T); a.dd2T = ST(L.dd2T); a.daT = ST(L.daT);
+    if (L.info) {
+        a.c1T = ST(L.c1T); a.c2T = ST(L.c2T); a.dc1T = ST(L.dc1T); a.dc2T = ST(L.dc2T); a.dc3T = ST(L.dc3T);
+        a.a1T = ST(L.a1T); a.a2T = ST(L.a2T); a.da1T = ST(L.da1T); a.da2T = ST(L.da2T); a.da3T = ST(L.da3T);
+    }
     const int grid = (int)plan->rows_grid;
     const bool m2 = plan->model == DVAE_MODEL_M2;
     int rc;
     {
         ProfScope ps(s, 0);
         if (bf) {
-            if (!m2) rc = launch_rows<PolBF16, 0, false>(a, grid, s);
+            if (L.info) rc = launch_rows<PolBF16, 16, false, true>(a, grid, s);
+            else if (!m2) rc = launch_rows<PolBF16, 0, false>(a, grid, s);
             else if (plan->y_dim == 1) rc = launch_rows<PolBF16, 16, true>(a, grid, s);
             else rc = launch_rows<PolBF16, 528, true>(a, grid, s);
         } else {
-            if (!m2) rc = launch_rows<PolF32, 0, false>(a, grid, s);
+            if (L.info) rc = launch_rows<PolF32, 16, false, true>(a, grid, s);
+            else if (!m2) rc = launch_rows<PolF32, 0, false>(a, grid, s);
             else if (plan->y_dim == 1) rc = launch_rows<PolF32, 16, true>(a, grid, s);
             else rc = launch_rows<PolF32, 528, true>(a, grid, s);
         }

@@ -23,15 +23,24 @@ class TrainPlan(ctypes.Structure):
                 ("B", ctypes.c_int64), ("n_tensors", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("n_params", ctypes.c_int64),
                 ("tensor_offset", ctypes.c_int64 * MAXT), ("tensor_rows", ctypes.c_int32 * MAXT), ("tensor_cols", ctypes.c_int32 * MAXT),
                 ("workspace_bytes", ctypes.c_int64), ("grad_offset_bytes", ctypes.c_int64), ("Bp", ctypes.c_int64),
-                ("rows_grid", ctypes.c_int64), ("flops_per_step", ctypes.c_double), ("min_hbm_bytes_per_step", ctypes.c_double)]
+                ("rows_grid", ctypes.c_int64), ("flops_per_step", ctypes.c_double), ("min_hbm_bytes_per_step", ctypes.c_double),
+                ("info_alpha", ctypes.c_double), ("info_beta", ctypes.c_double), ("info_gamma", ctypes.c_double)]
 
 
-MODEL_CODE = {"M1": 1, "M2": 2}
+MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3}
 PREC_CODE = {"fp32": 0, "bf16": 1}
 TENSOR_NAMES = ["encoder.hidden.0.weight", "encoder.hidden.0.bias", "encoder.hidden.1.weight", "encoder.hidden.1.bias",
                 "encoder.sample.mu.weight", "encoder.sample.mu.bias", "encoder.sample.log_var.weight", "encoder.sample.log_var.bias",
                 "decoder.hidden.0.weight", "decoder.hidden.0.bias", "decoder.hidden.1.weight", "decoder.hidden.1.bias",
                 "decoder.reconstruction.weight", "decoder.reconstruction.bias"]
+# M2_info (DeepGenerativeModel_v5): the same 14 under "enc_dec_clf.", then the classifier and the auxiliary net
+INFO_NAMES = (["enc_dec_clf." + n for n in TENSOR_NAMES]
+              + [f"enc_dec_clf.classifier.{l}.{w}" for l in ("hidden.0", "hidden.1", "output_layer") for w in ("weight", "bias")]
+              + [f"auxiliary.{l}.{w}" for l in ("hidden.0", "hidden.1", "output_layer") for w in ("weight", "bias")])
+
+
+def tensor_names(model):
+    return INFO_NAMES if model == "M2_info" else TENSOR_NAMES
 
 def _lib():
     return N.load()
@@ -39,7 +48,8 @@ def _lib():
 
 def supported(model, dims):
     return (model in MODEL_CODE and dims["x_dim"] == 513 and dims["z_dim"] == 16 and tuple(dims["h_dim"]) == (128, 128)
-            and ((model == "M1" and dims.get("y_dim", 0) in (0, None)) or (model == "M2" and dims["y_dim"] in (1, 513))))
+            and ((model == "M1" and dims.get("y_dim", 0) in (0, None)) or (model == "M2" and dims["y_dim"] in (1, 513))
+                 or (model == "M2_info" and dims["y_dim"] == 1)))
 
 
 class Trainer:
@@ -50,11 +60,11 @@ class Trainer:
     gradient is summed over ranks with one RCCL all-reduce and scaled by 1 / world."""
 
     def __init__(self, model, dims, params=None, batch=128, device="cuda:0", precision="fp32", lr=1e-4, betas=(0.9, 0.999),
-                 adam_eps=1e-8, elbo_eps=1e-8, process_group=None, world=1, ksplit=0, seed=None):
+                 adam_eps=1e-8, elbo_eps=1e-8, process_group=None, world=1, ksplit=0, seed=None, alpha=0.0, beta=10.0, gamma=1.0):
         if not torch.cuda.is_available():
             raise RuntimeError("Trainer needs the MI355X HIP path (no CPU fallback)")
         if not supported(model, dims):
-            raise NotImplementedError(f"fused train step covers M1 / M2 at x 513, z 16, h [128,128], y in (0, 1, 513); got {model} {dims}")
+            raise NotImplementedError(f"fused train step covers M1 / M2 (y 1 or 513) / M2_info (y 1) at x 513, z 16, h [128,128]; got {model} {dims}")
         self.lib = _lib()
         self.model, self.dims, self.B = model, dict(dims), int(batch)
         self.device = torch.device(device)
@@ -65,13 +75,16 @@ class Trainer:
         self.plan = TrainPlan()
         N.check(self.lib.dvae_train_plan(MODEL_CODE[model], self.y_dim, PREC_CODE[precision], self.B, ksplit, ctypes.byref(self.plan)),
                 "dvae_train_plan")
+        self.names = tensor_names(model)
+        if model == "M2_info":          # loss weights of scripts/training_M2_info_vad.py:53-55
+            self.plan.info_alpha, self.plan.info_beta, self.plan.info_gamma = float(alpha), float(beta), float(gamma)
         P = self.plan.n_params
         with torch.cuda.device(self.device):
             self.params = torch.zeros(P, dtype=torch.float32, device=self.device)
             self.m = torch.zeros(P, dtype=torch.float32, device=self.device)
             self.v = torch.zeros(P, dtype=torch.float32, device=self.device)
             self.ws = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
-            self.losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+            self.losses = torch.zeros(8 if model == "M2_info" else 3, dtype=torch.float32, device=self.device)
         go = self.plan.grad_offset_bytes
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
         self.step_count = 0
@@ -89,17 +102,19 @@ class Trainer:
             torch.manual_seed(seed)
         if self.model == "M1":
             m = M.VariationalAutoencoder([513, 16, [128, 128]])
-        else:
+        elif self.model == "M2":
             m = M.DeepGenerativeModel([513, self.y_dim, 16, [128, 128]], None)
+        else:
+            m = M.DeepGenerativeModel_v5([513, self.y_dim, 16, [128, 128]])
         return {k: v.detach() for k, v in m.state_dict().items()}
 
     def tensor_view(self, i):
         o, r, c = self.plan.tensor_offset[i], self.plan.tensor_rows[i], self.plan.tensor_cols[i]
         v = self.params[o:o + r * c]
-        return v.view(r, c) if TENSOR_NAMES[i].endswith("weight") else v
+        return v.view(r, c) if self.names[i].endswith("weight") else v
 
     def _write_params(self, sd):
-        for i, name in enumerate(TENSOR_NAMES):
+        for i, name in enumerate(self.names):
             t = sd[name]
             t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.detach()
             view = self.tensor_view(i)
@@ -113,7 +128,7 @@ class Trainer:
             N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
 
     def state_dict(self):
-        return {name: self.tensor_view(i).clone() for i, name in enumerate(TENSOR_NAMES)}
+        return {name: self.tensor_view(i).clone() for i, name in enumerate(self.names)}
 
     def state_dict_numpy(self):
         return {k: v.cpu().numpy() for k, v in self.state_dict().items()}
@@ -125,7 +140,7 @@ class Trainer:
         slabs = self.ws[go:go + 4 * P * ks].view(torch.float32).view(ks, P)
         flat = slabs[:self._used_slabs()].sum(0) if not self._reduced else slabs[0]
         out = {}
-        for i, name in enumerate(TENSOR_NAMES):
+        for i, name in enumerate(self.names):
             o, r, c = self.plan.tensor_offset[i], self.plan.tensor_rows[i], self.plan.tensor_cols[i]
             g = flat[o:o + r * c].cpu().numpy()
             out[name] = g.reshape(r, c) if name.endswith("weight") else g

@@ -3,6 +3,8 @@
  * One step = the loop body of the reference's training scripts
  *   scripts/training_M1.py:134-139   r, mu, logvar = model(x); elbo; backward; Adam.step; zero_grad
  *   scripts/training_M2.py:142-147   the same with model(x, y)
+ *   scripts/training_M2_info_vad.py:159-198   M2_info: + classifier(x), auxiliary(z), two BCE terms, two Adam
+ *       groups incl. the reference's gradient-accumulation quirk (the auxiliary net sees (gamma - beta) * dBCE)
  * for the only geometry those scripts use (x_dim 513, z_dim 16, h_dim [128, 128]; y_dim 0, 1 or 513),
  * in three launches:
  *   rows kernel  : per 32-frame tile, the whole forward (encoder, reparametrisation, decoder),
@@ -24,14 +26,14 @@
 extern "C" {
 #endif
 
-enum { DVAE_MODEL_M1 = 1, DVAE_MODEL_M2 = 2 };
+enum { DVAE_MODEL_M1 = 1, DVAE_MODEL_M2 = 2, DVAE_MODEL_M2_INFO = 3 };
 enum { DVAE_PREC_F32 = 0, DVAE_PREC_BF16 = 1 };
 #define DVAE_TRAIN_MAX_TENSORS 32
 
 typedef struct {
     /* inputs (echoed) */
     int32_t model;            /* DVAE_MODEL_* */
-    int32_t y_dim;            /* 0 (M1), 1 or 513 (M2) */
+    int32_t y_dim;            /* 0 (M1), 1 or 513 (M2), 1 (M2_info) */
     int32_t precision;        /* DVAE_PREC_*: matrix-core operand type (accumulation is always fp32) */
     int32_t ksplit;           /* frame-axis slices of the weight-gradient reduction */
     int64_t B;                /* frames per step */
@@ -51,6 +53,10 @@ typedef struct {
     /* algorithmic work per step, for roofline accounting */
     double  flops_per_step;
     double  min_hbm_bytes_per_step;
+    /* M2_info loss weights (scripts/training_M2_info_vad.py:53-55): enc_loss = ELBO + alpha*BCE(clf(x), y)
+       - beta*BCE(aux(z), y), aux_loss = gamma*BCE(aux(z.detach()), y).  dvae_train_plan sets the script's
+       defaults (0, 10, 1); the caller may overwrite them before dvae_train_init. */
+    double  info_alpha, info_beta, info_gamma;
 } dvae_train_plan_t;
 
 /* Fill `plan` for (model, y_dim, precision, B).  ksplit_hint 0 = choose.  Returns DVAE_E_UNSUPPORTED
@@ -68,7 +74,8 @@ int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* w
                      const float* y, int ldy, const float* eps_noise, float elbo_eps, int reduce_slabs, void* stream);
 
 /* apply kernel: g = grad_scale * sum of n_slabs slabs; Adam(lr, beta1, beta2, adam_eps) at `step` (1-based) on
- * params/m/v; refresh weight copies; losses3 = {recon + KL, recon, KL} (means over the B local frames). */
+ * params/m/v; refresh weight copies; losses3 = {recon + KL, recon, KL} (means over the B local frames);
+ * for M2_info the buffer holds 8 floats: {ELBO, recon, KL, enc_loss, classif_loss, aux_loss, aux_enc_loss, 0}. */
 int dvae_train_apply(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws, int n_slabs,
                      int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale,
                      float* losses3, void* stream);

@@ -1,0 +1,38 @@
+"""STFT / ISTFT throughput on the MI355X (device-resident input) next to the CPU oracle (numpy) and torch CPU.
+Algorithmic bytes per frame: 1024 B in (256 new fp32 samples; 2048 B for float64 audio) + 4104 B out."""
+import importlib, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+H = importlib.import_module("disentangled-vae_amd.stft")
+from oracle import stft_oracle as so
+
+def timeit(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+def main():
+    dev = torch.device("cuda")
+    res = {}
+    for secs, dt in ((5, torch.float64), (600, torch.float64), (600, torch.float32)):
+        n = 16000 * secs
+        x = torch.randn(n, dtype=dt, device=dev)
+        T = H.frame_count(n, 1024, 256)
+        w = H.window_f64("hann", 1024, dev)
+        t_c = timeit(lambda: H.stft_device(x, w, 1024, 256, T, 0))
+        t_p = timeit(lambda: H.stft_device(x, w, 1024, 256, T, 1))
+        S = H.stft_device(x, w, 1024, 256, T, 0)
+        t_i = timeit(lambda: H.istft_device(S, w, 1024, 256, T, 0, n))
+        inb = 256 * x.element_size()
+        res[f"{secs}s_{str(dt).split('.')[-1]}"] = dict(frames=T, stft_us=t_c * 1e6, stft_power_us=t_p * 1e6, istft_us=t_i * 1e6,
+            stft_Mframes_s=T / t_c / 1e6, stft_GBs=T * (inb + 4104) / t_c / 1e9, istft_Mframes_s=T / t_i / 1e6,
+            istft_GBs=T * (4104 + 1024) / t_i / 1e9)
+    xs = np.random.default_rng(0).standard_normal(16000 * 60)
+    t0 = time.perf_counter(); so.stft(xs, fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=False); t_np = time.perf_counter() - t0
+    res["cpu_numpy_oracle_Mframes_s"] = H.frame_count(len(xs) + 256, 1024, 256) / t_np / 1e6
+    print(json.dumps(res, indent=1))
+
+if __name__ == "__main__":
+    main()
