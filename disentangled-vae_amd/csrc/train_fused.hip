@@ -1217,7 +1217,11 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     const int64_t maxg = 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
     plan->rows_grid = ntiles < maxg ? ntiles : maxg;
     int ks = ksplit_hint;
-    if (ks <= 0) { ks = (int)(plan->Bp / 1024); if (ks < 1) ks = 1; if (ks > 8) ks = 8; }
+    // bf16: 8 slices (one per XCD).  fp32: the MFMA-bound wgrad needs a wave on every SIMD (>= 1024 wave jobs): 16.
+    if (ks <= 0) {
+        const int cap = precision == DVAE_PREC_BF16 ? 8 : 16;
+        ks = (int)(plan->Bp / (precision == DVAE_PREC_BF16 ? 1024 : 512)); if (ks < 1) ks = 1; if (ks > cap) ks = cap;
+    }
     if (ks > 64) ks = 64;
     plan->ksplit = ks;
     Layout L;
