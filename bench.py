@@ -174,13 +174,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)          # one rank per GPU on the node; wraps only on test rigs with fewer GPUs
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DVAE_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     y_dim = a.y_dim if a.y_dim is not None else {"M1": 0, "M2": 513, "M2_info": 1}[a.model]
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     B = a.batch

@@ -985,7 +985,7 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
 // round-robin to the 8 XCDs) work on different frame slices, so each XCD's L2 mostly holds one
 // slice of the stash.  blockDim.x / 64 groups per workgroup.
 template <typename P>
-__global__ __launch_bounds__(128) void wgrad_kernel(const GroupDesc* __restrict__ groups, int ngroups, int ksplit, int64_t Bp,
+__global__ __launch_bounds__(256) void wgrad_kernel(const GroupDesc* __restrict__ groups, int ngroups, int ksplit, int64_t Bp,
                                                     int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -1167,6 +1167,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
 }
 
 static bool g_prof = false;
+static thread_local bool g_eval_only = false;   // dvae_train_eval: skip the wgrad launch
 static unsigned long long* g_dbg = nullptr;   // set by dvae_train_debug_stamps
 static double g_ms[4] = {0, 0, 0, 0};
 static int64_t g_calls[4] = {0, 0, 0, 0};
@@ -1480,10 +1481,12 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         }
     }
     if (rc) return rc;
+    if (g_eval_only) return 0;
     const int64_t kper = kper_of(plan);
     const int ks = (int)((plan->Bp + kper - 1) / kper);
     DVAE_CHECK_ARG(ks <= plan->ksplit, "train_grads: internal k-split mismatch");
-    constexpr int GPW = 2;                                  // groups (waves) per workgroup
+    int GPW = 2;                                            // groups (waves) per workgroup
+    { const char* e = getenv("DVAE_GPW"); if (e) { GPW = atoi(e); if (GPW < 1 || GPW > 4) GPW = 2; } }   // diagnostic override
     const dim3 g2((unsigned)(((L.ntiles + GPW - 1) / GPW) * ks));
     float* slabs = (float*)(w + L.o_grads);
     {
@@ -1528,6 +1531,29 @@ extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, flo
 
 extern "C" int dvae_train_debug_stamps(void* buf) {
     g_dbg = (unsigned long long*)buf;
+    return 0;
+}
+
+extern "C" int dvae_train_eval(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                               const float* y, int ldy, const float* eps_noise, float elbo_eps, float* losses3, void* stream) {
+    DVAE_CHECK_ARG(plan && params && ws && x && eps_noise && losses3, "train_eval: bad argument");
+    // forward + loss sums only: the rows kernel also writes the stash, which is simply not consumed
+    Layout L;
+    make_layout(*plan, L);
+    const int saved = 0;
+    (void)saved;
+    // run the rows kernel through dvae_train_grads' argument setup, but stop before the wgrad launch
+    g_eval_only = true;
+    int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, elbo_eps, 0, stream);
+    g_eval_only = false;
+    if (rc) return rc;
+    ApplyArgs a;
+    memset(&a, 0, sizeof(a));
+    char* w = (char*)ws;
+    a.partials = (const double*)(w + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3;
+    a.info = plan->model == DVAE_MODEL_M2_INFO; a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
+    hipLaunchKernelGGL((apply_kernel<float, true>), dim3(1), dim3(256), 0, (hipStream_t)stream, a);   // grid of 1 = the loss block only
+    DVAE_LAUNCH_OK("apply_kernel(loss only)");
     return 0;
 }
 

@@ -188,6 +188,17 @@ class Trainer:
             self._reduced = True
         return self.losses
 
+    def evaluate(self, x, y=None, eps_noise=None):
+        """Validation pass (scripts/training_M2.py:176-193): forward + elbo on a batch of the trainer's size, no
+        backward, no update.  Returns a NEW device tensor [ELBO, recon, KL] (M2_info: 8 entries)."""
+        if eps_noise is None:
+            eps_noise = torch.randn((self.B, 16), dtype=torch.float32, device=x.device)
+        yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
+        out = torch.zeros_like(self.losses)
+        N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
+                                         N.ptr(eps_noise.contiguous()), self.elbo_eps, N.ptr(out), N.stream()), "dvae_train_eval")
+        return out
+
     def grads_only(self, x, y, eps_noise, reduce=False):
         """rows + wgrad kernels without the optimiser (tests / gradient inspection)."""
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)

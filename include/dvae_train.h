@@ -85,6 +85,11 @@ int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, floa
                     const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
                     int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream);
 
+/* Validation pass of the scripts (scripts/training_M2.py:176-193: forward + elbo, no backward, no update):
+ * rows kernel + loss finalisation only.  losses3 as for dvae_train_apply. */
+int dvae_train_eval(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                    const float* y, int ldy, const float* eps_noise, float elbo_eps, float* losses3, void* stream);
+
 /* Rebuild the kernel-layout weight copies after `params` was written from outside (load_state_dict). */
 int dvae_train_repack(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream);
 

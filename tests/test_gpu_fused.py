@@ -233,3 +233,21 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
     for k in params:
         gr = np.asarray(g1[k], np.float64) + (np.asarray(g2[k], np.float64) if k in g2 else 0.0)   # aux: (gamma - beta) dBCE
         assert _relmax(g[k], gr.reshape(g[k].shape)) < tol, k
+
+
+def test_evaluate_is_forward_only_and_matches_step_losses():
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 41)
+    x, y, e = gu.make_batch(dims, 1000, 42)
+    t = lambda a: torch.from_numpy(a).cuda()
+    tr = trainer.Trainer("M2", dims, params, batch=1000, precision="fp32")
+    before = tr.state_dict_numpy()
+    ev = tr.evaluate(t(x), t(y), t(e)).cpu().numpy()
+    after = tr.state_dict_numpy()
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k               # no update
+    st = tr.step(t(x), t(y), t(e)).cpu().numpy()
+    np.testing.assert_array_equal(ev, st)                            # same forward, same loss scalars
+    out, _ = vo.vae_loss_and_grads("M2", {k: v.astype(np.float64) for k, v in params.items()}, x.astype(np.float64),
+                                   y.astype(np.float64), e.astype(np.float64))
+    np.testing.assert_allclose(ev, [out["loss"], out["recon"], out["kl"]], rtol=1e-4)
