@@ -23,196 +23,12 @@
 // constant-one fragment.
 #include <math.h>
 #include <stdlib.h>
-#include "common.hpp"
+#include "fused_tiles.hpp"
 #include "../../include/dvae_train.h"
 
 namespace dvae {
 namespace fused {
 
-constexpr int XD = 513, HD = 128, ZD = 16;
-constexpr int XP = 528;   // 513 input features padded to a multiple of 16
-constexpr int NO = 544;   // 513 output features padded to 17 row tiles of 32
-constexpr int TB = 32;    // frames per tile
-constexpr int NT_OUT = 17;
-// Weight-copy layout.  false: row-major [out][in_padded] (each wave load touches 32 rows x 32 B; the 4 k-steps
-// that share a 128-B line hit L1).  true: fragment-major [k-step][row tile][lane][E] (one contiguous 1 KB per
-// wave load).  Measured on MI355X (B = 8192, 256 workgroups in lockstep): fragment-major weights made the wide
-// GEMM phases 3-4x SLOWER (L1 x-block 8.4 us vs 2.3 us) in both block orders, so row-major is used; the stash
-// (written and read once, by different kernels) is fragment-major, which cut the wgrad kernel from 37 to 23 us.
-constexpr bool WFRAG = true;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-struct PolF32 {
-    typedef float T;
-    typedef f32x4 Frag;
-    typedef f32x4 Pack4;
-    static constexpr int E = 4;        // elements per 16-byte fragment
-    static constexpr int KSTEP = 8;    // reduction depth per fragment pair
-    static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
-    static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
-    static constexpr int WRING = 4;    // wgrad: k-steps of operand fragments in flight per wave
-    static constexpr bool EARLY_Y = false;
-    static constexpr bool XFULL = false;   // fp32 x tile does not fit LDS next to fp32 activations: streamed in 128-column slices
-    static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
-    }
-    static __device__ __forceinline__ T cvt(float v) { return v; }
-    static __device__ __forceinline__ Frag ones() { return Frag{1.f, 1.f, 1.f, 1.f}; }
-    static __device__ __forceinline__ float tanh_(float v) { return tanhf(v); }
-    static __device__ __forceinline__ float exp_(float v) { return expf(v); }
-    static __device__ __forceinline__ float log_(float v) { return logf(v); }
-};
-
-struct PolBF16 {
-    typedef __bf16 T;
-    typedef bf16x8 Frag;
-    typedef bf16x4 Pack4;
-    static constexpr int E = 8;
-    static constexpr int KSTEP = 16;
-    static constexpr int PD = 16;
-    static constexpr int PRE = 6;
-    static constexpr int WRING = 8;
-    static constexpr bool EARLY_Y = true;   // request the y tile before the x GEMM (68 VGPRs held across it)
-    static constexpr bool XFULL = true;    // whole fp32 x tile stays in LDS for the loss epilogue
-    static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-    static __device__ __forceinline__ T cvt(float v) { return (__bf16)v; }
-    static __device__ __forceinline__ Frag ones() {
-        const __bf16 o = (__bf16)1.0f;
-        return Frag{o, o, o, o, o, o, o, o};
-    }
-    // throughput mode: hardware exp2/log2/rcp based transcendentals
-    // raw v_exp_f32 / v_log_f32 (base 2): arguments here are never denormal (x + eps >= 1e-8), so the
-    // denormal-scaling sequence __expf / __logf wrap around them (~10 VALU each) is dropped; at one wave
-    // per SIMD every VALU instruction costs 4 issue cycles and the loss epilogue is VALU-bound
-    static __device__ __forceinline__ float exp_(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
-    static __device__ __forceinline__ float log_(float v) { return __builtin_amdgcn_logf(v) * 0.693147180559945309f; }
-    static __device__ __forceinline__ float tanh_(float v) {
-        const float e = __builtin_amdgcn_exp2f(v * 2.88539008177792681f);
-        return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-    }
-};
-
-// LDS row strides (elements): an odd number of 16-byte slots per row
-template <typename T> struct Ld {
-    static constexpr int per16 = 16 / (int)sizeof(T);
-    static constexpr int u = NO + per16;          // [frame][544 features]   (x / y / da)
-    static constexpr int hh = HD + per16;         // [frame][128]
-    static constexpr int z = 32 + per16;          // [frame][32]              (z | pad, dmu | dlv)
-    static constexpr int xt = 129;                // fp32 [frame][128] slice of x for the loss epilogue
-    static constexpr int nbias = 4 * HD + 32 + NO;   // b1 b2 [bmu|blv] b3 b4 b5(padded): fp32 copies for the epilogues
-    static constexpr int ninfo = 6 * HD + 8;         // M2_info: bc1 bc2 wc3 ba1 ba2 wa3, bc3, ba3
-    static constexpr int xf_floats = (TB * XD + 63) / 64 * 64;
-    static constexpr int xt_floats = (TB * xt + 63) / 64 * 64;
-    static constexpr size_t bytes_slices = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xt_floats + nbias + ninfo) * sizeof(float) + 64;
-    static constexpr size_t bytes_full = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xf_floats + nbias + ninfo) * sizeof(float) + 64;
-};
-
-__device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// First weight fragments of a GEMM, requested ahead of time (weights never depend on data, so the
-// next layer's first fragments are in flight across the current layer's epilogue and barrier).
-template <typename P, int NSTEPS> struct WPre {
-    static constexpr int N = NSTEPS < P::PRE ? NSTEPS : P::PRE;
-    typename P::Frag a[N > 0 ? N : 1];
-};
-
-// Weight fragments are fetched with buffer loads: one resource descriptor for the whole weight-copy
-// buffer, the per-lane byte offset in ONE VGPR and the (matrix, row tile, k-step) offset in an SGPR.
-// With plain 64-bit global addresses hipcc materialises one VGPR address pair per in-flight fragment
-// whenever the k-step stride exceeds the 4 KB immediate range, spills them, and reloads each from
-// scratch behind an s_waitcnt vmcnt(0) in front of every weight load (measured: 600 cycles per k-step).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct WRef { int voff; unsigned soff; };      // per-lane byte offset (VGPR), wave-uniform byte offset (SGPR)
-
-template <typename P>
-__device__ __forceinline__ typename P::Frag wload(__amdgpu_buffer_rsrc_t rs, WRef r, unsigned step_bytes) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, r.voff, r.soff + step_bytes, 0);
-    return __builtin_bit_cast(typename P::Frag, v);
-}
-
-template <typename P, int NSTEPS>
-__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, __amdgpu_buffer_rsrc_t rs, WRef wr, unsigned WSTR) {
-#pragma unroll
-    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = wload<P>(rs, wr, i * WSTR);
-    // hipcc otherwise sinks these loads down to their first use (after the epilogue and barrier)
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// acc += W[rows of this lane][k-block] * act^T : NSTEPS fragment pairs.  Weights stream straight from
-// L2 into a ring of D = min(PD, NSTEPS) fragment registers: the slot an MFMA has just consumed is
-// re-requested D steps ahead, so D loads per wave stay in flight (an L2 round trip under load is
-// ~1000 cycles, an MFMA step 32).  Activations come from LDS.  Only the outer loop is rolled.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-
-// `after_fill` runs once the ring is requested and before the first MFMA: the place for global STORES
-// (the previous layer's stash tile).  vmcnt retires loads and stores in issue order, so a store issued
-// right before a load that the next MFMA needs exposes a full write-acknowledge round trip; issued
-// here, the store acks overlap the D k-steps the ring already covers.
-template <typename P, int NSTEPS, typename Hook = NoHook>
-__device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, __amdgpu_buffer_rsrc_t rs, WRef wr,
-                                           const typename P::T* brow, unsigned WSTR, Hook after_fill = Hook()) {
-    typedef typename P::Frag Frag;
-    constexpr int STR = 2 * P::E;        // LDS activations: k-step = 2E consecutive features of a frame row
-    constexpr int D = NSTEPS < P::PD ? NSTEPS : P::PD;
-    constexpr int NIT = D > 0 ? NSTEPS / D : 0, REM = D > 0 ? NSTEPS % D : 0;
-    // activation fragments are read from LDS BD k-steps ahead; BD divides D so ring slots are static across laps
-    constexpr int BD = D % 4 == 0 ? 4 : (D % 3 == 0 ? 3 : (D % 2 == 0 ? 2 : 1));
-    static_assert(NIT <= 1 || D % BD == 0, "B ring must divide the weight ring");
-    Frag a[D > 0 ? D : 1];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        if (i < WPre<P, NSTEPS>::N) a[i] = w.a[i];
-        else a[i] = wload<P>(rs, wr, i * WSTR);
-    }
-    // Order pins: without them hipcc moves every weight load down to just above the MFMA that
-    // consumes it (one exposed L2 round trip per k-step, measured 150 ns/step instead of ~30).
-    __builtin_amdgcn_sched_barrier(0);
-    after_fill();
-    __builtin_amdgcn_sched_barrier(0);
-    // B ring: with the order pinned, an LDS read issued right before its MFMA exposes the full LDS
-    // latency every k-step (measured ~250 cycles/step on an idle chip); keep BD reads in flight instead.
-    Frag bq[BD];
-#pragma unroll
-    for (int i = 0; i < BD; ++i)
-        if (i < NSTEPS) bq[i] = *reinterpret_cast<const Frag*>(brow + i * STR);
-    if (NIT > 1) {
-#pragma unroll 1
-        for (int c = 0; c < NIT - 1; ++c) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                P::mma(acc, a[i], bq[i % BD]);
-                // D is a multiple of BD whenever NIT > 1, so slot i % BD is static across laps
-                bq[i % BD] = *reinterpret_cast<const Frag*>(brow + (c * D + i + BD) * STR);
-                a[i] = wload<P>(rs, wr, ((c + 1) * D + i) * WSTR);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    if (NIT > 0) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            constexpr int base = (NIT - 1) * D;
-            P::mma(acc, a[i], bq[(base + i) % BD]);
-            if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
-            if (i < REM) a[i] = wload<P>(rs, wr, (NIT * D + i) * WSTR);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < REM; ++i) {
-        constexpr int base = NIT * D;
-        P::mma(acc, a[i], bq[(base + i) % BD]);
-        if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 struct RowsArgs {
     const float* x; const float* y; const float* eps;
@@ -237,39 +53,6 @@ struct RowsArgs {
 
 #define DVAE_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
-template <typename P> __device__ __forceinline__ void zero_acc(f32x16& a) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = 0.f;
-}
-
-// 16 bias values of this lane's C-tile rows (features fbase + 8g + 4h + 0..3) from the LDS bias table
-__device__ __forceinline__ void bias16(const float* bl, int fbase, int h, float (&b)[16]) {
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bl + fbase + 8 * gq + 4 * h);
-        b[4 * gq] = v[0]; b[4 * gq + 1] = v[1]; b[4 * gq + 2] = v[2]; b[4 * gq + 3] = v[3];
-    }
-}
-
-// Stash layout ("fragment-major"): a matrix of R features x Bp frames is stored as
-//   [feature tile (32)][k-step (KSTEP frames)][lane = h*32 + feature%32][E frames]
-// i.e. exactly the order in which one wgrad wave-instruction consumes it: every operand load of
-// the wgrad kernel and every store here is one contiguous 1 KB block.  A 32-feature tile block
-// starts at element 32 * tile * Bp, as in a plain [feature][Bp] matrix.
-//
-// put_tile: values v[r] of a 32-feature x 32-frame C tile (feature = fbase + feat_of(r,h), frame = l31)
-// go to LDS [frame][feature] (the next layer's B operand); the same wave then reads its own 32
-// columns back transposed (E consecutive frames of one feature = one fragment) for the stash.
-template <typename P>
-__device__ __forceinline__ void put_lds(const float (&v)[16], typename P::T* lds, int ldl, int fbase, int l31, int h) {
-    typedef typename P::Pack4 Pack4;
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        Pack4 p;
-        p[0] = P::cvt(v[4 * gq]); p[1] = P::cvt(v[4 * gq + 1]); p[2] = P::cvt(v[4 * gq + 2]); p[3] = P::cvt(v[4 * gq + 3]);
-        *reinterpret_cast<Pack4*>(lds + l31 * ldl + fbase + 8 * gq + 4 * h) = p;
-    }
-}
 
 // LDS tile [32 frames][features fbase .. fbase+31] -> fragment-major stash tile (E consecutive frames of
 // one feature = one 16-byte fragment).  Called by the wave that wrote those LDS columns.
