@@ -1,0 +1,591 @@
+// MCEM speech enhancement on the GPU (reference: packages/models/mcem.py): the Metropolis-Hastings
+// chain over the VAE latents as ONE persistent launch per E-step, the NMF multiplicative updates as
+// two HBM-streaming launches, the Wiener gains as one.  See include/dvae_mcem.h.
+//
+// MH kernel: one 256-thread workgroup owns a tile of 32 frames for the whole chain (frames are
+// independent given g and Vb).  The decoder (tanh 128, tanh 128, exp 513) runs on the MFMA tile
+// machinery of the train step (transposed orientation: the lane is the frame), so the
+// log-likelihood terms, the accept test and the masked update never leave registers / LDS:
+//   * the label part of decoder layer 1 (W3[:, 16:] y + b3) does not change along the chain: computed
+//     once per tile and kept in 16 registers;
+//   * the reference evaluates the decoder twice per iteration (proposal, then the updated state,
+//     mcem.py:247,268); the decoder acts frame by frame, so keeping the per-frame likelihood of the
+//     current state is equivalent and halves the work;
+//   * the per-frame likelihood sum over 513 bins is accumulated in double.
+#include <math.h>
+#include "fused_tiles.hpp"
+#include "../../include/dvae_mcem.h"
+
+namespace dvae {
+namespace fused {
+
+struct MhArgs {
+    const float* Z0;      // (16, N)            initial latents                       [MH mode]
+    const float* y;       // (ydim, N) or null
+    const float* g;       // (N)
+    const float* Vb;      // (513, N)
+    const float* X2;      // (513, N)
+    const float* noise;   // (nit, 16, N)
+    const float* logu;    // (nit, N)
+    float* Zs;            // (N, R, 16)  MH mode: written (R = nit - burnin); decode mode: read
+    float* Vs;            // (R, 513, N) or null
+    float* accp;          // (nit, N) log acceptance ratios, optional
+    unsigned char* accd;  // (nit, N) decisions, optional
+    int ydim, nit, burnin, R, ntiles;
+    int64_t N;
+    float sd;
+    const void* wcopy; int64_t wcopy_bytes;
+    int64_t oW3, oW4, oW5;     // element offsets of the fragment-major copies
+    const float* bias;         // b3[128] b4[128] b5[544]
+};
+
+template <typename T> struct MhLds {
+    static constexpr int per16 = 16 / (int)sizeof(T);
+    static constexpr int hh = HD + per16, z = 32 + per16;
+    static constexpr int nbias = 2 * HD + NO;
+    static constexpr size_t bytes(int yp) {
+        return (size_t)TB * (2 * hh + z + (yp ? yp + per16 : 0)) * sizeof(T) + (size_t)nbias * sizeof(float) + 64;
+    }
+};
+
+template <typename P, int YP>
+__global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
+    typedef typename P::T T;
+    constexpr int E = P::E, KS = P::KSTEP;
+    constexpr int LDH = MhLds<T>::hh, LDZ = MhLds<T>::z, LDY = YP + MhLds<T>::per16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ha = reinterpret_cast<T*>(smem);
+    T* Hb = Ha + TB * LDH;
+    T* Zb = Hb + TB * LDH;
+    T* Yb = Zb + TB * LDZ;
+    float* Bias = reinterpret_cast<float*>(Yb + (YP ? TB * LDY : 0));
+    constexpr int OB3 = 0, OB4 = HD, OB5 = 2 * HD;
+    __shared__ double red[4][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int fb = 32 * wave;
+    constexpr int FB = 64 * E;
+    constexpr unsigned SZ = sizeof(T);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr unsigned S4 = 4 * FB * SZ, S17 = NT_OUT * FB * SZ, TSTEP = FB * SZ;
+    constexpr unsigned KB3 = (ZD / KS) * 4 * FB * SZ;
+    const WRef W3r{lane * 16, (unsigned)(g.oW3 * SZ) + (unsigned)wave_u * TSTEP};
+    const WRef W4r{lane * 16, (unsigned)(g.oW4 * SZ) + (unsigned)wave_u * TSTEP};
+    const WRef W5r{lane * 16, (unsigned)(g.oW5 * SZ)};
+    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes}; };
+    const T* const Har = Ha + l31 * LDH + h * E;
+    const T* const Hbr = Hb + l31 * LDH + h * E;
+    const T* const Zbr = Zb + l31 * LDZ + h * E;
+    const T* const Ybr = Yb + l31 * LDY + h * E;
+
+    for (int i = tid; i < MhLds<T>::nbias; i += 256) Bias[i] = g.bias[i];
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        const int64_t n0 = (int64_t)tile * TB;
+        const bool live = n0 + l31 < g.N;
+        const int64_t n = live ? n0 + l31 : g.N - 1;          // clamped frame index of this lane
+        const float g_n = g.g ? g.g[n] : 1.f;
+
+        // ---- label part of decoder layer 1, once per tile: c1 = W3[:, 16:] y + b3 ----
+        float c1[16];
+        bias16(Bias + OB3, fb, h, c1);
+        if (YP > 0) {
+            for (int idx = tid; idx < TB * YP; idx += 256) {
+                const int f = idx >> 5, fr = idx & 31;          // consecutive threads: consecutive frames of one label row
+                float v = 0.f;
+                if (f < g.ydim && n0 + fr < g.N) v = g.y[(int64_t)f * g.N + n0 + fr];
+                Yb[fr * LDY + f] = P::cvt(v);
+            }
+            __syncthreads();
+            f32x16 acc;
+            zero_acc<P>(acc);
+            WPre<P, YP / KS> w3y;
+            wprefetch<P, YP / KS>(w3y, wrs, woff(W3r, KB3), S4);
+            gemm_block<P, YP / KS>(acc, w3y, wrs, woff(W3r, KB3), Ybr, S4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c1[r] += acc[r];
+        }
+
+        // latent state of this lane's frame (wave 0): features 4h..4h+3 and 8+4h..8+4h+3
+        float z[8], zp[8];
+        float prior_cur = 0.f;
+        double ll_cur = 0.0;
+        const int mstart = g.nit > 0 ? -1 : 0;
+        const int mend = g.nit > 0 ? g.nit : 0;
+        if (wave == 0 && g.nit > 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[r] = g.Z0[(int64_t)feat_of(r, h) * g.N + n];
+        }
+
+        // one decoder pass over the latents in Zb; EPI(t, f32x16 acc) handles output tile t of this wave
+        auto decode = [&](auto&& epi_pre, auto&& epi) {
+            f32x16 acc;
+            WPre<P, ZD / KS> w3z;
+            wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
+            zero_acc<P>(acc);
+            gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4);
+            WPre<P, HD / KS> w4;
+            wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + c1[r]);
+            put_lds<P>(v, Ha, LDH, fb, l31, h);
+            __syncthreads();
+            zero_acc<P>(acc);
+            gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4);
+            WPre<P, HD / KS> w5;
+            wprefetch<P, HD / KS>(w5, wrs, woff(W5r, wave_u * TSTEP), S17);
+            float bv[16];
+            bias16(Bias + OB4, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(v, Hb, LDH, fb, l31, h);
+            __syncthreads();
+#pragma unroll 1
+            for (int t = wave_u; t < NT_OUT; t += 4) {
+                zero_acc<P>(acc);
+                const WRef wr = woff(W5r, (unsigned)t * TSTEP);
+                gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { epi_pre(t); });
+                if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
+                bias16(Bias + OB5, 32 * t, h, bv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += bv[r];
+                epi(t, acc);
+            }
+        };
+
+        for (int m = mstart; m < mend; ++m) {
+            float prior_p = 0.f;
+            if (wave == 0) {
+                if (m >= 0) {
+                    const float* nz = g.noise + ((int64_t)m * ZD) * g.N + n;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) zp[r] = z[r] + g.sd * nz[(int64_t)feat_of(r, h) * g.N];   // mcem.py:244
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) zp[r] = z[r];
+                }
+                float zv[16];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { zv[r] = zp[r]; zv[r + 8] = 0.f; prior_p += zp[r] * zp[r]; }
+                put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+                prior_p += __shfl_xor(prior_p, 32, 64);
+            }
+            __syncthreads();
+            double ll = 0.0;
+            float xs[16], vbs[16];
+            decode(
+                [&](int t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int f = 32 * t + feat_of(r, h); f = f < XD ? f : XD - 1;
+                        xs[r] = g.X2[(int64_t)f * g.N + n];
+                        vbs[r] = g.Vb[(int64_t)f * g.N + n];
+                    }
+                },
+                [&](int t, const f32x16& a) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = 32 * t + feat_of(r, h) < XD;
+                        const float vx = fmaf(g_n, P::exp_(a[r]), vbs[r]);            // mcem.py:248-249
+                        const float term = P::log_(vx) + xs[r] / vx;                  // mcem.py:252-253
+                        s += ok ? term : 0.f;
+                    }
+                    ll += (double)s;
+                });
+            ll += __shfl_xor(ll, 32, 64);
+            if (h == 0) red[wave][l31] = ll;
+            __syncthreads();
+            if (wave == 0) {
+                const double ll_p = red[0][l31] + red[1][l31] + red[2][l31] + red[3][l31];
+                if (m < 0) {
+                    ll_cur = ll_p; prior_cur = prior_p;
+                } else {
+                    const float acc_prob = (float)(ll_cur - ll_p) + 0.5f * (prior_cur - prior_p);   // mcem.py:252-254
+                    const bool is_acc = g.logu[(int64_t)m * g.N + n] < acc_prob;                    // mcem.py:257
+                    if (is_acc) {
+                        ll_cur = ll_p; prior_cur = prior_p;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) z[r] = zp[r];
+                    }
+                    if (live && h == 0) {
+                        if (g.accp) g.accp[(int64_t)m * g.N + n] = acc_prob;
+                        if (g.accd) g.accd[(int64_t)m * g.N + n] = is_acc ? 1 : 0;
+                    }
+                    if (m >= g.burnin && live) {                                                    // mcem.py:271-273
+                        float* dst = g.Zs + ((int64_t)n * g.R + (m - g.burnin)) * ZD;
+                        *reinterpret_cast<f32x4*>(dst + 4 * h) = f32x4{z[0], z[1], z[2], z[3]};
+                        *reinterpret_cast<f32x4*>(dst + 8 + 4 * h) = f32x4{z[4], z[5], z[6], z[7]};
+                    }
+                }
+            }
+            // red[] and Zb are next written after the barriers of the following decoder pass
+        }
+
+        // ---- speech variances of the sampled latents: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
+        if (g.Vs != nullptr) {
+            for (int r_s = 0; r_s < g.R; ++r_s) {
+                __syncthreads();
+                if (wave == 0) {
+                    const float* src = g.Zs + ((int64_t)n * g.R + r_s) * ZD;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + 4 * h);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 8 + 4 * h);
+                    float zv[16];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { zv[r] = a0[r]; zv[4 + r] = a1[r]; zv[8 + r] = 0.f; zv[12 + r] = 0.f; }
+                    put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+                }
+                __syncthreads();
+                float* const vs_r = g.Vs + (int64_t)r_s * XD * g.N;
+                decode([&](int) {},
+                       [&](int t, const f32x16& a) {
+#pragma unroll
+                           for (int r = 0; r < 16; ++r) {
+                               const int f = 32 * t + feat_of(r, h);
+                               if (live && f < XD) vs_r[(int64_t)f * g.N + n] = P::exp_(a[r]);
+                           }
+                       });
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight pack: nn.Linear [rows][ld] fp32 -> fragment-major [k-step][row tile][lane][E] copy
+template <typename T>
+__global__ void mcem_pack_kernel(const float* __restrict__ src, int rows, int cols, int ld, T* __restrict__ dst, int nt, int ksteps) {
+    constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
+    const int64_t total = (int64_t)ksteps * nt * 64 * E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const int ln = (int)((i / E) % 64);
+        const int tile = (int)((i / (64 * E)) % nt);
+        const int ks = (int)(i / ((int64_t)64 * E * nt));
+        const int row = 32 * tile + (ln & 31), col = ks * KS + (ln >> 5) * E + e;
+        const float v = (row < rows && col < cols) ? src[(int64_t)row * ld + col] : 0.f;
+        dst[i] = (T)v;
+    }
+}
+
+__global__ void mcem_bias_kernel(const float* b3, const float* b4, const float* b5, float* dst) {
+    for (int i = threadIdx.x; i < 2 * HD + NO; i += blockDim.x)
+        dst[i] = i < HD ? b3[i] : (i < 2 * HD ? b4[i - HD] : (i - 2 * HD < XD ? b5[i - 2 * HD] : 0.f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// M-step (EM.M_step, mcem.py:91-153).  Vx[r] = g Vs[r] + Vb is never materialised.
+constexpr int KMAX = 16;
+
+// W update: one workgroup per frequency bin f: num[k] = sum_n X2 sum_r Vx^-2 H[k,n], den[k] = sum_n sum_r Vx^-1 H[k,n]
+__global__ __launch_bounds__(256) void mstep_w_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int K,
+                                                      const float* __restrict__ W, const float* __restrict__ H, const float* __restrict__ g,
+                                                      const float* __restrict__ Vb, float* __restrict__ Wun) {
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[4][2 * KMAX];
+    float num[KMAX], den[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { num[k] = 0.f; den[k] = 0.f; }
+    const int64_t FN = (int64_t)XD * N;
+    for (int64_t n = tid; n < N; n += 256) {
+        const float vb = Vb[(int64_t)f * N + n], gn = g[n], x2 = X2[(int64_t)f * N + n];
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float inv = 1.f / fmaf(gn, Vs[r * FN + (int64_t)f * N + n], vb);
+            a1 += inv; a2 += inv * inv;
+        }
+        const float p2 = x2 * a2;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) { const float hk = H[(int64_t)k * N + n]; num[k] = fmaf(p2, hk, num[k]); den[k] = fmaf(a1, hk, den[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const float a = wave_sum(num[k]), b = wave_sum(den[k]);
+        if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = b; }
+    }
+    __syncthreads();
+    if (tid < K) {
+        const float a = red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid];
+        const float b = red[0][2 * tid + 1] + red[1][2 * tid + 1] + red[2][2 * tid + 1] + red[3][2 * tid + 1];
+        Wun[f * K + tid] = W[f * K + tid] * sqrtf(a / b);                       // mcem.py:111
+    }
+}
+
+// H, g update, new Vb, cost: one workgroup per 32 frames (lane = frame, 8 bin groups per frame)
+__global__ __launch_bounds__(256) void mstep_frames_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int K,
+                                                           const float* __restrict__ Wun, float* __restrict__ H, float* __restrict__ g,
+                                                           float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K]
+    __shared__ float redk[8][2 * KMAX][32];
+    __shared__ float nrm[KMAX];
+    __shared__ double redc[4];
+    const int tid = threadIdx.x, fr = tid & 31, grp = tid >> 5, lane = tid & 63, wave = tid >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    const bool live = n0 + fr < N;
+    const int64_t n = live ? n0 + fr : N - 1;
+    const int64_t FN = (int64_t)XD * N;
+    for (int i = tid; i < XD * K; i += 256) lw[i] = Wun[i];
+    __syncthreads();
+    // column norms of the un-normalised W (mcem.py:130): recomputed by every workgroup (5 K values)
+    if (tid < K) {
+        float s = 0.f;
+        for (int f = 0; f < XD; ++f) s += fabsf(lw[f * K + tid]);
+        nrm[tid] = s;
+        if (blockIdx.x == 0) norms_out[tid] = s;
+    }
+    float hk[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) hk[k] = k < K ? H[(int64_t)k * N + n] : 0.f;
+    const float gn = g[n];
+
+    // ---- H update (mcem.py:118-123) with Vb = Wun H ----
+    float num[KMAX], den[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { num[k] = 0.f; den[k] = 0.f; }
+    for (int f = grp; f < XD; f += 8) {
+        float vb = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) vb = fmaf(lw[f * K + k], hk[k], vb);
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float inv = 1.f / fmaf(gn, Vs[r * FN + (int64_t)f * N + n], vb);
+            a1 += inv; a2 += inv * inv;
+        }
+        const float p2 = X2[(int64_t)f * N + n] * a2;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) { const float w = lw[f * K + k]; num[k] = fmaf(w, p2, num[k]); den[k] = fmaf(w, a1, den[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) if (k < K) { redk[grp][2 * k][fr] = num[k]; redk[grp][2 * k + 1][fr] = den[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            float a = 0.f, b = 0.f;
+            for (int q = 0; q < 8; ++q) { a += redk[q][2 * k][fr]; b += redk[q][2 * k + 1][fr]; }
+            hk[k] = hk[k] * sqrtf(a / b);
+        }
+    }
+    __syncthreads();
+
+    // ---- new Vb = Wun Hnew (mcem.py:126); g update (mcem.py:137-143) ----
+    float ng = 0.f, dg = 0.f;
+    for (int f = grp; f < XD; f += 8) {
+        float vb = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) vb = fmaf(lw[f * K + k], hk[k], vb);
+        if (live) Vb[(int64_t)f * N + n] = vb;
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float vs = Vs[r * FN + (int64_t)f * N + n];
+            const float inv = 1.f / fmaf(gn, vs, vb);
+            s1 = fmaf(vs, inv, s1); s2 = fmaf(vs, inv * inv, s2);
+        }
+        ng = fmaf(X2[(int64_t)f * N + n], s2, ng); dg += s1;
+    }
+    redk[grp][0][fr] = ng; redk[grp][1][fr] = dg;
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < 8; ++q) { a += redk[q][0][fr]; b += redk[q][1][fr]; }
+    const float gnew = gn * sqrtf(a / b);
+
+    // ---- cost (mcem.py:69-71) with the updated g; H is stored normalised (mcem.py:134) ----
+    double c = 0.0;
+    for (int f = grp; f < XD; f += 8) {
+        float vb = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) vb = fmaf(lw[f * K + k], hk[k], vb);
+        const float x2 = X2[(int64_t)f * N + n];
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float vx = fmaf(gnew, Vs[r * FN + (int64_t)f * N + n], vb);
+            s += logf(vx) + x2 / vx;
+        }
+        c += (double)s;
+    }
+    if (!live) c = 0.0;
+    c = wave_sum(c);
+    if (lane == 0) redc[wave] = c;
+    if (grp == 0 && live) {
+        g[n] = gnew;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < K) H[(int64_t)k * N + n] = hk[k] * nrm[k];
+    }
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = redc[0] + redc[1] + redc[2] + redc[3];
+}
+
+// W = Wun / norm (mcem.py:132), cost = mean over (R, F, N)
+__global__ __launch_bounds__(256) void mstep_finish_kernel(const float* __restrict__ Wun, const float* __restrict__ norms, int K, float* __restrict__ W,
+                                                           const double* __restrict__ partial, int nparts, double count, float* __restrict__ cost) {
+    for (int i = threadIdx.x; i < XD * K; i += 256) W[i] = Wun[i] / norms[i % K];
+    __shared__ double red[4];
+    double c = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) c += partial[i];
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && cost) cost[0] = (float)((red[0] + red[1] + red[2] + red[3]) / count);
+}
+
+// Wiener gains (compute_WF, mcem.py:321-327)
+__global__ __launch_bounds__(256) void wiener_kernel(const float* __restrict__ Vs, int R, int64_t FN, int64_t N, const float* __restrict__ g,
+                                                     const float* __restrict__ Vb, float* __restrict__ WFs, float* __restrict__ WFn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= FN) return;
+    const float gn = g[i % N], vb = Vb[i];
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float vs = gn * Vs[r * FN + i];
+        const float inv = 1.f / (vs + vb);
+        s = fmaf(vs, inv, s); q = fmaf(vb, inv, q);
+    }
+    WFs[i] = s / (float)R;
+    WFn[i] = q / (float)R;
+}
+
+struct McemLayout { int yp, ld3; int64_t oW3, oW4, oW5, elems, bias_off_bytes, total_bytes; };
+static McemLayout mcem_layout(int y_dim, int precision) {
+    McemLayout L;
+    const int esz = precision == DVAE_PREC_BF16 ? 2 : 4;
+    L.yp = y_dim == 0 ? 0 : (y_dim + 15) / 16 * 16;
+    L.ld3 = ZD + L.yp;
+    L.oW3 = 0;
+    L.oW4 = L.oW3 + (int64_t)HD * L.ld3;
+    L.oW5 = L.oW4 + (int64_t)HD * HD;
+    L.elems = L.oW5 + (int64_t)NO * HD;
+    L.bias_off_bytes = (L.elems * esz + 255) / 256 * 256;
+    L.total_bytes = L.bias_off_bytes + (2 * HD + NO) * (int64_t)sizeof(float) + 256;
+    return L;
+}
+
+template <typename P, int YP>
+static int launch_mh(const MhArgs& a, hipStream_t s) {
+    const size_t lds = MhLds<typename P::T>::bytes(YP);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)mcem_mh_kernel<P, YP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(mcem_mh_kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mcem_mh_kernel<P, YP>), dim3(a.ntiles), dim3(256), lds, s, a);
+    DVAE_LAUNCH_OK("mcem_mh_kernel");
+    return 0;
+}
+
+static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hipStream_t s) {
+    const McemLayout L = mcem_layout(plan->y_dim, plan->precision);
+    a.ydim = plan->y_dim;
+    a.ntiles = (int)((a.N + TB - 1) / TB);
+    a.wcopy = wcopy; a.wcopy_bytes = L.bias_off_bytes;
+    a.oW3 = L.oW3; a.oW4 = L.oW4; a.oW5 = L.oW5;
+    a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
+    const bool bf = plan->precision == DVAE_PREC_BF16;
+    if (L.yp == 0) return bf ? launch_mh<PolBF16, 0>(a, s) : launch_mh<PolF32, 0>(a, s);
+    if (L.yp == 16) return bf ? launch_mh<PolBF16, 16>(a, s) : launch_mh<PolF32, 16>(a, s);
+    if (L.yp == 528) return bf ? launch_mh<PolBF16, 528>(a, s) : launch_mh<PolF32, 528>(a, s);
+    set_error("mcem: y_dim %d not supported (0, 1..16, 513)", plan->y_dim);
+    return DVAE_E_BADARG;
+}
+
+}  // namespace fused
+}  // namespace dvae
+
+using namespace dvae;
+using namespace dvae::fused;
+
+extern "C" int dvae_mcem_plan(int y_dim, int precision, dvae_mcem_plan_t* plan) {
+    DVAE_CHECK_ARG(plan != nullptr, "mcem_plan: null plan");
+    DVAE_CHECK_ARG(y_dim == 0 || (y_dim >= 1 && y_dim <= 16) || y_dim == XD, "mcem_plan: y_dim %d not supported (0, 1..16, 513)", y_dim);
+    DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16, "mcem_plan: bad precision %d", precision);
+    const McemLayout L = mcem_layout(y_dim, precision);
+    memset(plan, 0, sizeof(*plan));
+    plan->y_dim = y_dim; plan->precision = precision; plan->x_dim = XD; plan->z_dim = ZD; plan->h_dim = HD;
+    plan->weights_bytes = L.total_bytes;
+    return 0;
+}
+
+extern "C" int dvae_mcem_pack(const dvae_mcem_plan_t* plan, const float* W3, int ld3, const float* b3, const float* W4, int ld4,
+                              const float* b4, const float* W5, int ld5, const float* b5, void* weights, void* stream) {
+    DVAE_CHECK_ARG(plan && W3 && b3 && W4 && b4 && W5 && b5 && weights, "mcem_pack: null argument");
+    DVAE_CHECK_ARG(ld3 >= ZD + plan->y_dim && ld4 >= HD && ld5 >= HD, "mcem_pack: row strides too small");
+    const McemLayout L = mcem_layout(plan->y_dim, plan->precision);
+    hipStream_t s = (hipStream_t)stream;
+    if (plan->precision == DVAE_PREC_BF16) {
+        __bf16* w = (__bf16*)weights;
+        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, s, W3, HD, ZD + plan->y_dim, ld3, w + L.oW3, 4, L.ld3 / 16);
+        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, s, W4, HD, HD, ld4, w + L.oW4, 4, HD / 16);
+        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(128), dim3(256), 0, s, W5, XD, HD, ld5, w + L.oW5, NT_OUT, HD / 16);
+    } else {
+        float* w = (float*)weights;
+        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(64), dim3(256), 0, s, W3, HD, ZD + plan->y_dim, ld3, w + L.oW3, 4, L.ld3 / 8);
+        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(64), dim3(256), 0, s, W4, HD, HD, ld4, w + L.oW4, 4, HD / 8);
+        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(128), dim3(256), 0, s, W5, XD, HD, ld5, w + L.oW5, NT_OUT, HD / 8);
+    }
+    hipLaunchKernelGGL(mcem_bias_kernel, dim3(1), dim3(256), 0, s, b3, b4, b5, (float*)((char*)weights + L.bias_off_bytes));
+    DVAE_LAUNCH_OK("mcem_pack");
+    return 0;
+}
+
+extern "C" int dvae_mcem_sample(const dvae_mcem_plan_t* plan, const void* weights, const float* Z0, const float* y, const float* g,
+                                const float* Vb, const float* X2, const float* noise, const float* logu, int nit, int burnin,
+                                float var_rw, int64_t N, float* Zs, float* Vs, float* acc_logratio, unsigned char* accepted, void* stream) {
+    DVAE_CHECK_ARG(plan && weights && Z0 && g && Vb && X2 && noise && logu && Zs, "mcem_sample: null argument");
+    DVAE_CHECK_ARG((plan->y_dim == 0) == (y == nullptr), "mcem_sample: y must be given exactly when the plan has y_dim > 0");
+    DVAE_CHECK_ARG(N > 0 && nit > 0 && burnin >= 0 && burnin < nit, "mcem_sample: need N > 0 and 0 <= burnin < nit (N=%lld nit=%d burnin=%d)", (long long)N, nit, burnin);
+    DVAE_CHECK_ARG(var_rw >= 0.f, "mcem_sample: negative random-walk variance");
+    MhArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Z0 = Z0; a.y = y; a.g = g; a.Vb = Vb; a.X2 = X2; a.noise = noise; a.logu = logu; a.Zs = Zs; a.Vs = Vs; a.accp = acc_logratio; a.accd = accepted;
+    a.nit = nit; a.burnin = burnin; a.R = nit - burnin; a.N = N; a.sd = sqrtf(var_rw);
+    return run_mh(plan, weights, a, (hipStream_t)stream);
+}
+
+extern "C" int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weights, const float* Zs, const float* y, int R, int64_t N,
+                                float* Vs, void* stream) {
+    DVAE_CHECK_ARG(plan && weights && Zs && Vs, "mcem_decode: null argument");
+    DVAE_CHECK_ARG((plan->y_dim == 0) == (y == nullptr), "mcem_decode: y must be given exactly when the plan has y_dim > 0");
+    DVAE_CHECK_ARG(N > 0 && R > 0, "mcem_decode: need N > 0 and R > 0");
+    MhArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y = y; a.Zs = const_cast<float*>(Zs); a.Vs = Vs; a.nit = 0; a.burnin = 0; a.R = R; a.N = N;
+    return run_mh(plan, weights, a, (hipStream_t)stream);
+}
+
+extern "C" size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K) {
+    return (size_t)(XD * K * sizeof(float) + 256 + KMAX * sizeof(float) + 256 + ((N + 31) / 32) * sizeof(double) + 256);
+}
+
+extern "C" int dvae_mcem_m_step(const float* X2, const float* Vs, int R, int64_t N, int K, float* W, float* H, float* g, float* Vb,
+                                float* cost, void* workspace, void* stream) {
+    DVAE_CHECK_ARG(X2 && Vs && W && H && g && Vb && workspace, "mcem_m_step: null argument");
+    DVAE_CHECK_ARG(R > 0 && N > 0 && K > 0 && K <= KMAX, "mcem_m_step: need R > 0, N > 0, 0 < K <= %d", KMAX);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* Wun = (float*)ws;
+    float* norms = (float*)(ws + (XD * K * sizeof(float) + 255) / 256 * 256);
+    double* partial = (double*)((char*)norms + 256);
+    const int nparts = (int)((N + 31) / 32);
+    hipLaunchKernelGGL(mstep_w_kernel, dim3(XD), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun);
+    DVAE_LAUNCH_OK("mstep_w_kernel");
+    hipLaunchKernelGGL(mstep_frames_kernel, dim3(nparts), dim3(256), (size_t)XD * K * sizeof(float), s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial);
+    DVAE_LAUNCH_OK("mstep_frames_kernel");
+    hipLaunchKernelGGL(mstep_finish_kernel, dim3(1), dim3(256), 0, s, Wun, norms, K, W, partial, nparts, (double)R * XD * (double)N, cost);
+    DVAE_LAUNCH_OK("mstep_finish_kernel");
+    return 0;
+}
+
+extern "C" int dvae_mcem_wiener(const float* Vs, int R, int64_t N, const float* g, const float* Vb, float* WFs, float* WFn, void* stream) {
+    DVAE_CHECK_ARG(Vs && g && Vb && WFs && WFn, "mcem_wiener: null argument");
+    DVAE_CHECK_ARG(R > 0 && N > 0, "mcem_wiener: need R > 0 and N > 0");
+    const int64_t FN = (int64_t)XD * N;
+    hipLaunchKernelGGL(wiener_kernel, dim3((unsigned)((FN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Vs, R, FN, N, g, Vb, WFs, WFn);
+    DVAE_LAUNCH_OK("wiener_kernel");
+    return 0;
+}

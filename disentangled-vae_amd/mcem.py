@@ -1,0 +1,117 @@
+"""Device side of the MCEM enhancement loop: thin Python over the C ABI of include/dvae_mcem.h.
+
+`DecoderPack` holds the kernel-layout copy of a VAE decoder; the free functions mirror the steps of the
+reference's packages/models/mcem.py (sample_posterior, compute_Vs, M_step, compute_WF) on CUDA
+tensors in the reference's own shapes.  No fallback: errors from the library raise.
+"""
+import ctypes
+
+import torch
+
+from . import native as N
+
+F_BINS, Z_DIM, H_DIM = 513, 16, 128
+PREC = {"fp32": 0, "bf16": 1}
+
+
+class McemPlan(ctypes.Structure):
+    _fields_ = [("y_dim", ctypes.c_int32), ("precision", ctypes.c_int32), ("x_dim", ctypes.c_int32),
+                ("z_dim", ctypes.c_int32), ("h_dim", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("weights_bytes", ctypes.c_int64)]
+
+
+def _f32c(t, what):
+    if t is None:
+        raise RuntimeError(f"{what}: required (got None)")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected a CUDA tensor")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: the HIP path computes in float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def decoder_supported(decoder, y_dim):
+    """The kernels cover the geometry the reference's scripts use (decoder [16+y]-128-128-513)."""
+    hs = list(decoder.hidden)
+    return (len(hs) == 2 and hs[0].out_features == H_DIM and hs[1].in_features == H_DIM and hs[1].out_features == H_DIM
+            and hs[0].in_features == Z_DIM + y_dim and decoder.reconstruction.out_features == F_BINS
+            and (y_dim == 0 or 1 <= y_dim <= 16 or y_dim == F_BINS))
+
+
+class DecoderPack:
+    """Kernel-layout copy of `vae.decoder` (packages/models/models.py:108-122) for the MCEM kernels."""
+
+    def __init__(self, decoder, y_dim, precision="fp32"):
+        self.lib = N.load()
+        if not decoder_supported(decoder, y_dim):
+            raise RuntimeError("MCEM kernels: decoder geometry not supported (need [16+y_dim]-128-128-513, y_dim 0/1..16/513)")
+        self.y_dim = y_dim
+        self.plan = McemPlan()
+        N.check(self.lib.dvae_mcem_plan(y_dim, PREC[precision], ctypes.byref(self.plan)), "dvae_mcem_plan")
+        dev = decoder.reconstruction.weight.device
+        self.weights = torch.empty(self.plan.weights_bytes, dtype=torch.uint8, device=dev)
+        self.repack(decoder)
+
+    def repack(self, decoder):
+        l3, l4, l5 = decoder.hidden[0], decoder.hidden[1], decoder.reconstruction
+        t = [_f32c(x.detach(), "decoder parameter") for x in (l3.weight, l3.bias, l4.weight, l4.bias, l5.weight, l5.bias)]
+        N.check(self.lib.dvae_mcem_pack(ctypes.byref(self.plan), N.ptr(t[0]), t[0].stride(0), N.ptr(t[1]), N.ptr(t[2]), t[2].stride(0),
+                                        N.ptr(t[3]), N.ptr(t[4]), t[4].stride(0), N.ptr(t[5]), N.ptr(self.weights), N.stream()),
+                "dvae_mcem_pack")
+        self._keep = t
+
+    # sample_posterior (mcem.py:207-277, 372-448) [+ compute_Vs of the kept samples when want_vs]
+    def sample(self, Z, y, g, Vb, X2, noise, logu, burnin, var_rw=0.01, want_vs=True, trace=False):
+        nit, L, n = noise.shape
+        assert L == Z_DIM and Z.shape == (Z_DIM, n) and logu.shape == (nit, n) and Vb.shape == (F_BINS, n) and X2.shape == (F_BINS, n)
+        R = nit - burnin
+        Z, g, Vb, X2, noise, logu = (_f32c(a, nm) for a, nm in ((Z, "Z"), (g, "g"), (Vb, "Vb"), (X2, "X2"), (noise, "noise"), (logu, "logu")))
+        y = _f32c(y, "y") if self.y_dim else None
+        if y is not None:
+            assert y.shape == (self.y_dim, n), (tuple(y.shape), self.y_dim, n)
+        Zs = torch.empty((n, R, Z_DIM), dtype=torch.float32, device=Z.device)
+        Vs = torch.empty((R, F_BINS, n), dtype=torch.float32, device=Z.device) if want_vs else None
+        accp = torch.empty((nit, n), dtype=torch.float32, device=Z.device) if trace else None
+        accd = torch.empty((nit, n), dtype=torch.uint8, device=Z.device) if trace else None
+        N.check(self.lib.dvae_mcem_sample(ctypes.byref(self.plan), N.ptr(self.weights), N.ptr(Z), N.ptr(y), N.ptr(g), N.ptr(Vb), N.ptr(X2),
+                                          N.ptr(noise), N.ptr(logu), nit, burnin, float(var_rw), n, N.ptr(Zs), N.ptr(Vs), N.ptr(accp),
+                                          N.ptr(accd), N.stream()), "dvae_mcem_sample")
+        return (Zs, Vs, accp, accd) if trace else (Zs, Vs)
+
+    # compute_Vs (mcem.py:280-290): Zs (N, R, 16) -> (R, F, N)
+    def decode(self, Zs, y):
+        n, R, L = Zs.shape
+        assert L == Z_DIM
+        Zs = _f32c(Zs, "Zs")
+        y = _f32c(y, "y") if self.y_dim else None
+        Vs = torch.empty((R, F_BINS, n), dtype=torch.float32, device=Zs.device)
+        N.check(self.lib.dvae_mcem_decode(ctypes.byref(self.plan), N.ptr(self.weights), N.ptr(Zs), N.ptr(y), R, n, N.ptr(Vs), N.stream()),
+                "dvae_mcem_decode")
+        return Vs
+
+
+def m_step_(X2, Vs, W, H, g, Vb, want_cost=True):
+    """EM.M_step (mcem.py:91-153), in place on W (F,K), H (K,N), g (N), Vb (F,N); returns the cost (1-element tensor)."""
+    lib = N.load()
+    R, F, n = Vs.shape
+    K = W.shape[1]
+    assert F == F_BINS and W.shape == (F, K) and H.shape == (K, n) and g.shape == (n,) and Vb.shape == (F, n) and X2.shape == (F, n)
+    for a, nm in ((X2, "X2"), (Vs, "Vs"), (W, "W"), (H, "H"), (g, "g"), (Vb, "Vb")):
+        if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
+            raise RuntimeError(f"m_step_: {nm} must be a contiguous float32 CUDA tensor")
+    ws = torch.empty(lib.dvae_mcem_m_step_workspace_bytes(n, K), dtype=torch.uint8, device=W.device)
+    cost = torch.empty(1, dtype=torch.float32, device=W.device) if want_cost else None
+    N.check(lib.dvae_mcem_m_step(N.ptr(X2), N.ptr(Vs), R, n, K, N.ptr(W), N.ptr(H), N.ptr(g), N.ptr(Vb), N.ptr(cost), N.ptr(ws), N.stream()),
+            "dvae_mcem_m_step")
+    return cost
+
+
+def wiener(Vs, g, Vb):
+    """compute_WF (mcem.py:321-327) -> WFs, WFn (F, N)."""
+    lib = N.load()
+    R, F, n = Vs.shape
+    Vs, g, Vb = _f32c(Vs, "Vs"), _f32c(g, "g"), _f32c(Vb, "Vb")
+    WFs = torch.empty((F, n), dtype=torch.float32, device=Vs.device)
+    WFn = torch.empty_like(WFs)
+    N.check(lib.dvae_mcem_wiener(N.ptr(Vs), R, n, N.ptr(g), N.ptr(Vb), N.ptr(WFs), N.ptr(WFn), N.stream()), "dvae_mcem_wiener")
+    return WFs, WFn

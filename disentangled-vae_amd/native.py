@@ -21,7 +21,7 @@ _lib = None
 c_vp, c_i, c_i64, c_f, c_d, c_sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                                     ctypes.c_double, ctypes.c_size_t)
 
-# name -> (restype, argtypes); mirrors include/dvae.h and include/dvae_train.h
+# name -> (restype, argtypes); mirrors include/dvae.h, include/dvae_train.h and include/dvae_mcem.h
 SIGNATURES = {
     "dvae_abi_version": (c_i, []),
     "dvae_last_error": (ctypes.c_char_p, []),
@@ -52,6 +52,14 @@ SIGNATURES = {
     "dvae_train_profile": (c_i, [c_i]),
     "dvae_train_debug_stamps": (c_i, [c_vp]),
     "dvae_train_profile_read": (c_i, [c_vp, c_vp]),
+    # include/dvae_mcem.h
+    "dvae_mcem_plan": (c_i, [c_i, c_i, c_vp]),
+    "dvae_mcem_pack": (c_i, [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp]),
+    "dvae_mcem_sample": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dvae_mcem_decode": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i64, c_vp, c_vp]),
+    "dvae_mcem_m_step_workspace_bytes": (c_sz, [c_i64, c_i]),
+    "dvae_mcem_m_step": (c_i, [c_vp, c_vp, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dvae_mcem_wiener": (c_i, [c_vp, c_i, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 

@@ -1,0 +1,67 @@
+/* dvae_mcem.h -- C ABI of the MCEM speech-enhancement loop (libdvae_hip.so).
+ *
+ * Reference: packages/models/mcem.py (classes EM, MCEM_M1, MCEM_M2, MCEM_M2v2, MCEM_M2v3), driven by
+ * scripts/evaluate_ntcd_M1.py / _M2.py / _M2_info_vad.py (`mcem.init_parameters(...)`, `mcem.run()`).
+ * For the geometry those scripts use (F = 513 bins, latent 16, decoder 128-128-513, y_dim 0 / 1 / 513).
+ *
+ * Array shapes are the reference's own (row-major, fp32): X2, Vb, WFs, WFn (F, N); Vs (R, F, N);
+ * Z (16, N); y (y_dim, N); g (N); W (F, K); H (K, N); sampled latents (N, R, 16).
+ * All pointers are caller-owned device memory; calls enqueue on `stream` and do not synchronise.
+ * Every random number is an argument: the caller draws `noise` and `logu` (the reference draws them with
+ * torch.randn / torch.rand inside the loop, mcem.py:244,257).
+ */
+#ifndef DVAE_MCEM_H
+#define DVAE_MCEM_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "dvae_train.h"      /* DVAE_PREC_* */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t y_dim;            /* label rows fed to the decoder next to z: 0 (MCEM_M1), 1..16 or 513 */
+    int32_t precision;        /* DVAE_PREC_F32 (parity mode) or DVAE_PREC_BF16 (matrix-core operands in bf16) */
+    int32_t x_dim, z_dim, h_dim;   /* echoed: 513, 16, 128 */
+    int32_t reserved;
+    int64_t weights_bytes;    /* size of the kernel-layout decoder copy filled by dvae_mcem_pack */
+} dvae_mcem_plan_t;
+
+int dvae_mcem_plan(int y_dim, int precision, dvae_mcem_plan_t* plan);
+
+/* Kernel-layout copy of the decoder (vae.decoder: hidden.0 [128][16+y_dim], hidden.1 [128][128], reconstruction
+ * [513][128], nn.Linear layouts with row strides ld*; packages/models/models.py:108-122).  Call again after the
+ * weights change. */
+int dvae_mcem_pack(const dvae_mcem_plan_t* plan, const float* W3, int ld3, const float* b3, const float* W4, int ld4,
+                   const float* b4, const float* W5, int ld5, const float* b5, void* weights, void* stream);
+
+/* sample_posterior (mcem.py:207-277, 372-448): `nit` = nsamples + burnin Metropolis-Hastings iterations of the
+ * random walk Z' = Z + sqrt(var_rw) * noise[m], accepted where logu[m] < log acceptance ratio.
+ *   noise (nit, 16, N), logu (nit, N): the draws; Z0 (16, N) start; y (y_dim, N) or NULL when y_dim == 0.
+ *   Zs (N, nit - burnin, 16): the kept samples (the reference's Z_sampled_t).
+ *   Vs (nit - burnin, F, N) or NULL: decoder variances of the kept samples (compute_Vs, mcem.py:280-290).
+ *   acc_logratio (nit, N), accepted (nit, N) bytes: optional diagnostics (NULL to skip). */
+int dvae_mcem_sample(const dvae_mcem_plan_t* plan, const void* weights, const float* Z0, const float* y, const float* g,
+                     const float* Vb, const float* X2, const float* noise, const float* logu, int nit, int burnin,
+                     float var_rw, int64_t N, float* Zs, float* Vs, float* acc_logratio, unsigned char* accepted, void* stream);
+
+/* compute_Vs alone (mcem.py:280-290, 451-461): Vs (R, F, N) = decoder([Zs[:, r, :] | y]). */
+int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weights, const float* Zs, const float* y, int R, int64_t N,
+                     float* Vs, void* stream);
+
+/* EM.M_step (mcem.py:91-153) + compute_expected_neg_log_like (mcem.py:69-71).  In place: W, H (stored normalised),
+ * g, and Vb (the product of the un-normalised factors, which is what the reference keeps for the next E-step).
+ * cost: 1 float or NULL.  K <= 16. */
+size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K);
+int dvae_mcem_m_step(const float* X2, const float* Vs, int R, int64_t N, int K, float* W, float* H, float* g, float* Vb,
+                     float* cost, void* workspace, void* stream);
+
+/* compute_WF (mcem.py:321-327): WFs = mean_r(g Vs / Vx), WFn = mean_r(Vb / Vx), both (F, N). */
+int dvae_mcem_wiener(const float* Vs, int R, int64_t N, const float* g, const float* Vb, float* WFs, float* WFn, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

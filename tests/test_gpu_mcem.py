@@ -1,0 +1,165 @@
+"""MCEM kernels (include/dvae_mcem.h) against the numpy oracle on the same draws, and against the golden
+vectors captured from the reference's own packages/models/mcem.py."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import mcem_cases as mc
+from impl_modules import build_model
+from oracle import mcem_oracle as mo
+
+pytestmark = pytest.mark.gpu
+mcem_dev = importlib.import_module("disentangled-vae_amd.mcem")
+
+FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "mcem_golden.npz"))
+
+
+def case_fix(name):
+    return {k.split("/", 1)[1]: FIX[k] for k in FIX.files if k.startswith(name + "/")}
+
+
+def t(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def setup(model, y_dim, N, seed, wscale=1.0, precision="fp32"):
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, seed, wscale)
+    m = build_model(model, dims)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    m.cuda()
+    vae = m.enc_dec_clf if model == "M2_info" else m
+    pack = mcem_dev.DecoderPack(vae.decoder, y_dim, precision)
+    prefix = "enc_dec_clf.decoder." if model == "M2_info" else "decoder."
+    rng = np.random.default_rng(seed + 77)
+    X2 = (rng.standard_normal((513, N)) ** 2 * np.exp(rng.standard_normal((513, 1)) - 1)).astype(np.float32) + 1e-4
+    y = (rng.random((y_dim, N)) > 0.5).astype(np.float32) if y_dim else None
+    Z = rng.standard_normal((16, N)).astype(np.float32)
+    g = np.exp(0.2 * rng.standard_normal(N)).astype(np.float32)
+    W = np.maximum(rng.random((513, 10)), 1e-6).astype(np.float32)
+    H = np.maximum(rng.random((10, N)), 1e-6).astype(np.float32)
+    return params, prefix, pack, X2, y, Z, g, W, H, rng
+
+
+def chains_agree(accd, trace_a):
+    """per frame: index of the first iteration whose accept decision differs (nit if none)."""
+    diff = accd != trace_a
+    first = np.where(diff.any(axis=0), diff.argmax(axis=0), diff.shape[0])
+    return first
+
+
+@pytest.mark.parametrize("model,y_dim,N", [("M1", 0, 45), ("M2", 1, 70), ("M2", 513, 33), ("M2_info", 1, 100)])
+def test_sample_posterior_matches_oracle(model, y_dim, N):
+    params, prefix, pack, X2, y, Z, g, W, H, rng = setup(model, y_dim, N, 5)
+    nit, burnin = 12, 5
+    noise = rng.standard_normal((nit, 16, N)).astype(np.float32)
+    logu = np.log(rng.random((nit, N)).astype(np.float32))
+    Vb = (W @ H).astype(np.float32)
+    Zs_o, tp, ta = mo.sample_posterior(params, prefix, Z, y, g, Vb, X2, noise, logu, burnin, return_trace=True)
+    Zs, Vs, accp, accd = pack.sample(t(Z), t(y), t(g), t(Vb), t(X2), t(noise), t(logu), burnin, trace=True)
+    Zs, Vs, accp, accd = Zs.cpu().numpy(), Vs.cpu().numpy(), accp.cpu().numpy(), accd.cpu().numpy().astype(bool)
+    first = chains_agree(accd, ta)
+    # log acceptance ratios agree as long as the two chains are in the same state (sums of 513 terms of size ~5:
+    # the reference's own float32 summation noise is ~1e-4 absolute)
+    for n in range(N):
+        k = min(first[n] + 1, nit)
+        np.testing.assert_allclose(accp[:k, n], tp[:k, n], rtol=2e-4, atol=2e-3)
+    same = first == nit
+    assert same.mean() >= 0.97, same.mean()
+    np.testing.assert_allclose(Zs[same], Zs_o[same], rtol=1e-5, atol=1e-6)
+    assert 0.02 < accd.mean() < 0.98            # the chain actually moves and actually rejects
+    # variances of the kept samples (compute_Vs) in the same launch
+    Vs_o = mo.compute_vs(params, prefix, Zs, y)
+    np.testing.assert_allclose(Vs, Vs_o, rtol=1e-4, atol=1e-9)
+    # and alone
+    Vs2 = pack.decode(t(Zs), t(y)).cpu().numpy()
+    np.testing.assert_array_equal(Vs2, Vs)
+
+
+@pytest.mark.parametrize("N,R,K", [(45, 3, 10), (300, 10, 10), (32, 1, 4), (1, 2, 16)])
+def test_m_step_and_wiener_match_oracle(N, R, K):
+    rng = np.random.default_rng(N + R)
+    X2 = (rng.standard_normal((513, N)) ** 2).astype(np.float32) + 1e-4
+    Vs = np.exp(rng.standard_normal((R, 513, N)) - 0.5).astype(np.float32)
+    W = np.maximum(rng.random((513, K)), 1e-6).astype(np.float32)
+    H = np.maximum(rng.random((K, N)), 1e-6).astype(np.float32)
+    g = np.exp(0.3 * rng.standard_normal(N)).astype(np.float32)
+    Vb = (W @ H).astype(np.float32)
+    Wo, Ho, go, Vbo, Vxo, cost_o = mo.m_step(X2, Vs, W, H, g, Vb, dtype=np.float64)
+    dW, dH, dg, dVb = t(W), t(H), t(g), t(Vb)
+    cost = mcem_dev.m_step_(t(X2), t(Vs), dW, dH, dg, dVb)
+    np.testing.assert_allclose(dW.cpu().numpy(), Wo, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(dH.cpu().numpy(), Ho, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(dg.cpu().numpy(), go, rtol=1e-4)
+    np.testing.assert_allclose(dVb.cpu().numpy(), Vbo, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(cost.item(), cost_o, rtol=1e-5)
+    WFs_o, WFn_o = mo.wiener(Vs.astype(np.float64), go, Vbo)
+    WFs, WFn = mcem_dev.wiener(t(Vs), dg, dVb)
+    np.testing.assert_allclose(WFs.cpu().numpy(), WFs_o, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(WFn.cpu().numpy(), WFn_o, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose((WFs + WFn).cpu().numpy(), 1.0, rtol=1e-5)        # the two gains partition the mixture
+
+
+@pytest.mark.parametrize("case", mc.CASES, ids=[c["name"] for c in mc.CASES])
+def test_full_run_matches_reference_golden(case):
+    """EM.run on the draws recorded from the reference: state after every iteration vs the reference's."""
+    fix = case_fix(case["name"])
+    dims = mc.DIMS[case["model"]]
+    params, prefix, pack, *_ = setup(case["model"], dims["y_dim"], case["N"], case["seed"], case["wscale"])
+    X, S, y = mc.make_utterance(case)
+    X2 = t((np.abs(X) ** 2).astype(np.float32))
+    yd = t(y) if case["model"] != "M1" else None
+    W, H, g = mo.init_nmf(fix["rand_W"], fix["rand_H"], mc.EPS)
+    W, H, g = t(W), t(H), t(g)
+    Vb = (W @ H).contiguous()
+    Z = t(fix["Z0"])
+    n_e, b_e, n_wf, b_wf = mc.effective_counts(case)
+    for it in range(case["niter"]):
+        Zs, Vs = pack.sample(Z, yd, g, Vb, X2, t(fix[f"noise{it}"]), t(fix[f"logu{it}"]), b_e)
+        Z = Zs[:, -1, :].t().contiguous()
+        cost = mcem_dev.m_step_(X2, Vs, W, H, g, Vb)
+        dz = np.abs(Z.cpu().numpy() - fix["Z"][it]).max(axis=0)
+        assert (dz > 1e-3).mean() <= 0.03, (it, dz.max())
+        ok = dz <= 1e-3
+        np.testing.assert_allclose(g.cpu().numpy()[ok], fix["g"][it][ok], rtol=2e-3)
+        np.testing.assert_allclose(H.cpu().numpy()[:, ok], fix["H"][it][:, ok], rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(W.cpu().numpy(), fix["W"][it], rtol=5e-3, atol=1e-6)
+        np.testing.assert_allclose(cost.item(), fix["cost"][it], rtol=1e-3)
+    it = case["niter"]
+    Zs, Vs = pack.sample(Z, yd, g, Vb, X2, t(fix[f"noise{it}"]), t(fix[f"logu{it}"]), b_wf)
+    WFs, WFn = mcem_dev.wiener(Vs, g, Vb)
+    assert (np.abs(WFs.cpu().numpy() - fix["WFs"]) > 5e-3).mean() < 0.05
+    assert (np.abs(WFn.cpu().numpy() - fix["WFn"]) > 5e-3).mean() < 0.05
+
+
+def test_bf16_chain_is_statistically_close():
+    """Throughput mode (bf16 matrix-core operands): first-iteration log ratios within bf16 noise of the oracle,
+    same acceptance rate to a few percent."""
+    params, prefix, pack, X2, y, Z, g, W, H, rng = setup("M2", 1, 256, 9, precision="bf16")
+    nit, burnin = 20, 10
+    noise = rng.standard_normal((nit, 16, 256)).astype(np.float32)
+    logu = np.log(rng.random((nit, 256)).astype(np.float32))
+    Vb = (W @ H).astype(np.float32)
+    _, tp, ta = mo.sample_posterior(params, prefix, Z, y, g, Vb, X2, noise, logu, burnin, return_trace=True)
+    Zs, Vs, accp, accd = pack.sample(t(Z), t(y), t(g), t(Vb), t(X2), t(noise), t(logu), burnin, trace=True)
+    accp, accd = accp.cpu().numpy(), accd.cpu().numpy().astype(bool)
+    err = np.abs(accp[0] - tp[0])
+    assert np.median(err) < 0.15 and err.max() < 2.0, (np.median(err), err.max())
+    assert abs(accd.mean() - ta.mean()) < 0.05
+    assert torch.isfinite(Vs).all()
+
+
+def test_bad_arguments_fail_loudly():
+    params, prefix, pack, X2, y, Z, g, W, H, rng = setup("M2", 1, 8, 3)
+    noise = torch.zeros((4, 16, 8), device="cuda"); logu = torch.zeros((4, 8), device="cuda")
+    with pytest.raises(RuntimeError):
+        pack.sample(t(Z), None, t(g), t(W @ H), t(X2), noise, logu, 1)        # y missing although y_dim == 1
+    with pytest.raises(RuntimeError):
+        pack.sample(t(Z), t(y), t(g), t(W @ H), t(X2), noise, logu, 4)        # burnin == nit: nothing kept
+    with pytest.raises(RuntimeError):
+        mcem_dev.m_step_(t(X2), torch.ones((2, 513, 8), device="cuda"), torch.ones((513, 17), device="cuda"),
+                         torch.ones((17, 8), device="cuda"), t(g), t((W @ H)))   # K > 16
