@@ -28,3 +28,7 @@ def native():
 
 def stft_host():
     return importlib.import_module("disentangled-vae_amd.stft")
+
+
+def mcem_dev():
+    return importlib.import_module("disentangled-vae_amd.mcem")
