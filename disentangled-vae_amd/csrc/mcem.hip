@@ -279,19 +279,26 @@ __global__ void mcem_bias_kernel(const float* b3, const float* b4, const float* 
 
 // ---------------------------------------------------------------------------------------------
 // M-step (EM.M_step, mcem.py:91-153).  Vx[r] = g Vs[r] + Vb is never materialised.
+// Batched form: the frame axis holds U utterances ("segments"), each starting on a multiple of 32 frames
+// (seg_start) with seg_count valid frames; W, Wun, norms and cost carry a leading U axis.  Null tables = one
+// utterance covering all N frames.
 constexpr int KMAX = 16;
+constexpr int FT = 1024;          // threads of the frames kernel: 32 frames x 32 bin groups
 
-// W update: one workgroup per frequency bin f: num[k] = sum_n X2 sum_r Vx^-2 H[k,n], den[k] = sum_n sum_r Vx^-1 H[k,n]
+// W update: one workgroup per (frequency bin f, utterance u):
+//   num[k] = sum_n X2 sum_r Vx^-2 H[k,n],  den[k] = sum_n sum_r Vx^-1 H[k,n],  Wun = W sqrt(num / den)   (mcem.py:107-111)
 __global__ __launch_bounds__(256) void mstep_w_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int K,
                                                       const float* __restrict__ W, const float* __restrict__ H, const float* __restrict__ g,
-                                                      const float* __restrict__ Vb, float* __restrict__ Wun) {
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                      const float* __restrict__ Vb, float* __restrict__ Wun,
+                                                      const int* __restrict__ seg_start, const int* __restrict__ seg_count) {
+    const int f = blockIdx.x, u = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nbeg = seg_start ? seg_start[u] : 0, nend = nbeg + (seg_count ? seg_count[u] : N);
     __shared__ float red[4][2 * KMAX];
     float num[KMAX], den[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { num[k] = 0.f; den[k] = 0.f; }
     const int64_t FN = (int64_t)XD * N;
-    for (int64_t n = tid; n < N; n += 256) {
+    for (int64_t n = nbeg + tid; n < nend; n += 256) {
         const float vb = Vb[(int64_t)f * N + n], gn = g[n], x2 = X2[(int64_t)f * N + n];
         float a1 = 0.f, a2 = 0.f;
         for (int r = 0; r < R; ++r) {
@@ -313,42 +320,72 @@ __global__ __launch_bounds__(256) void mstep_w_kernel(const float* __restrict__ 
     if (tid < K) {
         const float a = red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid];
         const float b = red[0][2 * tid + 1] + red[1][2 * tid + 1] + red[2][2 * tid + 1] + red[3][2 * tid + 1];
-        Wun[f * K + tid] = W[f * K + tid] * sqrtf(a / b);                       // mcem.py:111
+        const int64_t o = ((int64_t)u * XD + f) * K + tid;
+        Wun[o] = W[o] * sqrtf(a / b);
     }
 }
 
-// H, g update, new Vb, cost: one workgroup per 32 frames (lane = frame, 8 bin groups per frame)
-__global__ __launch_bounds__(256) void mstep_frames_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int K,
-                                                           const float* __restrict__ Wun, float* __restrict__ H, float* __restrict__ g,
-                                                           float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K]
-    __shared__ float redk[8][2 * KMAX][32];
+// H update, new Vb, g update, cost: one 1024-thread workgroup per 32 frames (lane & 31 = frame, 32 bin groups).
+// Everything after the W update is local to a frame, so the three passes over Vs share one launch.
+__global__ __launch_bounds__(FT) void mstep_frames_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int K,
+                                                          const float* __restrict__ Wun_all, float* __restrict__ H, float* __restrict__ g,
+                                                          float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial,
+                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_count,
+                                                          const int* __restrict__ tile_seg) {
+    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [16][2K][32], then sums [2K][32]
+    float* wpart = lw + (XD * K + 3) / 4 * 4;
+    float* sums = wpart + 16 * 2 * K * 32;
     __shared__ float nrm[KMAX];
-    __shared__ double redc[4];
+    __shared__ double redc[16];
     const int tid = threadIdx.x, fr = tid & 31, grp = tid >> 5, lane = tid & 63, wave = tid >> 6;
+    const int u = tile_seg ? tile_seg[blockIdx.x] : 0;
     const int64_t n0 = (int64_t)blockIdx.x * 32;
-    const bool live = n0 + fr < N;
-    const int64_t n = live ? n0 + fr : N - 1;
+    const int64_t nend = seg_start ? (int64_t)seg_start[u] + seg_count[u] : N;
+    const bool live = n0 + fr < nend;
+    const int64_t n = live ? n0 + fr : nend - 1;
     const int64_t FN = (int64_t)XD * N;
-    for (int i = tid; i < XD * K; i += 256) lw[i] = Wun[i];
+    const float* Wun = Wun_all + (int64_t)u * XD * K;
+    for (int i = tid; i < XD * K; i += FT) lw[i] = Wun[i];
     __syncthreads();
-    // column norms of the un-normalised W (mcem.py:130): recomputed by every workgroup (5 K values)
-    if (tid < K) {
+    // column norms of the un-normalised W (mcem.py:130): 16 threads per column
+    if (tid < 16 * K) {
+        const int k = tid >> 4, q = tid & 15;
         float s = 0.f;
-        for (int f = 0; f < XD; ++f) s += fabsf(lw[f * K + tid]);
-        nrm[tid] = s;
-        if (blockIdx.x == 0) norms_out[tid] = s;
+        for (int f = q; f < XD; f += 16) s += fabsf(lw[f * K + k]);
+        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+        if (q == 0) { nrm[k] = s; if (n0 == (seg_start ? seg_start[u] : 0)) norms_out[u * KMAX + k] = s; }
     }
     float hk[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) hk[k] = k < K ? H[(int64_t)k * N + n] : 0.f;
     const float gn = g[n];
 
-    // ---- H update (mcem.py:118-123) with Vb = Wun H ----
-    float num[KMAX], den[KMAX];
+    // sum over the 32 bin groups of `cnt` per-thread values v[]: wave shuffle (2 groups), LDS (16 waves)
+    auto group_sums = [&](auto& v, int cnt) {
+        constexpr int M = (int)(sizeof(v) / sizeof(float));
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) { num[k] = 0.f; den[k] = 0.f; }
-    for (int f = grp; f < XD; f += 8) {
+        for (int i = 0; i < M; ++i) {
+            if (i < cnt) {
+                float a = v[i];
+                a += __shfl_xor(a, 32, 64);
+                if ((lane >> 5) == 0) wpart[(wave * cnt + i) * 32 + fr] = a;
+            }
+        }
+        __syncthreads();
+        if (grp < cnt) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a += wpart[(w * cnt + grp) * 32 + fr];
+            sums[grp * 32 + fr] = a;
+        }
+        __syncthreads();
+    };
+
+    // ---- H update (mcem.py:118-123) with Vb = Wun H ----
+    float acc[2 * KMAX];
+#pragma unroll
+    for (int k = 0; k < 2 * KMAX; ++k) acc[k] = 0.f;
+    for (int f = grp; f < XD; f += 32) {
         float vb = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) if (k < K) vb = fmaf(lw[f * K + k], hk[k], vb);
@@ -359,24 +396,16 @@ __global__ __launch_bounds__(256) void mstep_frames_kernel(const float* __restri
         }
         const float p2 = X2[(int64_t)f * N + n] * a2;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) if (k < K) { const float w = lw[f * K + k]; num[k] = fmaf(w, p2, num[k]); den[k] = fmaf(w, a1, den[k]); }
+        for (int k = 0; k < KMAX; ++k) if (k < K) { const float w = lw[f * K + k]; acc[2 * k] = fmaf(w, p2, acc[2 * k]); acc[2 * k + 1] = fmaf(w, a1, acc[2 * k + 1]); }
     }
+    group_sums(acc, 2 * K);
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) if (k < K) { redk[grp][2 * k][fr] = num[k]; redk[grp][2 * k + 1][fr] = den[k]; }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        if (k < K) {
-            float a = 0.f, b = 0.f;
-            for (int q = 0; q < 8; ++q) { a += redk[q][2 * k][fr]; b += redk[q][2 * k + 1][fr]; }
-            hk[k] = hk[k] * sqrtf(a / b);
-        }
-    }
+    for (int k = 0; k < KMAX; ++k) if (k < K) hk[k] = hk[k] * sqrtf(sums[(2 * k) * 32 + fr] / sums[(2 * k + 1) * 32 + fr]);
     __syncthreads();
 
     // ---- new Vb = Wun Hnew (mcem.py:126); g update (mcem.py:137-143) ----
-    float ng = 0.f, dg = 0.f;
-    for (int f = grp; f < XD; f += 8) {
+    float gv[2] = {0.f, 0.f};
+    for (int f = grp; f < XD; f += 32) {
         float vb = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) if (k < K) vb = fmaf(lw[f * K + k], hk[k], vb);
@@ -387,17 +416,14 @@ __global__ __launch_bounds__(256) void mstep_frames_kernel(const float* __restri
             const float inv = 1.f / fmaf(gn, vs, vb);
             s1 = fmaf(vs, inv, s1); s2 = fmaf(vs, inv * inv, s2);
         }
-        ng = fmaf(X2[(int64_t)f * N + n], s2, ng); dg += s1;
+        gv[0] = fmaf(X2[(int64_t)f * N + n], s2, gv[0]); gv[1] += s1;
     }
-    redk[grp][0][fr] = ng; redk[grp][1][fr] = dg;
-    __syncthreads();
-    float a = 0.f, b = 0.f;
-    for (int q = 0; q < 8; ++q) { a += redk[q][0][fr]; b += redk[q][1][fr]; }
-    const float gnew = gn * sqrtf(a / b);
+    group_sums(gv, 2);
+    const float gnew = gn * sqrtf(sums[fr] / sums[32 + fr]);
 
     // ---- cost (mcem.py:69-71) with the updated g; H is stored normalised (mcem.py:134) ----
     double c = 0.0;
-    for (int f = grp; f < XD; f += 8) {
+    for (int f = grp; f < XD; f += 32) {
         float vb = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) if (k < K) vb = fmaf(lw[f * K + k], hk[k], vb);
@@ -418,20 +444,30 @@ __global__ __launch_bounds__(256) void mstep_frames_kernel(const float* __restri
         for (int k = 0; k < KMAX; ++k) if (k < K) H[(int64_t)k * N + n] = hk[k] * nrm[k];
     }
     __syncthreads();
-    if (tid == 0) partial[blockIdx.x] = redc[0] + redc[1] + redc[2] + redc[3];
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += redc[w];
+        partial[blockIdx.x] = t;
+    }
 }
 
-// W = Wun / norm (mcem.py:132), cost = mean over (R, F, N)
+// per utterance: W = Wun / norm (mcem.py:132), cost = mean over (R, F, N_u) of the tile partials
 __global__ __launch_bounds__(256) void mstep_finish_kernel(const float* __restrict__ Wun, const float* __restrict__ norms, int K, float* __restrict__ W,
-                                                           const double* __restrict__ partial, int nparts, double count, float* __restrict__ cost) {
-    for (int i = threadIdx.x; i < XD * K; i += 256) W[i] = Wun[i] / norms[i % K];
+                                                           const double* __restrict__ partial, int R, int64_t N,
+                                                           const int* __restrict__ seg_start, const int* __restrict__ seg_count,
+                                                           float* __restrict__ cost) {
+    const int u = blockIdx.x;
+    const int64_t o = (int64_t)u * XD * K;
+    for (int i = threadIdx.x; i < XD * K; i += 256) W[o + i] = Wun[o + i] / norms[u * KMAX + i % K];
+    const int64_t nbeg = seg_start ? seg_start[u] : 0, cnt = seg_count ? seg_count[u] : N;
+    const int t0 = (int)(nbeg / 32), t1 = (int)((nbeg + cnt + 31) / 32);
     __shared__ double red[4];
     double c = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) c += partial[i];
+    for (int i = t0 + threadIdx.x; i < t1; i += 256) c += partial[i];
     c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0 && cost) cost[0] = (float)((red[0] + red[1] + red[2] + red[3]) / count);
+    if (threadIdx.x == 0 && cost) cost[u] = (float)((red[0] + red[1] + red[2] + red[3]) / ((double)R * XD * (double)cnt));
 }
 
 // Wiener gains (compute_WF, mcem.py:321-327)
@@ -558,27 +594,55 @@ extern "C" int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weight
     return run_mh(plan, weights, a, (hipStream_t)stream);
 }
 
-extern "C" size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K) {
-    return (size_t)(XD * K * sizeof(float) + 256 + KMAX * sizeof(float) + 256 + ((N + 31) / 32) * sizeof(double) + 256);
+static size_t mstep_ws_layout(int64_t N, int K, int U, size_t* o_norms, size_t* o_partial) {
+    size_t o = ((size_t)U * XD * K * sizeof(float) + 255) / 256 * 256;
+    *o_norms = o; o += ((size_t)U * KMAX * sizeof(float) + 255) / 256 * 256;
+    *o_partial = o; o += ((size_t)((N + 31) / 32) * sizeof(double) + 255) / 256 * 256;
+    return o;
+}
+
+extern "C" size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K, int U) {
+    size_t a, b;
+    return mstep_ws_layout(N, K, U < 1 ? 1 : U, &a, &b);
+}
+
+extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, int64_t N, int K, int U, const int* seg_start,
+                                      const int* seg_count, const int* tile_seg, float* W, float* H, float* g, float* Vb,
+                                      float* cost, void* workspace, void* stream) {
+    DVAE_CHECK_ARG(X2 && Vs && W && H && g && Vb && workspace, "mcem_m_step: null argument");
+    DVAE_CHECK_ARG(R > 0 && N > 0 && K > 0 && K <= KMAX && U > 0, "mcem_m_step: need R > 0, N > 0, U > 0, 0 < K <= %d", KMAX);
+    DVAE_CHECK_ARG((seg_start != nullptr) == (seg_count != nullptr) && (seg_start != nullptr) == (tile_seg != nullptr),
+                   "mcem_m_step: the three segment tables go together");
+    DVAE_CHECK_ARG(seg_start != nullptr || U == 1, "mcem_m_step: U > 1 needs the segment tables");
+    DVAE_CHECK_ARG(seg_start == nullptr || N % 32 == 0, "mcem_m_step: batched frame axis must be padded to a multiple of 32");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    size_t o_norms, o_partial;
+    mstep_ws_layout(N, K, U, &o_norms, &o_partial);
+    float* Wun = (float*)ws;
+    float* norms = (float*)(ws + o_norms);
+    double* partial = (double*)(ws + o_partial);
+    const int ntiles = (int)((N + 31) / 32);
+    hipLaunchKernelGGL(mstep_w_kernel, dim3(XD, U), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun, seg_start, seg_count);
+    DVAE_LAUNCH_OK("mstep_w_kernel");
+    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + 16 * 2 * K * 32 + 2 * K * 32) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + 16 * 2 * KMAX * 32 + 2 * KMAX * 32) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mstep_frames_kernel, dim3(ntiles), dim3(FT), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    DVAE_LAUNCH_OK("mstep_frames_kernel");
+    hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost);
+    DVAE_LAUNCH_OK("mstep_finish_kernel");
+    return 0;
 }
 
 extern "C" int dvae_mcem_m_step(const float* X2, const float* Vs, int R, int64_t N, int K, float* W, float* H, float* g, float* Vb,
                                 float* cost, void* workspace, void* stream) {
-    DVAE_CHECK_ARG(X2 && Vs && W && H && g && Vb && workspace, "mcem_m_step: null argument");
-    DVAE_CHECK_ARG(R > 0 && N > 0 && K > 0 && K <= KMAX, "mcem_m_step: need R > 0, N > 0, 0 < K <= %d", KMAX);
-    hipStream_t s = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    float* Wun = (float*)ws;
-    float* norms = (float*)(ws + (XD * K * sizeof(float) + 255) / 256 * 256);
-    double* partial = (double*)((char*)norms + 256);
-    const int nparts = (int)((N + 31) / 32);
-    hipLaunchKernelGGL(mstep_w_kernel, dim3(XD), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun);
-    DVAE_LAUNCH_OK("mstep_w_kernel");
-    hipLaunchKernelGGL(mstep_frames_kernel, dim3(nparts), dim3(256), (size_t)XD * K * sizeof(float), s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial);
-    DVAE_LAUNCH_OK("mstep_frames_kernel");
-    hipLaunchKernelGGL(mstep_finish_kernel, dim3(1), dim3(256), 0, s, Wun, norms, K, W, partial, nparts, (double)R * XD * (double)N, cost);
-    DVAE_LAUNCH_OK("mstep_finish_kernel");
-    return 0;
+    return dvae_mcem_m_step_batch(X2, Vs, R, N, K, 1, nullptr, nullptr, nullptr, W, H, g, Vb, cost, workspace, stream);
 }
 
 extern "C" int dvae_mcem_wiener(const float* Vs, int R, int64_t N, const float* g, const float* Vb, float* WFs, float* WFn, void* stream) {

@@ -6,6 +6,7 @@ tensors in the reference's own shapes.  No fallback: errors from the library rai
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import native as N
@@ -99,7 +100,7 @@ def m_step_(X2, Vs, W, H, g, Vb, want_cost=True):
     for a, nm in ((X2, "X2"), (Vs, "Vs"), (W, "W"), (H, "H"), (g, "g"), (Vb, "Vb")):
         if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
             raise RuntimeError(f"m_step_: {nm} must be a contiguous float32 CUDA tensor")
-    ws = torch.empty(lib.dvae_mcem_m_step_workspace_bytes(n, K), dtype=torch.uint8, device=W.device)
+    ws = torch.empty(lib.dvae_mcem_m_step_workspace_bytes(n, K, 1), dtype=torch.uint8, device=W.device)
     cost = torch.empty(1, dtype=torch.float32, device=W.device) if want_cost else None
     N.check(lib.dvae_mcem_m_step(N.ptr(X2), N.ptr(Vs), R, n, K, N.ptr(W), N.ptr(H), N.ptr(g), N.ptr(Vb), N.ptr(cost), N.ptr(ws), N.stream()),
             "dvae_mcem_m_step")
@@ -115,3 +116,113 @@ def wiener(Vs, g, Vb):
     WFn = torch.empty_like(WFs)
     N.check(lib.dvae_mcem_wiener(N.ptr(Vs), R, n, N.ptr(g), N.ptr(Vb), N.ptr(WFs), N.ptr(WFn), N.stream()), "dvae_mcem_wiener")
     return WFs, WFn
+
+
+def m_step_batch_(X2, Vs, W, H, g, Vb, seg_start, seg_count, tile_seg):
+    """M-step for U utterances laid side by side on the (padded) frame axis; in place; returns cost (U)."""
+    lib = N.load()
+    R, F, n = Vs.shape
+    U, _, K = W.shape
+    assert F == F_BINS and W.shape == (U, F, K) and H.shape == (K, n) and g.shape == (n,) and Vb.shape == (F, n) and X2.shape == (F, n)
+    assert n % 32 == 0 and tile_seg.numel() == n // 32 and seg_start.numel() == U and seg_count.numel() == U
+    for a, nm in ((X2, "X2"), (Vs, "Vs"), (W, "W"), (H, "H"), (g, "g"), (Vb, "Vb")):
+        if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
+            raise RuntimeError(f"m_step_batch_: {nm} must be a contiguous float32 CUDA tensor")
+    for a in (seg_start, seg_count, tile_seg):
+        if not (a.is_cuda and a.dtype == torch.int32 and a.is_contiguous()):
+            raise RuntimeError("m_step_batch_: segment tables must be contiguous int32 CUDA tensors")
+    ws = torch.empty(lib.dvae_mcem_m_step_workspace_bytes(n, K, U), dtype=torch.uint8, device=W.device)
+    cost = torch.empty(U, dtype=torch.float32, device=W.device)
+    N.check(lib.dvae_mcem_m_step_batch(N.ptr(X2), N.ptr(Vs), R, n, K, U, N.ptr(seg_start), N.ptr(seg_count), N.ptr(tile_seg),
+                                       N.ptr(W), N.ptr(H), N.ptr(g), N.ptr(Vb), N.ptr(cost), N.ptr(ws), N.stream()),
+            "dvae_mcem_m_step_batch")
+    return cost
+
+
+class McemBatch:
+    """MCEM enhancement of many utterances at once (the MI355X-native form of the reference's process pool,
+    scripts/evaluate_ntcd_M2.py:288-327: there, nb_devices * 2 processes each run one utterance at a time).
+
+    The utterances are laid side by side on the frame axis, each padded to a multiple of 32 frames; the
+    Metropolis-Hastings chains are independent per frame, the NMF factors per utterance.  Per EM iteration:
+    one chain launch, three M-step launches, whatever the number of utterances.
+
+    vae: a packages.models VAE (encoder / decoder / z_dim).  label_in_encoder / label_in_decoder select the
+    reference variant: MCEM_M1 (False, False), MCEM_M2 (True, True), MCEM_M2v2 / M2v3 (False, True).
+    """
+
+    def __init__(self, vae, niter=100, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, var_RW=0.01,
+                 nmf_rank=10, eps=2.220446049250313e-16, label_in_encoder=True, label_in_decoder=True, precision="fp32"):
+        self.vae, self.niter = vae, niter
+        self.n_e, self.b_e, self.n_wf, self.b_wf = nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF
+        self.var_RW, self.K, self.eps = var_RW, nmf_rank, eps
+        self.label_in_encoder, self.label_in_decoder = label_in_encoder, label_in_decoder
+        self.precision = precision
+        self._pack = None
+
+    def _layout(self, counts, dev):
+        starts, pos = [], 0
+        for c in counts:
+            starts.append(pos)
+            pos += (c + 31) // 32 * 32
+        tile_seg = []
+        for u, c in enumerate(counts):
+            tile_seg += [u] * ((c + 31) // 32)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        return starts, pos, i32(starts), i32(counts), i32(tile_seg)
+
+    def init_parameters(self, X_list, y_list=None, device="cuda"):
+        """X_list: complex mixture STFTs (F, N_u) (numpy); y_list: labels (y_dim, N_u) tensors/arrays or None."""
+        dev = torch.device(device)
+        self.X_list = X_list
+        self.counts = [x.shape[1] for x in X_list]
+        self.starts, self.ntot, self.seg_start, self.seg_count, self.tile_seg = self._layout(self.counts, dev)
+        U, K = len(X_list), self.K
+        self.X2 = torch.ones((F_BINS, self.ntot), dtype=torch.float32, device=dev)
+        self.H = torch.ones((K, self.ntot), dtype=torch.float32, device=dev)
+        self.Vb = torch.ones((F_BINS, self.ntot), dtype=torch.float32, device=dev)
+        self.g = torch.ones(self.ntot, dtype=torch.float32, device=dev)
+        self.Z = torch.zeros((Z_DIM, self.ntot), dtype=torch.float32, device=dev)
+        self.W = torch.empty((U, F_BINS, K), dtype=torch.float32, device=dev)
+        self.y = None
+        if self.label_in_decoder:
+            y_dim = y_list[0].shape[0]
+            self.y = torch.zeros((y_dim, self.ntot), dtype=torch.float32, device=dev)
+        for u, X in enumerate(X_list):
+            s, c = self.starts[u], self.counts[u]
+            self.X2[:, s:s + c] = torch.from_numpy((np.abs(X) ** 2).astype(np.float32)).to(dev)
+            self.W[u] = torch.clamp_min(torch.rand(F_BINS, K, device=dev), self.eps)               # mcem.py:42
+            self.H[:, s:s + c] = torch.clamp_min(torch.rand(K, c, device=dev), self.eps)           # mcem.py:43
+            self.Vb[:, s:s + c] = self.W[u] @ self.H[:, s:s + c]                                    # mcem.py:52
+            if self.y is not None:
+                self.y[:, s:s + c] = torch.as_tensor(y_list[u], dtype=torch.float32).to(dev)
+        enc_in = torch.cat([self.X2, self.y], dim=0) if self.label_in_encoder else self.X2
+        with torch.no_grad():
+            _, mu, _ = self.vae.encoder(torch.t(enc_in))                                            # mcem.py:200, 364
+        self.Z = torch.t(mu).contiguous()
+        y_dim = self.y.shape[0] if self.y is not None else 0
+        self._pack = DecoderPack(self.vae.decoder, y_dim, self.precision)
+
+    def _chain(self, nsamples, burnin, draws=None):
+        nit = nsamples + burnin
+        if draws is None:
+            noise = torch.randn(nit, Z_DIM, self.ntot, device=self.Z.device)
+            logu = torch.log(torch.rand(nit, self.ntot, device=self.Z.device))
+        else:
+            noise, logu = draws
+        return self._pack.sample(self.Z, self.y, self.g, self.Vb, self.X2, noise, logu, burnin, var_rw=float(self.var_RW))
+
+    def run(self, draws=None):
+        """EM.run (mcem.py:156-179) for all utterances.  draws: optional list of niter + 1 (noise, logu) pairs.
+        Returns cost (niter, U); sets S_hat / N_hat (lists of complex (F, N_u) arrays)."""
+        cost = torch.empty((self.niter, len(self.counts)), dtype=torch.float32, device=self.Z.device)
+        for it in range(self.niter):
+            Zs, Vs = self._chain(self.n_e, self.b_e, None if draws is None else draws[it])
+            self.Z = Zs[:, -1, :].t().contiguous()
+            cost[it] = m_step_batch_(self.X2, Vs, self.W, self.H, self.g, self.Vb, self.seg_start, self.seg_count, self.tile_seg)
+        Zs, Vs = self._chain(self.n_wf, self.b_wf, None if draws is None else draws[self.niter])
+        self.WFs, self.WFn = wiener(Vs, self.g, self.Vb)
+        WFs, WFn = self.WFs.cpu().numpy(), self.WFn.cpu().numpy()
+        self.S_hat = [WFs[:, s:s + c] * X for s, c, X in zip(self.starts, self.counts, self.X_list)]
+        self.N_hat = [WFn[:, s:s + c] * X for s, c, X in zip(self.starts, self.counts, self.X_list)]
+        return cost.cpu().numpy()

@@ -57,7 +57,8 @@ SIGNATURES = {
     "dvae_mcem_pack": (c_i, [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp]),
     "dvae_mcem_sample": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_decode": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_i64, c_vp, c_vp]),
-    "dvae_mcem_m_step_workspace_bytes": (c_sz, [c_i64, c_i]),
+    "dvae_mcem_m_step_workspace_bytes": (c_sz, [c_i64, c_i, c_i]),
+    "dvae_mcem_m_step_batch": (c_i, [c_vp, c_vp, c_i, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_m_step": (c_i, [c_vp, c_vp, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_wiener": (c_i, [c_vp, c_i, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

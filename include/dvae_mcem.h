@@ -54,9 +54,20 @@ int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weights, const fl
 /* EM.M_step (mcem.py:91-153) + compute_expected_neg_log_like (mcem.py:69-71).  In place: W, H (stored normalised),
  * g, and Vb (the product of the un-normalised factors, which is what the reference keeps for the next E-step).
  * cost: 1 float or NULL.  K <= 16. */
-size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K);
+size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K, int U);
 int dvae_mcem_m_step(const float* X2, const float* Vs, int R, int64_t N, int K, float* W, float* H, float* g, float* Vb,
                      float* cost, void* workspace, void* stream);
+
+/* The same for U utterances laid side by side on the frame axis (the reference runs one utterance per process,
+ * scripts/evaluate_ntcd_M2.py:317-327; one MI355X holds dozens of them in one launch).  Utterance u owns frames
+ * seg_start[u] .. seg_start[u] + seg_count[u] - 1; seg_start[u] is a multiple of 32, N (the padded total) too;
+ * tile_seg[t] = utterance of frames 32t .. 32t+31.  Padding frames must hold finite values (e.g. X2 = Vb = g = 1)
+ * and are never written.  W is (U, F, K), cost (U); H, g, Vb, X2, Vs as above with N = padded total.
+ * The three tables are device int32 arrays.  dvae_mcem_sample / _decode / _wiener act frame by frame and need
+ * no batched form. */
+int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, int64_t N, int K, int U, const int* seg_start,
+                           const int* seg_count, const int* tile_seg, float* W, float* H, float* g, float* Vb,
+                           float* cost, void* workspace, void* stream);
 
 /* compute_WF (mcem.py:321-327): WFs = mean_r(g Vs / Vx), WFn = mean_r(Vb / Vx), both (F, N). */
 int dvae_mcem_wiener(const float* Vs, int R, int64_t N, const float* g, const float* Vb, float* WFs, float* WFn, void* stream);

@@ -163,3 +163,44 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(RuntimeError):
         mcem_dev.m_step_(t(X2), torch.ones((2, 513, 8), device="cuda"), torch.ones((513, 17), device="cuda"),
                          torch.ones((17, 8), device="cuda"), t(g), t((W @ H)))   # K > 16
+
+
+def test_batched_run_equals_per_utterance_runs():
+    """McemBatch (utterances side by side, padded to 32 frames) == each utterance alone on the same draws."""
+    counts = [45, 64, 7]
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 21)
+    m = build_model("M2", dims)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    m.cuda().eval()
+    utts = [mc.make_utterance(dict(seed=40 + i, N=n, model="M2")) for i, n in enumerate(counts)]
+    mb = mcem_dev.McemBatch(m, niter=3, nsamples_E_step=3, burnin_E_step=4, nsamples_WF=4, burnin_WF=3)
+    torch.manual_seed(1)
+    mb.init_parameters([u[0] for u in utts], [u[2] for u in utts])
+    W0, H0, Z0, Vb0 = mb.W.clone(), mb.H.clone(), mb.Z.clone(), mb.Vb.clone()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    draws = []
+    for it in range(4):
+        nit = 7
+        draws.append((torch.randn(nit, 16, mb.ntot, device="cuda", generator=gen),
+                      torch.log(torch.rand(nit, mb.ntot, device="cuda", generator=gen))))
+    cost = mb.run(draws)
+    assert cost.shape == (3, 3) and np.isfinite(cost).all()
+    for u, n in enumerate(counts):
+        s = mb.starts[u]
+        sl = slice(s, s + n)
+        X2 = mb.X2[:, sl].contiguous(); y = mb.y[:, sl].contiguous()
+        W, H, g = W0[u].clone(), H0[:, sl].contiguous(), torch.ones(n, device="cuda")
+        Vb, Z = Vb0[:, sl].contiguous(), Z0[:, sl].contiguous()
+        for it in range(3):
+            Zs, Vs = mb._pack.sample(Z, y, g, Vb, X2, draws[it][0][:, :, sl].contiguous(), draws[it][1][:, sl].contiguous(), 4)
+            Z = Zs[:, -1, :].t().contiguous()
+            c = mcem_dev.m_step_(X2, Vs, W, H, g, Vb)
+            np.testing.assert_allclose(c.item(), cost[it, u], rtol=1e-6)
+        torch.testing.assert_close(W, mb.W[u], rtol=1e-6, atol=0)
+        torch.testing.assert_close(H, mb.H[:, sl], rtol=1e-6, atol=0)
+        torch.testing.assert_close(g, mb.g[sl], rtol=1e-6, atol=0)
+        Zs, Vs = mb._pack.sample(Z, y, g, Vb, X2, draws[3][0][:, :, sl].contiguous(), draws[3][1][:, sl].contiguous(), 3)
+        WFs, WFn = mcem_dev.wiener(Vs, g, Vb)
+        np.testing.assert_allclose(WFs.cpu().numpy() * utts[u][0], mb.S_hat[u], rtol=1e-5, atol=1e-7)
+        assert mb.S_hat[u].shape == utts[u][0].shape
