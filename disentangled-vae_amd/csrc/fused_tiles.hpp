@@ -43,6 +43,7 @@ struct PolF32 {
     static __device__ __forceinline__ float tanh_(float v) { return tanhf(v); }
     static __device__ __forceinline__ float exp_(float v) { return expf(v); }
     static __device__ __forceinline__ float log_(float v) { return logf(v); }
+    static __device__ __forceinline__ float div_(float a, float b) { return a / b; }
 };
 
 struct PolBF16 {
@@ -74,6 +75,7 @@ struct PolBF16 {
         const float e = __builtin_amdgcn_exp2f(v * 2.88539008177792681f);
         return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
     }
+    static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
 // LDS row strides (elements): an odd number of 16-byte slots per row
@@ -188,6 +190,23 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w
         P::mma(acc, a[i], bq[(base + i) % BD]);
         if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc += W * act^T with the weight fragments already in registers (kernels that reuse one small weight set many
+// times, e.g. the Metropolis-Hastings chain): only the LDS activation fragments are fetched, 4 k-steps ahead.
+template <typename P, int NSTEPS>
+__device__ __forceinline__ void gemm_resident(f32x16& acc, const typename P::Frag (&w)[NSTEPS], const typename P::T* brow) {
+    typedef typename P::Frag Frag;
+    constexpr int STR = 2 * P::E;
+    constexpr int BD = NSTEPS < 4 ? NSTEPS : 4;
+    Frag bq[BD];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) bq[i] = *reinterpret_cast<const Frag*>(brow + i * STR);
+#pragma unroll
+    for (int i = 0; i < NSTEPS; ++i) {
+        P::mma(acc, w[i], bq[i % BD]);
+        if (i + BD < NSTEPS) bq[i % BD] = *reinterpret_cast<const Frag*>(brow + (i + BD) * STR);
     }
 }
 

@@ -48,9 +48,28 @@ template <typename T> struct MhLds {
     }
 };
 
-template <typename P, int YP>
+// The chain reuses one small weight set thousands of times per launch, so weights live in registers where they fit
+// (one wave per SIMD: 512 VGPRs + AGPRs): RES = 1 keeps decoder layers 1-2 resident and streams the output layer
+// through a 16-deep ring (fp32: the 5 output tiles of a wave would need 320 registers); RES = 2 keeps all of it
+// (bf16: 196 registers), leaving no weight traffic at all inside the chain.
+// fp32 chain policy: exact fp32 products; the 513-bin likelihood epilogue (exp, log, divide per bin and per chain
+// step) is VALU-bound at one wave per SIMD, so it uses the hardware exp2 / log2 / rcp units (1-2 ulp) instead of
+// the ~60-instruction libm expansions: 8 us of a 23 us chain step on MI355X.
+struct PolF32Deep : PolF32 {
+    static constexpr int PD = 16; static constexpr int PRE = 8;
+    static __device__ __forceinline__ float exp_(float v) { return __expf(v); }
+    static __device__ __forceinline__ float log_(float v) { return __logf(v); }
+    static __device__ __forceinline__ float div_(float a, float b) { return __fdividef(a, b); }
+    static __device__ __forceinline__ float tanh_(float v) {
+        const float e = __expf(2.f * v);                       // tanh = 1 - 2 / (e^{2v} + 1); saturates cleanly at +-1
+        return 1.f - __fdividef(2.f, e + 1.f);
+    }
+};
+
+template <typename P, int YP, int RES>
 __global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
     typedef typename P::T T;
+    typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP;
     constexpr int LDH = MhLds<T>::hh, LDZ = MhLds<T>::z, LDY = YP + MhLds<T>::per16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,6 +100,22 @@ __global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
     const T* const Ybr = Yb + l31 * LDY + h * E;
 
     for (int i = tid; i < MhLds<T>::nbias; i += 256) Bias[i] = g.bias[i];
+    // resident weight fragments of this wave
+    constexpr int NT5 = (NT_OUT + 3) / 4;                      // output tiles per wave (wave 0: 5, others 4)
+    Frag w3zR[ZD / KS], w4R[HD / KS], w5R[RES == 2 ? NT5 : 1][HD / KS];
+#pragma unroll
+    for (int i = 0; i < ZD / KS; ++i) w3zR[i] = wload<P>(wrs, W3r, i * S4);
+#pragma unroll
+    for (int i = 0; i < HD / KS; ++i) w4R[i] = wload<P>(wrs, W4r, i * S4);
+    if constexpr (RES == 2) {
+#pragma unroll
+        for (int q = 0; q < NT5; ++q) {
+            const int t = wave_u + 4 * q;
+            const WRef wr = woff(W5r, (unsigned)(t < NT_OUT ? t : wave_u) * TSTEP);
+#pragma unroll
+            for (int i = 0; i < HD / KS; ++i) w5R[q][i] = wload<P>(wrs, wr, i * S17);
+        }
+    }
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
@@ -123,37 +158,51 @@ __global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
         // one decoder pass over the latents in Zb; EPI(t, f32x16 acc) handles output tile t of this wave
         auto decode = [&](auto&& epi_pre, auto&& epi) {
             f32x16 acc;
-            WPre<P, ZD / KS> w3z;
-            wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
             zero_acc<P>(acc);
-            gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4);
-            WPre<P, HD / KS> w4;
-            wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
+            gemm_resident<P, ZD / KS>(acc, w3zR, Zbr);
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + c1[r]);
             put_lds<P>(v, Ha, LDH, fb, l31, h);
             __syncthreads();
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4);
             WPre<P, HD / KS> w5;
-            wprefetch<P, HD / KS>(w5, wrs, woff(W5r, wave_u * TSTEP), S17);
+            if constexpr (RES != 2) wprefetch<P, HD / KS>(w5, wrs, woff(W5r, wave_u * TSTEP), S17);
+            gemm_resident<P, HD / KS>(acc, w4R, Har);
             float bv[16];
             bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
             put_lds<P>(v, Hb, LDH, fb, l31, h);
             __syncthreads();
-#pragma unroll 1
-            for (int t = wave_u; t < NT_OUT; t += 4) {
-                zero_acc<P>(acc);
-                const WRef wr = woff(W5r, (unsigned)t * TSTEP);
-                gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { epi_pre(t); });
-                if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
-                bias16(Bias + OB5, 32 * t, h, bv);
+            if constexpr (RES == 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += bv[r];
-                epi(t, acc);
+                for (int q = 0; q < NT5; ++q) {
+                    const int t = wave_u + 4 * q;
+                    __builtin_amdgcn_sched_barrier(0);      // keep one tile's operand loads in flight at a time
+                    if (t < NT_OUT) {
+                        epi_pre(t);
+                        zero_acc<P>(acc);
+                        gemm_resident<P, HD / KS>(acc, w5R[q], Hbr);
+                        bias16(Bias + OB5, 32 * t, h, bv);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += bv[r];
+                        epi(t, acc);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int t = wave_u; t < NT_OUT; t += 4) {
+                    zero_acc<P>(acc);
+                    const WRef wr = woff(W5r, (unsigned)t * TSTEP);
+                    gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { epi_pre(t); });
+                    // the next tile's first fragments (the last tile wraps to the first tile of the next decoder pass)
+                    wprefetch<P, HD / KS>(w5, wrs, woff(W5r, (unsigned)(t + 4 < NT_OUT ? t + 4 : wave_u) * TSTEP), S17);
+                    bias16(Bias + OB5, 32 * t, h, bv);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += bv[r];
+                    epi(t, acc);
+                }
             }
         };
 
@@ -192,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
                     for (int r = 0; r < 16; ++r) {
                         const bool ok = 32 * t + feat_of(r, h) < XD;
                         const float vx = fmaf(g_n, P::exp_(a[r]), vbs[r]);            // mcem.py:248-249
-                        const float term = P::log_(vx) + xs[r] / vx;                  // mcem.py:252-253
+                        const float term = P::log_(vx) + P::div_(xs[r], vx);           // mcem.py:252-253
                         s += ok ? term : 0.f;
                     }
                     ll += (double)s;
@@ -501,16 +550,16 @@ static McemLayout mcem_layout(int y_dim, int precision) {
     return L;
 }
 
-template <typename P, int YP>
+template <typename P, int YP, int RES>
 static int launch_mh(const MhArgs& a, hipStream_t s) {
     const size_t lds = MhLds<typename P::T>::bytes(YP);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mcem_mh_kernel<P, YP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)mcem_mh_kernel<P, YP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mcem_mh_kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
-    hipLaunchKernelGGL((mcem_mh_kernel<P, YP>), dim3(a.ntiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((mcem_mh_kernel<P, YP, RES>), dim3(a.ntiles), dim3(256), lds, s, a);
     DVAE_LAUNCH_OK("mcem_mh_kernel");
     return 0;
 }
@@ -523,9 +572,9 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     a.oW3 = L.oW3; a.oW4 = L.oW4; a.oW5 = L.oW5;
     a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
     const bool bf = plan->precision == DVAE_PREC_BF16;
-    if (L.yp == 0) return bf ? launch_mh<PolBF16, 0>(a, s) : launch_mh<PolF32, 0>(a, s);
-    if (L.yp == 16) return bf ? launch_mh<PolBF16, 16>(a, s) : launch_mh<PolF32, 16>(a, s);
-    if (L.yp == 528) return bf ? launch_mh<PolBF16, 528>(a, s) : launch_mh<PolF32, 528>(a, s);
+    if (L.yp == 0) return bf ? launch_mh<PolBF16, 0, 1>(a, s) : launch_mh<PolF32Deep, 0, 1>(a, s);
+    if (L.yp == 16) return bf ? launch_mh<PolBF16, 16, 1>(a, s) : launch_mh<PolF32Deep, 16, 1>(a, s);
+    if (L.yp == 528) return bf ? launch_mh<PolBF16, 528, 1>(a, s) : launch_mh<PolF32Deep, 528, 1>(a, s);
     set_error("mcem: y_dim %d not supported (0, 1..16, 513)", plan->y_dim);
     return DVAE_E_BADARG;
 }

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--y-dim", type=int, default=1)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--batch", type=int, nargs="*", default=[8, 25, 51, 102])
     a = ap.parse_args()
     model = "M2" if a.y_dim else "M1"
     cls = mcem.MCEM_M2 if a.y_dim else mcem.MCEM_M1
@@ -80,6 +81,24 @@ def main():
         res[prec]["e_step_us"] = ev[0].elapsed_time(ev[1]) * 1e3 / reps
         res[prec]["mh_iteration_us"] = res[prec]["e_step_us"] / (n_e + b_e + n_e + 1)     # 41 chain passes + 10 decode passes
         res[prec]["m_step_us"] = ev[1].elapsed_time(ev[2]) * 1e3 / reps
+    # many utterances side by side (McemBatch): throughput in utterances / s
+    dev = __import__("importlib").import_module("disentangled-vae_amd.mcem")
+    res["batched"] = {}
+    for prec in ("fp32", "bf16"):
+        for U in a.batch:
+            m, X, S, y = make(model, a.y_dim, a.frames, "cuda", prec)
+            mb = dev.McemBatch(m, niter=niter, nsamples_E_step=n_e, burnin_E_step=b_e, nsamples_WF=n_wf, burnin_WF=b_wf,
+                               label_in_encoder=bool(a.y_dim), label_in_decoder=bool(a.y_dim), precision=prec)
+            ys = [y] * U if y is not None else None
+            mb.niter = 2
+            mb.init_parameters([X] * U, ys); mb.run()
+            mb.niter = niter
+            mb.init_parameters([X] * U, ys)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            cost = mb.run()
+            torch.cuda.synchronize(); t = time.perf_counter() - t0
+            res["batched"][f"{prec}_U{U}"] = dict(seconds=t, utterances_per_s=U / t, ms_per_em_iteration=1e3 * t / niter,
+                                                  ref_decoder_frame_passes_per_s=U * passes_ref / t, cost_last=float(cost[-1].mean()))
     if not a.no_cpu:
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         m, X, S, y = make(model, a.y_dim, a.frames, "cpu", "fp32")
