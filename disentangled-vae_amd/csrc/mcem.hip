@@ -13,6 +13,7 @@
 //     current state is equivalent and halves the work;
 //   * the per-frame likelihood sum over 513 bins is accumulated in double.
 #include <math.h>
+#include <stdlib.h>
 #include "fused_tiles.hpp"
 #include "../../include/dvae_mcem.h"
 
@@ -48,10 +49,11 @@ template <typename T> struct MhLds {
     }
 };
 
-// The chain reuses one small weight set thousands of times per launch, so weights live in registers where they fit
-// (one wave per SIMD: 512 VGPRs + AGPRs): RES = 1 keeps decoder layers 1-2 resident and streams the output layer
-// through a 16-deep ring (fp32: the 5 output tiles of a wave would need 320 registers); RES = 2 keeps all of it
-// (bf16: 196 registers), leaving no weight traffic at all inside the chain.
+// The chain reuses one small weight set thousands of times per launch.  RES = 0 streams every layer from L2 through
+// the fragment ring (lean: 168 VGPRs, three workgroups per CU); RES = 1 keeps decoder layers 1-2 in registers and
+// streams the output layer through a 16-deep ring; RES = 2 keeps all of it (bf16: 196 registers -- hipcc spills
+// instead of using AGPRs for the fragments, so it is not selected).  A chain step is issue-bound (MFMA, then the
+// VALU-heavy likelihood epilogue, in the same waves), which is why co-resident workgroups pay off.
 // fp32 chain policy: exact fp32 products; the 513-bin likelihood epilogue (exp, log, divide per bin and per chain
 // step) is VALU-bound at one wave per SIMD, so it uses the hardware exp2 / log2 / rcp units (1-2 ulp) instead of
 // the ~60-instruction libm expansions: 8 us of a 23 us chain step on MI355X.
@@ -66,8 +68,10 @@ struct PolF32Deep : PolF32 {
     }
 };
 
+struct PolF32Lean : PolF32Deep { static constexpr int PD = 6; static constexpr int PRE = 2; };
+
 template <typename P, int YP, int RES>
-__global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
+__global__ __launch_bounds__(256, RES == 0 ? 3 : 1) void mcem_mh_kernel(const MhArgs g) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP;
@@ -102,11 +106,13 @@ __global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
     for (int i = tid; i < MhLds<T>::nbias; i += 256) Bias[i] = g.bias[i];
     // resident weight fragments of this wave
     constexpr int NT5 = (NT_OUT + 3) / 4;                      // output tiles per wave (wave 0: 5, others 4)
-    Frag w3zR[ZD / KS], w4R[HD / KS], w5R[RES == 2 ? NT5 : 1][HD / KS];
+    Frag w3zR[ZD / KS], w4R[RES >= 1 ? HD / KS : 1], w5R[RES == 2 ? NT5 : 1][HD / KS];
 #pragma unroll
     for (int i = 0; i < ZD / KS; ++i) w3zR[i] = wload<P>(wrs, W3r, i * S4);
+    if constexpr (RES >= 1) {
 #pragma unroll
-    for (int i = 0; i < HD / KS; ++i) w4R[i] = wload<P>(wrs, W4r, i * S4);
+        for (int i = 0; i < HD / KS; ++i) w4R[i] = wload<P>(wrs, W4r, i * S4);
+    }
     if constexpr (RES == 2) {
 #pragma unroll
         for (int q = 0; q < NT5; ++q) {
@@ -167,8 +173,15 @@ __global__ __launch_bounds__(256, 1) void mcem_mh_kernel(const MhArgs g) {
             __syncthreads();
             zero_acc<P>(acc);
             WPre<P, HD / KS> w5;
-            if constexpr (RES != 2) wprefetch<P, HD / KS>(w5, wrs, woff(W5r, wave_u * TSTEP), S17);
-            gemm_resident<P, HD / KS>(acc, w4R, Har);
+            if constexpr (RES >= 1) {
+                if constexpr (RES != 2) wprefetch<P, HD / KS>(w5, wrs, woff(W5r, wave_u * TSTEP), S17);
+                gemm_resident<P, HD / KS>(acc, w4R, Har);
+            } else {
+                WPre<P, HD / KS> w4;
+                wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
+                gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4);
+                wprefetch<P, HD / KS>(w5, wrs, woff(W5r, wave_u * TSTEP), S17);
+            }
             float bv[16];
             bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
@@ -572,9 +585,12 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     a.oW3 = L.oW3; a.oW4 = L.oW4; a.oW5 = L.oW5;
     a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
     const bool bf = plan->precision == DVAE_PREC_BF16;
-    if (L.yp == 0) return bf ? launch_mh<PolBF16, 0, 1>(a, s) : launch_mh<PolF32Deep, 0, 1>(a, s);
-    if (L.yp == 16) return bf ? launch_mh<PolBF16, 16, 1>(a, s) : launch_mh<PolF32Deep, 16, 1>(a, s);
-    if (L.yp == 528) return bf ? launch_mh<PolBF16, 528, 1>(a, s) : launch_mh<PolF32Deep, 528, 1>(a, s);
+    // fp32: lean streaming variant (168 VGPRs, 3 workgroups per CU co-resident: 3.2 us per tile and chain at >= 768
+    // tiles against 4.3 us with resident layers 1-2 at one workgroup per CU; equal at <= 256 tiles).
+    // bf16: layers 1-2 resident (1.11 us per tile against 1.18 us).  Measured with tools/exp_mcem_occupancy.py.
+    if (L.yp == 0) return bf ? launch_mh<PolBF16, 0, 1>(a, s) : launch_mh<PolF32Lean, 0, 0>(a, s);
+    if (L.yp == 16) return bf ? launch_mh<PolBF16, 16, 1>(a, s) : launch_mh<PolF32Lean, 16, 0>(a, s);
+    if (L.yp == 528) return bf ? launch_mh<PolBF16, 528, 1>(a, s) : launch_mh<PolF32Lean, 528, 0>(a, s);
     set_error("mcem: y_dim %d not supported (0, 1..16, 513)", plan->y_dim);
     return DVAE_E_BADARG;
 }
