@@ -41,6 +41,8 @@ SIGNATURES = {
     "dvae_stft": (c_i, [c_vp, c_i, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i, c_vp]),
     "dvae_istft_workspace_bytes": (c_sz, [c_i64, c_i]),
     "dvae_istft": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dvae_transpose": (c_i, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "dvae_gather_rows": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i, c_vp, c_i64, c_vp, c_vp]),
     # include/dvae_train.h (plan pointers are passed with ctypes.byref)
     "dvae_train_plan": (c_i, [c_i, c_i, c_i, c_i64, c_i, c_vp]),
     "dvae_train_init": (c_i, [c_vp, c_vp, c_vp, c_vp]),

@@ -60,7 +60,8 @@ class Trainer:
     gradient is summed over ranks with one RCCL all-reduce and scaled by 1 / world."""
 
     def __init__(self, model, dims, params=None, batch=128, device="cuda:0", precision="fp32", lr=1e-4, betas=(0.9, 0.999),
-                 adam_eps=1e-8, elbo_eps=1e-8, process_group=None, world=1, ksplit=0, seed=None, alpha=0.0, beta=10.0, gamma=1.0):
+                 adam_eps=1e-8, elbo_eps=1e-8, process_group=None, world=1, ksplit=0, seed=None, alpha=0.0, beta=10.0, gamma=1.0,
+                 share=None):
         if not torch.cuda.is_available():
             raise RuntimeError("Trainer needs the MI355X HIP path (no CPU fallback)")
         if not supported(model, dims):
@@ -80,19 +81,45 @@ class Trainer:
             self.plan.info_alpha, self.plan.info_beta, self.plan.info_gamma = float(alpha), float(beta), float(gamma)
         P = self.plan.n_params
         with torch.cuda.device(self.device):
-            self.params = torch.zeros(P, dtype=torch.float32, device=self.device)
-            self.m = torch.zeros(P, dtype=torch.float32, device=self.device)
-            self.v = torch.zeros(P, dtype=torch.float32, device=self.device)
+            if share is None:
+                self.params = torch.zeros(P, dtype=torch.float32, device=self.device)
+                self.m = torch.zeros(P, dtype=torch.float32, device=self.device)
+                self.v = torch.zeros(P, dtype=torch.float32, device=self.device)
+                self._shared = {"step_count": 0, "version": 0}
+            else:                       # same parameters / Adam state, another batch size (see fork())
+                self.params, self.m, self.v, self._shared = share.params, share.m, share.v, share._shared
             self.ws = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
             self.losses = torch.zeros(8 if model == "M2_info" else 3, dtype=torch.float32, device=self.device)
         go = self.plan.grad_offset_bytes
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
-        self.step_count = 0
-        if params is None:
-            params = self._reference_init(seed)
-        self._write_params(params)
+        self._copy_version = self._shared["version"]
+        if share is None:
+            if params is None:
+                params = self._reference_init(seed)
+            self._write_params(params)
         with torch.cuda.device(self.device):
             N.check(self.lib.dvae_train_init(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_init")
+
+    @property
+    def step_count(self):
+        return self._shared["step_count"]
+
+    @step_count.setter
+    def step_count(self, v):
+        self._shared["step_count"] = v
+
+    def fork(self, batch):
+        """A trainer for another batch size over the SAME parameters and Adam moments (e.g. the last, shorter
+        batch of an epoch, or the validation batch size).  Each trainer has its own kernel-layout weight copies;
+        they are refreshed automatically when the other one has stepped."""
+        return Trainer(self.model, self.dims, batch=batch, device=self.device, precision=self.precision, lr=self.lr, betas=self.betas,
+                       adam_eps=self.adam_eps, elbo_eps=self.elbo_eps, process_group=self.pg, world=self.world,
+                       alpha=self.plan.info_alpha, beta=self.plan.info_beta, gamma=self.plan.info_gamma, share=self)
+
+    def _sync_copies(self):
+        if self._copy_version != self._shared["version"]:
+            N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
+            self._copy_version = self._shared["version"]
 
     # ---- parameters under the reference's state_dict names ----
     def _reference_init(self, seed):
@@ -126,6 +153,8 @@ class Trainer:
         self._write_params(sd)
         with torch.cuda.device(self.device):
             N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
+        self._shared["version"] += 1
+        self._copy_version = self._shared["version"]
 
     def state_dict(self):
         return {name: self.tensor_view(i).clone() for i, name in enumerate(self.names)}
@@ -170,7 +199,10 @@ class Trainer:
         if self.y_dim:
             y = y if y.stride(1) == 1 else y.contiguous()
             yp, ldy = N.ptr(y), N.ld(y)
+        self._sync_copies()
         self.step_count += 1
+        self._shared["version"] += 1
+        self._copy_version = self._shared["version"]
         plan = ctypes.byref(self.plan)
         s = N.stream()
         if self.world == 1:
@@ -193,6 +225,7 @@ class Trainer:
         backward, no update.  Returns a NEW device tensor [ELBO, recon, KL] (M2_info: 8 entries)."""
         if eps_noise is None:
             eps_noise = torch.randn((self.B, 16), dtype=torch.float32, device=x.device)
+        self._sync_copies()
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         out = torch.zeros_like(self.losses)
         N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
@@ -201,6 +234,7 @@ class Trainer:
 
     def grads_only(self, x, y, eps_noise, reduce=False):
         """rows + wgrad kernels without the optimiser (tests / gradient inspection)."""
+        self._sync_copies()
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
                                           N.ptr(eps_noise.contiguous()), self.elbo_eps, 1 if reduce else 0, N.stream()), "dvae_train_grads")

@@ -139,6 +139,16 @@ int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int 
  * Declared in dvae_train.h.
  * ------------------------------------------------------------------------- */
 
+/* ---- frame store (GPU-resident replacement of HDF5CleanSpectrogramLabeledFrames, packages/data_handling.py:19-67) ----
+ * dvae_transpose: the on-disk (F, N) matrix (one frame per column, scripts/create_train_set.py:116) -> frames-major
+ *   [N][F] rows, the layout the train step reads.  rows/cols describe `in`; rows <= 2M.
+ * dvae_gather_rows: dst[i] = src[idx[i]] (epoch shuffle: what DataLoader(shuffle=True) does frame by frame,
+ *   scripts/training_M2.py:84-86).  Indices outside [0, nsrc) are skipped and counted in *bad_count (device int,
+ *   may be NULL). */
+int dvae_transpose(const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo, void* stream);
+int dvae_gather_rows(const float* src, int64_t ld, int64_t nsrc, const int64_t* idx, int64_t n, int cols, float* dst,
+                     int64_t ldd, int* bad_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
