@@ -140,8 +140,15 @@ class Trainer:
         v = self.params[o:o + r * c]
         return v.view(r, c) if self.names[i].endswith("weight") else v
 
-    def _write_params(self, sd):
+    def _write_params(self, sd, strict=True):
+        unknown = [k for k in sd if k not in self.names]
+        if strict and unknown:
+            raise KeyError(f"unexpected keys in state_dict: {unknown[:4]}")
         for i, name in enumerate(self.names):
+            if name not in sd:
+                if strict:
+                    raise KeyError(f"missing key in state_dict: {name}")
+                continue
             t = sd[name]
             t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.detach()
             view = self.tensor_view(i)
@@ -149,8 +156,10 @@ class Trainer:
                 raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(view.shape)}")
             view.copy_(t.to(torch.float32))
 
-    def load_state_dict(self, sd):
-        self._write_params(sd)
+    def load_state_dict(self, sd, strict=True):
+        """strict=False overwrites only the tensors present (the pretrain flow of
+        scripts/training_M2_info_vad_pretrain.py:102-112: `model_dict.update(filtered); load_state_dict(model_dict)`)."""
+        self._write_params(sd, strict)
         with torch.cuda.device(self.device):
             N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
         self._shared["version"] += 1
