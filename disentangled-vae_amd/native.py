@@ -43,6 +43,10 @@ SIGNATURES = {
     "dvae_istft": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dvae_transpose": (c_i, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "dvae_gather_rows": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i, c_vp, c_i64, c_vp, c_vp]),
+    "dvae_vad_workspace_bytes": (c_sz, [c_i64]),
+    "dvae_vad_labels": (c_i, [c_vp, c_i, c_i64, c_i, c_i, c_i64, c_d, c_vp, c_vp, c_vp]),
+    "dvae_ibm_workspace_bytes": (c_sz, []),
+    "dvae_ibm_labels": (c_i, [c_vp, c_i64, c_i64, c_f, c_f, c_vp, c_vp, c_vp, c_vp]),
     # include/dvae_train.h (plan pointers are passed with ctypes.byref)
     "dvae_train_plan": (c_i, [c_i, c_i, c_i, c_i64, c_i, c_vp]),
     "dvae_train_init": (c_i, [c_vp, c_vp, c_vp, c_vp]),

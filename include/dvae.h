@@ -149,6 +149,20 @@ int dvae_transpose(const float* in, int64_t rows, int64_t cols, int64_t ldi, flo
 int dvae_gather_rows(const float* src, int64_t ld, int64_t nsrc, const int64_t* idx, int64_t n, int cols, float* dst,
                      int64_t ldd, int* bad_count, void* stream);
 
+/* ---- label makers of the training-set builders (packages/processing/target.py) ----
+ * dvae_vad_labels: clean_speech_VAD (target.py:5-56, center=False): vad[t] = E[t] > 10^vad_threshold * min_t E[t],
+ *   E[t] = sum of squares of frame t (double accumulation); y: n samples (float32, or float64 when in_f64), the zero
+ *   end-pad of `hop` samples is implied (frames may reach n + hop); frames from the host-side pad rule.  vad: (frames).
+ * dvae_ibm_labels: clean_speech_IBM (target.py:58-70): mask = 20 log10(|S| + eps) > max - ibm_threshold over the whole
+ *   (rows, cols) complex64 matrix S; vad_gate (cols) or NULL multiplies each column (noise_robust_clean_speech_IBM,
+ *   target.py:72-104).  mask: (rows, cols) float32. */
+size_t dvae_vad_workspace_bytes(int64_t frames);
+int dvae_vad_labels(const void* y, int in_f64, int64_t n, int nfft, int hop, int64_t frames, double vad_threshold,
+                    float* vad, void* workspace, void* stream);
+size_t dvae_ibm_workspace_bytes(void);
+int dvae_ibm_labels(const void* S, int64_t rows, int64_t cols, float eps, float ibm_threshold, const float* vad_gate,
+                    float* mask, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

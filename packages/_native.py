@@ -32,3 +32,7 @@ def stft_host():
 
 def mcem_dev():
     return importlib.import_module("disentangled-vae_amd.mcem")
+
+
+def target_dev():
+    return importlib.import_module("disentangled-vae_amd.target")
