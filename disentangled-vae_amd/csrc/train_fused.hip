@@ -316,42 +316,43 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     double tot_rec = 0.0, tot_kl = 0.0, tot_bc = 0.0, tot_ba = 0.0;
 
     // fp32 bias table -> LDS once (epilogues must not queue global loads behind the weight prefetch).
-    // All loads are issued before the first store (clamped addresses instead of branches).
-    {
-        constexpr int NB = (Ld<T>::nbias + 255) / 256;
-        float bvv[NB];
+    // The loads are issued here (clamped addresses instead of branches); the LDS stores wait until the first
+    // tile's x loads are in flight, so the kernel's first HBM round trip carries both.
+    constexpr int NB = (Ld<T>::nbias + 255) / 256;
+    float bvv[NB];
 #pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            int i = tid + 256 * it;
-            i = i < Ld<T>::nbias ? i : Ld<T>::nbias - 1;
-            const float* src;
-            int k;
-            if (i < OB2) { src = g.b1; k = i; }
-            else if (i < OBMV) { src = g.b2; k = i - OB2; }
-            else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
-            else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
-            else if (i < OB4) { src = g.b3; k = i - OB3; }
-            else if (i < OB5) { src = g.b4; k = i - OB4; }
-            else { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
-            bvv[it] = src[k];
-        }
+    for (int it = 0; it < NB; ++it) {
+        int i = tid + 256 * it;
+        i = i < Ld<T>::nbias ? i : Ld<T>::nbias - 1;
+        const float* src;
+        int k;
+        if (i < OB2) { src = g.b1; k = i; }
+        else if (i < OBMV) { src = g.b2; k = i - OB2; }
+        else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
+        else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
+        else if (i < OB4) { src = g.b3; k = i - OB3; }
+        else if (i < OB5) { src = g.b4; k = i - OB4; }
+        else { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
+        bvv[it] = src[k];
+    }
+    auto store_bias_table = [&]() {
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
             const int i = tid + 256 * it;
             if (i < Ld<T>::nbias) Bias[i] = (i >= OB5 + XD) ? 0.f : bvv[it];
         }
-    }
-    if (INFO) {
-        for (int i = tid; i < 6 * HD + 2; i += 256) {
-            float v;
-            const int q = i / HD, k = i - q * HD;
-            if (q == 0) v = g.bc1[k]; else if (q == 1) v = g.bc2[k]; else if (q == 2) v = g.wc3[k];
-            else if (q == 3) v = g.ba1[k]; else if (q == 4) v = g.ba2[k]; else if (q == 5) v = g.wa3[k];
-            else v = k == 0 ? g.bc3[0] : g.ba3[0];
-            Bias[OI + i] = v;
+        if (INFO) {
+            for (int i = tid; i < 6 * HD + 2; i += 256) {
+                float v;
+                const int q = i / HD, k = i - q * HD;
+                if (q == 0) v = g.bc1[k]; else if (q == 1) v = g.bc2[k]; else if (q == 2) v = g.wc3[k];
+                else if (q == 3) v = g.ba1[k]; else if (q == 4) v = g.ba2[k]; else if (q == 5) v = g.wa3[k];
+                else v = k == 0 ? g.bc3[0] : g.ba3[0];
+                Bias[OI + i] = v;
+            }
         }
-    }
-    __syncthreads();
+    };
+    bool bias_pending = true;
 
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t b0 = (int64_t)tile * TB;
@@ -385,11 +386,13 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (g.fastx && full) {
             f32x4 xv[NQ513];
             tile513_issue(g.x + b0 * XD, xv, tl);
-            if constexpr (Y513 && P::EARLY_Y) {
-                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);      // y tile in flight under the x GEMM
-            }
+            if (bias_pending) { store_bias_table(); bias_pending = false; }
             tile513_commit<P, XP>(xv, U, LDU, tl, P::XFULL ? Xt : nullptr);
+            if constexpr (Y513 && P::EARLY_Y) {
+                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);      // y tile in flight under the x GEMM (requested once x has landed: the two transfers would share the HBM burst)
+            }
         } else {
+            if (bias_pending) { store_bias_table(); bias_pending = false; }
             load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, P::XFULL ? Xt : nullptr);
             if constexpr (Y513 && P::EARLY_Y) {
                 if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);
