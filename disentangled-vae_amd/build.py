@@ -42,7 +42,7 @@ def build(force=False, verbose=True):
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in deps if p.endswith((".hpp", ".h"))]):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function"] + os.environ.get("DVAE_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

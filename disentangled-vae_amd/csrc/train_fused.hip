@@ -51,29 +51,66 @@ struct RowsArgs {
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
 };
 
+#ifdef DVAE_FINE_STAMPS
+#define DVAE_FSTAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define DVAE_FSTAMP(i) do { } while (0)
+#endif
 #define DVAE_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
 
 // LDS tile [32 frames][features fbase .. fbase+31] -> fragment-major stash tile (E consecutive frames of
-// one feature = one 16-byte fragment).  Called by the wave that wrote those LDS columns.
+// one feature = one 16-byte fragment).  Called by the wave that wrote those LDS columns, with EXEC all ones.
+// bf16: the transposition is done by the LDS itself: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of
+// a 4-row x 16-column block (gfx950), so a fragment costs 2 reads instead of 8 two-byte ones.  The lane with index
+// 4q + p in its group supplies the address of row q, columns 4p .. 4p+3 of the block.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
 template <typename P>
 __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr,
-                                           int64_t b0, int l31, int h, float scale = 1.f) {
+                                           int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
     if (stash_tile_ptr == nullptr) return;
     T* dst = stash_tile_ptr + (b0 / P::KSTEP) * (64 * E) + l31 * E;
+    if constexpr (sizeof(T) == 2) {
+        const int i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
+        const T* blk = lds + q * ldl + fbase + 16 * cg + 4 * pp;
+        const bool keep = fbase + l31 < col_limit;
 #pragma unroll
-    for (int i = 0; i < TB / (2 * E); ++i) {
-        const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
-        Frag f;
+        for (int i = 0; i < TB / (2 * E); ++i) {
+            const int gq = h + 2 * i;                      // frame group: frames gq*8 .. gq*8+7
+            const s16x4 lo = lds_tr16(blk + (8 * gq) * ldl), hi = lds_tr16(blk + (8 * gq + 4) * ldl);
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            s16x8 raw = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            Frag f = __builtin_bit_cast(Frag, raw);
+            if (scale != 1.f) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const T v = lds[(gq * E + j) * ldl + fbase + l31];
-            f[j] = scale == 1.f ? v : P::cvt((float)v * scale);
+                for (int j = 0; j < E; ++j) f[j] = P::cvt((float)f[j] * scale);
+            }
+            if (!keep) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) f[j] = P::cvt(0.f);
+            }
+            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
         }
-        *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < TB / (2 * E); ++i) {
+            const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
+            Frag f;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const T v = lds[(gq * E + j) * ldl + fbase + l31];
+                f[j] = scale == 1.f ? v : P::cvt((float)v * scale);
+                if (fbase + l31 >= col_limit) f[j] = P::cvt(0.f);
+            }
+            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
+        }
     }
 }
 
@@ -134,6 +171,13 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
                                                int64_t Bp, int64_t b0, int tid) {
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
+    if constexpr (sizeof(typename P::T) == 2) {
+        // one wave per 32-feature tile (wave-uniform loop: EXEC stays all ones for the transposing reads)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        for (int ft = wave; ft < srows / 32; ft += 4)
+            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, b0, lane & 31, lane >> 5, 1.f, pcols);
+        return;
+    }
     constexpr int groups = TB / E;
     const int total = srows * groups;
     for (int idx = tid; idx < total; idx += 256) {
@@ -368,6 +412,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         asm volatile("" : "+v"(tl));
 
         DVAE_STAMP(0);
+        if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 30] = clock64();
         // reparametrisation noise of this lane's frame (wave 0 owns the latent tile): requested first,
         // long before it is needed
         float ep_r[8];
@@ -386,11 +431,11 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (g.fastx && full) {
             f32x4 xv[NQ513];
             tile513_issue(g.x + b0 * XD, xv, tl);
+            if constexpr (Y513 && P::EARLY_Y) {
+                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);      // y tile in flight under the x commit and the x GEMM
+            }
             if (bias_pending) { store_bias_table(); bias_pending = false; }
             tile513_commit<P, XP>(xv, U, LDU, tl, P::XFULL ? Xt : nullptr);
-            if constexpr (Y513 && P::EARLY_Y) {
-                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);      // y tile in flight under the x GEMM (requested once x has landed: the two transfers would share the HBM burst)
-            }
         } else {
             if (bias_pending) { store_bias_table(); bias_pending = false; }
             load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, P::XFULL ? Xt : nullptr);
@@ -450,7 +495,8 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(4);
         // ---------------- encoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+        gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4, [&]() { DVAE_FSTAMP(16); stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); DVAE_FSTAMP(17); });
+        DVAE_FSTAMP(18);
         WPre<P, HD / KS> wmv;
         WPre<P, ZD / KS> w3z;
         if (wave == 0) wprefetch<P, HD / KS>(wmv, wrs, Wmvr, S1);
@@ -459,7 +505,9 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         bias16(Bias + OB2, fb, h, bv);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + bv[r]);
+        DVAE_FSTAMP(19);
         put_lds<P>(h2r, Hb, LDH, fb, l31, h);
+        DVAE_FSTAMP(20);
         __syncthreads();
 
         DVAE_STAMP(5);
@@ -668,6 +716,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         __syncthreads();
     }
     DVAE_STAMP(15);
+    if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 31] = clock64();
     if (tid == 0) {
         g.partials[4 * blockIdx.x] = tot_rec;
         g.partials[4 * blockIdx.x + 1] = tot_kl;

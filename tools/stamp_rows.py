@@ -19,3 +19,12 @@ names = ["x load+commit+stash", "L1 x gemm", "y load+stash+L1 y gemm", "h1 epilo
 d = np.diff(s, axis=1)
 print(f"{prec} B={B} {'grads only' if noapply else 'full step'}: kernel span {s[:,15].max()-s[:,0].min():.1f} us; per-WG median {np.median(s[:,15]-s[:,0]):.1f} us; start skew {s[:,0].max()-s[:,0].min():.1f} us")
 print("  " + "  ".join(f"{n}={np.median(d[:, i]):.2f}" for i, n in enumerate(names)))
+
+if os.environ.get("DVAE_FINE"):
+    raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64) * 0.01
+    f = raw[:, [4, 16, 17, 18, 19, 20, 5]]
+    print("  L2 fine (us, median): ring filled=%.2f stash issued=%.2f gemm done=%.2f tanh done=%.2f lds put=%.2f barrier=%.2f" % tuple(np.median(np.diff(f, axis=1), axis=0)))
+
+raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64)
+cyc = raw[:, 31] - raw[:, 30]; us = (raw[:, 15] - raw[:, 0]) * 0.01
+print("  shader clock during the kernel: %.0f MHz (median over workgroups)" % np.median(cyc / us))
