@@ -85,7 +85,7 @@ template <typename T> struct Ld {
     static constexpr int hh = HD + per16;         // [frame][128]
     static constexpr int z = 32 + per16;          // [frame][32]              (z | pad, dmu | dlv)
     static constexpr int xt = 129;                // fp32 [frame][128] slice of x for the loss epilogue
-    static constexpr int nbias = 4 * HD + 32 + NO;   // b1 b2 [bmu|blv] b3 b4 b5(padded): fp32 copies for the epilogues
+    static constexpr int nbias = 4 * HD + 32 + NO + HD;   // b1 b2 [bmu|blv] b3 b4 b5(padded), last row of W5: fp32 copies for the epilogues
     static constexpr int ninfo = 6 * HD + 8;         // M2_info: bc1 bc2 wc3 ba1 ba2 wa3, bc3, ba3
     static constexpr int xf_floats = (TB * XD + 63) / 64 * 64;
     static constexpr int xt_floats = (TB * xt + 63) / 64 * 64;

@@ -39,6 +39,7 @@ struct RowsArgs {
     float invB, elbo_eps;
     const void *W1s, *W2s, *Wmvs, *W3s, *W4s, *W5s, *W5t, *W4t, *W3zt, *Wmvt, *W2t;
     const float *b1, *b2, *bmu, *blv, *b3, *b4, *b5;
+    const float* w5last;   // fp32 row 512 of the output layer (the one real feature of the 17th 32-row tile)
     void *xT, *yT, *h1T, *h2T, *dh1T, *dh2T, *dmlvT, *zT, *d1T, *d2T, *dd1T, *dd2T, *daT;
     const void* wcopy; int64_t wcopy_bytes;   // whole weight-copy buffer (one buffer descriptor)
     // M2_info (DeepGenerativeModel_v5): classifier on x, auxiliary classifier on z (both 128-128-1, relu/relu/sigmoid)
@@ -376,14 +377,15 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
         else if (i < OB4) { src = g.b3; k = i - OB3; }
         else if (i < OB5) { src = g.b4; k = i - OB4; }
-        else { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
+        else if (i < OB5 + NO) { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
+        else { src = g.w5last; k = i - OB5 - NO; }
         bvv[it] = src[k];
     }
     auto store_bias_table = [&]() {
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
             const int i = tid + 256 * it;
-            if (i < Ld<T>::nbias) Bias[i] = (i >= OB5 + XD) ? 0.f : bvv[it];
+            if (i < Ld<T>::nbias) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[it];
         }
         if (INFO) {
             for (int i = tid; i < 6 * HD + 2; i += 256) {
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             zero_acc<P>(acc);
             const WRef wr = woff(W5s, (unsigned)t * TSTEP);
             gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { if (t < 4) stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
-            if (t + 4 < NT_OUT) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
+            if (t + 4 < (P::XFULL ? NT_OUT - 1 : NT_OUT)) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
             else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
             float da[16], b5v[16], xs[16];
 #pragma unroll
@@ -617,9 +619,40 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             put_lds<P>(da, U, LDU, 32 * t, l31, h);
         };
         if (P::XFULL) {
-            // the fp32 x tile is resident in LDS ([frame][513], odd stride: conflict-free): no barriers here
+            // the fp32 x tile is resident in LDS ([frame][513], odd stride: conflict-free): no barriers here.
+            // 16 full tiles = 4 per wave.  The 17th tile holds ONE real feature (bin 512): a whole MFMA tile and
+            // epilogue round for it would be a fifth round for wave 0; wave 3 does it as a 128-term dot product instead.
 #pragma unroll 1
-            for (int t = wave_u; t < NT_OUT; t += 4) out_tile(t, Xt, XD, 32 * t, XD - 1);
+            for (int t = wave_u; t < NT_OUT - 1; t += 4) out_tile(t, Xt, XD, 32 * t, XD - 1);
+            if (wave_u == 3) {
+                const float* wl = Bias + OB5 + NO + 64 * h;                 // this half's 64 weights (LDS broadcast reads)
+                const T* drow = Hb + l31 * LDH + 64 * h;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 64 / E; ++c) {
+                    const typename P::Frag dv = *reinterpret_cast<const typename P::Frag*>(drow + c * E);
+#pragma unroll
+                    for (int j = 0; j < E; j += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + c * E + j);
+                        s = fmaf((float)dv[j], wv[0], s); s = fmaf((float)dv[j + 1], wv[1], s);
+                        s = fmaf((float)dv[j + 2], wv[2], s); s = fmaf((float)dv[j + 3], wv[3], s);
+                    }
+                }
+                s += __shfl_xor(s, 32, 64);
+                const float a = s + Bias[OB5 + XD - 1];
+                const float xv512 = Xt[l31 * XD + XD - 1];
+                const float xe = xv512 * P::exp_(-a);
+                if (h == 0) rec_lane += xe - P::log_(xv512 + g.elbo_eps) + a - 1.f;
+                const float da512 = live ? (1.f - xe) * g.invB : 0.f;
+                // columns 512 .. 543 of this frame's da row: the value, then 31 zeros (16 bf16 = 2 fragments per half)
+                typename P::Frag z0, z1;
+#pragma unroll
+                for (int j = 0; j < E; ++j) { z0[j] = P::cvt(0.f); z1[j] = P::cvt(0.f); }
+                if (h == 0) z0[0] = P::cvt(da512);
+                T* urow = U + l31 * LDU + (XD - 1) + 16 * h;
+                *reinterpret_cast<typename P::Frag*>(urow) = z0;
+                *reinterpret_cast<typename P::Frag*>(urow + E) = z1;
+            }
             __syncthreads();
         } else {
 #pragma unroll 1
@@ -1280,6 +1313,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.b1 = params + plan->tensor_offset[1]; a.b2 = params + plan->tensor_offset[3];
     a.bmu = params + plan->tensor_offset[5]; a.blv = params + plan->tensor_offset[7];
     a.b3 = params + plan->tensor_offset[9]; a.b4 = params + plan->tensor_offset[11]; a.b5 = params + plan->tensor_offset[13];
+    a.w5last = params + plan->tensor_offset[12] + (int64_t)(XD - 1) * HD;
     if (L.info) {
         a.Wc1s = WC(L.Wc1s); a.Wc2s = WC(L.Wc2s); a.Wc2t = WC(L.Wc2t); a.Wa1s = WC(L.Wa1s); a.Wa1t = WC(L.Wa1t); a.Wa2s = WC(L.Wa2s); a.Wa2t = WC(L.Wa2t);
         a.bc1 = params + plan->tensor_offset[15]; a.bc2 = params + plan->tensor_offset[17]; a.wc3 = params + plan->tensor_offset[18]; a.bc3 = params + plan->tensor_offset[19];
