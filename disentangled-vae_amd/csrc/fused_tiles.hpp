@@ -29,6 +29,7 @@ struct PolF32 {
     static constexpr int KSTEP = 8;    // reduction depth per fragment pair
     static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
     static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
+    static constexpr int PRE128 = 2;   // the same for the 128-deep layers
     static constexpr int WRING = 4;    // wgrad: k-steps of operand fragments in flight per wave
     static constexpr bool EARLY_Y = false;
     static constexpr bool XFULL = false;   // fp32 x tile does not fit LDS next to fp32 activations: streamed in 128-column slices
@@ -54,6 +55,8 @@ struct PolBF16 {
     static constexpr int KSTEP = 16;
     static constexpr int PD = 16;
     static constexpr int PRE = 6;
+    static constexpr int PRE128 = 8;   // 128-deep layers: the whole weight tile of a wave (8 fragments) is requested ahead; with 6, the
+                                       // last two arrive one L2 round trip (~0.5 us) after the GEMM starts, in every one of ~12 such phases
     static constexpr int WRING = 8;
     static constexpr bool EARLY_Y = true;   // request the y tile before the x GEMM (68 VGPRs held across it)
     static constexpr bool XFULL = true;    // whole fp32 x tile stays in LDS for the loss epilogue
@@ -97,8 +100,8 @@ __device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >
 
 // First weight fragments of a GEMM, requested ahead of time (weights never depend on data, so the
 // next layer's first fragments are in flight across the current layer's epilogue and barrier).
-template <typename P, int NSTEPS> struct WPre {
-    static constexpr int N = NSTEPS < P::PRE ? NSTEPS : P::PRE;
+template <typename P, int NSTEPS, int PREN = P::PRE> struct WPre {
+    static constexpr int N = NSTEPS < PREN ? NSTEPS : PREN;
     typename P::Frag a[N > 0 ? N : 1];
 };
 
@@ -116,10 +119,10 @@ __device__ __forceinline__ typename P::Frag wload(__amdgpu_buffer_rsrc_t rs, WRe
     return __builtin_bit_cast(typename P::Frag, v);
 }
 
-template <typename P, int NSTEPS>
-__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS>& w, __amdgpu_buffer_rsrc_t rs, WRef wr, unsigned WSTR) {
+template <typename P, int NSTEPS, int PREN>
+__device__ __forceinline__ void wprefetch(WPre<P, NSTEPS, PREN>& w, __amdgpu_buffer_rsrc_t rs, WRef wr, unsigned WSTR) {
 #pragma unroll
-    for (int i = 0; i < WPre<P, NSTEPS>::N; ++i) w.a[i] = wload<P>(rs, wr, i * WSTR);
+    for (int i = 0; i < WPre<P, NSTEPS, PREN>::N; ++i) w.a[i] = wload<P>(rs, wr, i * WSTR);
     // hipcc otherwise sinks these loads down to their first use (after the epilogue and barrier)
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -134,8 +137,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // (the previous layer's stash tile).  vmcnt retires loads and stores in issue order, so a store issued
 // right before a load that the next MFMA needs exposes a full write-acknowledge round trip; issued
 // here, the store acks overlap the D k-steps the ring already covers.
-template <typename P, int NSTEPS, typename Hook = NoHook>
-__device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w, __amdgpu_buffer_rsrc_t rs, WRef wr,
+template <typename P, int NSTEPS, typename Hook = NoHook, int PREN = P::PRE>
+__device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PREN>& w, __amdgpu_buffer_rsrc_t rs, WRef wr,
                                            const typename P::T* brow, unsigned WSTR, Hook after_fill = Hook()) {
     typedef typename P::Frag Frag;
     constexpr int STR = 2 * P::E;        // LDS activations: k-step = 2E consecutive features of a frame row
@@ -147,7 +150,7 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS>& w
     Frag a[D > 0 ? D : 1];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        if (i < WPre<P, NSTEPS>::N) a[i] = w.a[i];
+        if (i < WPre<P, NSTEPS, PREN>::N) a[i] = w.a[i];
         else a[i] = wload<P>(rs, wr, i * WSTR);
     }
     // Order pins: without them hipcc moves every weight load down to just above the MFMA that

@@ -243,7 +243,7 @@ __device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideA
     wprefetch<P, K1STEPS>(w1, wrs, a.W1, a.s1);
     zero_acc<P>(acc);
     gemm_block<P, K1STEPS>(acc, w1, wrs, a.W1, in_row, a.s1);
-    WPre<P, HD / KS> w2;
+    WPre<P, HD / KS, P::PRE128> w2;
     wprefetch<P, HD / KS>(w2, wrs, a.W2, S4);
     bias16(a.b1, fb, h, bv);
 #pragma unroll
@@ -253,7 +253,7 @@ __device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideA
     // layer 2 + output dot product
     zero_acc<P>(acc);
     gemm_block<P, HD / KS>(acc, w2, wrs, a.W2, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.h1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h); });
-    WPre<P, HD / KS> w2t;
+    WPre<P, HD / KS, P::PRE128> w2t;
     wprefetch<P, HD / KS>(w2t, wrs, a.W2t, S4);
     bias16(a.b2, fb, h, bv);
     bias16(a.w3, fb, h, w3v);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             side_mlp<P, XP / KS>(wrs, sa, Ur, Ha, Hb, red2, wave, l31, h, S4, bce_c, pc, dxc);
             acc = acc_keep;
         }
-        WPre<P, HD / KS> w2;
+        WPre<P, HD / KS, P::PRE128> w2;
         WPre<P, (YENC ? YP : 0) / KS> w1y;
         if (YENC) wprefetch<P, (YENC ? YP : 0) / KS>(w1y, wrs, woff(W1r, KB1), S4);
         else wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4, [&]() { DVAE_FSTAMP(16); stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); DVAE_FSTAMP(17); });
         DVAE_FSTAMP(18);
-        WPre<P, HD / KS> wmv;
+        WPre<P, HD / KS, P::PRE128> wmv;
         WPre<P, ZD / KS> w3z;
         if (wave == 0) wprefetch<P, HD / KS>(wmv, wrs, Wmvr, S1);
         wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
         gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (!INFO && wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h); });
-        WPre<P, HD / KS> w4;
+        WPre<P, HD / KS, P::PRE128> w4;
         if (YP > 0) {
             WPre<P, YP / KS> w3y;
             wprefetch<P, YP / KS>(w3y, wrs, woff(W3r, KB3), S4);
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- decoder layer 2 ----------------
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
-        WPre<P, HD / KS> w5;
+        WPre<P, HD / KS, P::PRE128> w5;
         wprefetch<P, HD / KS>(w5, wrs, woff(W5s, wave_u * TSTEP), S17);
         float xr[16];
         if (!P::XFULL) xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
@@ -584,11 +584,14 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         WPre<P, NO / KS> w5t;
         // one 32-feature tile t of the output layer for this wave: GEMM, loss terms, da
         auto out_tile = [&](int t, const float* xsrc, int xld, int xcol0, int xcmax) {
+            if (t == 4) DVAE_FSTAMP(21);
             zero_acc<P>(acc);
             const WRef wr = woff(W5s, (unsigned)t * TSTEP);
             gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { if (t < 4) stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+            if (t == 4) DVAE_FSTAMP(22);
             if (t + 4 < (P::XFULL ? NT_OUT - 1 : NT_OUT)) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
             else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
+            if (t == 4) DVAE_FSTAMP(23);
             float da[16], b5v[16], xs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                       // all x reads up front: one LDS wait, not sixteen
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                 xs[r] = xsrc[l31 * xld + xc];
             }
             bias16(Bias + OB5, 32 * t, h, b5v);
+            if (t == 4) DVAE_FSTAMP(24);
             const float invB_l = live ? g.invB : 0.f;            // frames past B contribute nothing
             if (t < NT_OUT - 1) {                                // all 32 features of the tile exist
 #pragma unroll
@@ -616,7 +620,9 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
                     da[r] = ok ? (1.f - xe) * invB_l : 0.f;
                 }
             }
+            if (t == 4) DVAE_FSTAMP(25);
             put_lds<P>(da, U, LDU, 32 * t, l31, h);
+            if (t == 4) DVAE_FSTAMP(26);
         };
         if (P::XFULL) {
             // the fp32 x tile is resident in LDS ([frame][513], odd stride: conflict-free): no barriers here.
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         gemm_block<P, NO / KS>(acc, w5t, wrs, W5tr, Ur, S4, [&]() {
             for (int t = wave; t < NT_OUT; t += 4) stash_tile<P>(U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT + (int64_t)(t) * 32 * g.Bp, b0, l31, h);
         });
-        WPre<P, HD / KS> w4t;
+        WPre<P, HD / KS, P::PRE128> w4t;
         wprefetch<P, HD / KS>(w4t, wrs, W4tr, S4);
         float dv[16];
 #pragma unroll
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- backward: d1 <- dpre_d2 ----------------
         zero_acc<P>(acc);
         gemm_block<P, HD / KS>(acc, w4t, wrs, W4tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
-        WPre<P, HD / KS> w3zt;
+        WPre<P, HD / KS, P::PRE128> w3zt;
         WPre<P, 32 / KS> wmvt;
         if (wave == 0) wprefetch<P, HD / KS>(w3zt, wrs, W3ztr, S1);
         wprefetch<P, 32 / KS>(wmvt, wrs, Wmvtr, S4);
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
         zero_acc<P>(acc);
         gemm_block<P, 32 / KS>(acc, wmvt, wrs, Wmvtr, Zbr, S4, [&]() { if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, b0, l31, h); });
-        WPre<P, HD / KS> w2t;
+        WPre<P, HD / KS, P::PRE128> w2t;
         wprefetch<P, HD / KS>(w2t, wrs, W2tr, S4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);

@@ -23,6 +23,8 @@ print("  " + "  ".join(f"{n}={np.median(d[:, i]):.2f}" for i, n in enumerate(nam
 if os.environ.get("DVAE_FINE"):
     raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64) * 0.01
     f = raw[:, [4, 16, 17, 18, 19, 20, 5]]
+    f2 = raw[:, [21, 22, 23, 24, 25, 26]]
+    print("  out tile 4 (wave 0, us): gemm=%.2f prefetch=%.2f x+bias lds reads=%.2f epilogue math=%.2f put=%.2f" % tuple(np.median(np.diff(f2, axis=1), axis=0)))
     print("  L2 fine (us, median): ring filled=%.2f stash issued=%.2f gemm done=%.2f tanh done=%.2f lds put=%.2f barrier=%.2f" % tuple(np.median(np.diff(f, axis=1), axis=0)))
 
 raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64)
