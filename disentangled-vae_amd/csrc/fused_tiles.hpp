@@ -57,7 +57,10 @@ struct PolBF16 {
     static constexpr int PRE = 6;
     static constexpr int PRE128 = 8;   // 128-deep layers: the whole weight tile of a wave (8 fragments) is requested ahead; with 6, the
                                        // last two arrive one L2 round trip (~0.5 us) after the GEMM starts, in every one of ~12 such phases
-    static constexpr int WRING = 8;
+#ifndef DVAE_WRING_BF16
+#define DVAE_WRING_BF16 8
+#endif
+    static constexpr int WRING = DVAE_WRING_BF16;
     static constexpr bool EARLY_Y = true;   // request the y tile before the x GEMM (68 VGPRs held across it)
     static constexpr bool XFULL = true;    // whole fp32 x tile stays in LDS for the loss epilogue
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {

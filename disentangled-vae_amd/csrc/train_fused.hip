@@ -858,8 +858,11 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
 // grid.x = workgroups * ksplit with the k-slice as the FAST index: consecutive workgroups (dealt
 // round-robin to the 8 XCDs) work on different frame slices, so each XCD's L2 mostly holds one
 // slice of the stash.  blockDim.x / 64 groups per workgroup.
+#ifndef DVAE_WGRAD_OCC
+#define DVAE_WGRAD_OCC 1
+#endif
 template <typename P>
-__global__ __launch_bounds__(256) void wgrad_kernel(const GroupDesc* __restrict__ groups, int ngroups, int ksplit, int64_t Bp,
+__global__ __launch_bounds__(256, DVAE_WGRAD_OCC) void wgrad_kernel(const GroupDesc* __restrict__ groups, int ngroups, int ksplit, int64_t Bp,
                                                     int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
