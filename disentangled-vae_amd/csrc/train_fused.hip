@@ -129,36 +129,41 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
     }
 }
 
-// dense 513-column tile: the 32 rows are ONE contiguous 16-byte aligned block of 4104 float4
-constexpr int NV513 = TB * XD / 4;
-constexpr int NQ513 = (NV513 + 255) / 256;       // 17 float4 per thread
+// dense 513-column tile (32 rows back to back in memory).  Thread t takes the 4-column chunks c = t + 256 i
+// (i < 16): row c >> 7, columns 4 (c & 127) .. +3 -- shifts only, and the LDS image row U[row][col .. col+3] is
+// one aligned 8-byte store.  The global address (row * 513 + col floats) is only 4-byte aligned: gfx950 takes
+// dwordx4 loads at dword alignment.  Column 512 of row (t & 31) rides in slot 16.
+constexpr int NQ513 = 17;
+struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
 __device__ __forceinline__ void tile513_issue(const float* __restrict__ tile, f32x4 (&v)[NQ513], int tid) {
 #pragma unroll
-    for (int i = 0; i < NQ513; ++i) {
-        int q = tid + 256 * i;
-        q = q < NV513 ? q : NV513 - 1;            // clamp instead of branching around the load
-        v[i] = reinterpret_cast<const f32x4*>(tile)[q];
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = reinterpret_cast<const F4U*>(tile + (c >> 7) * XD + 4 * (c & 127))->v;
     }
+    v[16][0] = tile[(tid & 31) * XD + XD - 1];
     __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
 }
 template <typename P, int PCOLS>
 __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr) {
+    typedef typename P::Pack4 Pack4;
 #pragma unroll
-    for (int i = 0; i < NQ513; ++i) {
-        const int q = tid + 256 * i;
-        if (q < NV513) {
-            if (xf) reinterpret_cast<f32x4*>(xf)[q] = v[i];       // dense [frame][513] fp32 copy
-            const int base = 4 * q;
-            const int row = base / XD, col = base - row * XD;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                int c = col + jj, r = row;
-                if (c >= XD) { c -= XD; r += 1; }
-                U[r * ldu + c] = P::cvt(v[i][jj]);
-            }
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 7, col = 4 * (c & 127);
+        if (xf) {                                              // dense [frame][513] fp32 copy (rows 4-byte aligned)
+            float* d = xf + row * XD + col;
+            d[0] = v[i][0]; d[1] = v[i][1]; d[2] = v[i][2]; d[3] = v[i][3];
         }
+        Pack4 pk;
+        pk[0] = P::cvt(v[i][0]); pk[1] = P::cvt(v[i][1]); pk[2] = P::cvt(v[i][2]); pk[3] = P::cvt(v[i][3]);
+        *reinterpret_cast<Pack4*>(U + row * ldu + col) = pk;
     }
-    constexpr int PADC = PCOLS - XD;
+    constexpr int PADC = PCOLS - XD;                            // column 512, then PADC zero columns
+    if (tid < TB) {
+        if (xf) xf[tid * XD + XD - 1] = v[16][0];
+        U[tid * ldu + XD - 1] = P::cvt(v[16][0]);
+    }
     for (int idx = tid; idx < TB * PADC; idx += 256) {
         const int r = idx / PADC, c = XD + idx - r * PADC;
         U[r * ldu + c] = P::cvt(0.f);
