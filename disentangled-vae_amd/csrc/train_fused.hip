@@ -953,19 +953,36 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     }
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= g.n_params) return;
+    // Everything this thread reads sits at flat index idx (alignment padding between tensors included, the buffers
+    // are allocated whole): request it all FIRST, so the two dependent table lookups below (chunk -> tensor ->
+    // descriptor) overlap the one HBM round trip instead of preceding it.
+    float pi = g.p[idx];
+    float m_old = 0.f, v_old = 0.f, gi = 0.f;
+    if (ADAM) {
+        m_old = g.m[idx]; v_old = g.v[idx];
+        constexpr int NS = 8;
+        if (g.nslabs <= NS) {
+            float part[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) part[k] = g.slabs[(k < g.nslabs ? k : 0) * g.slab_stride + idx];   // independent loads
+            gi = part[0];
+#pragma unroll
+            for (int k = 1; k < NS; ++k) if (k < g.nslabs) gi += part[k];                                    // fixed order: deterministic
+        } else {
+            gi = g.slabs[idx];
+            for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
+        }
+    }
     const int t = g.chunk_tensor[idx >> 6];
     if (t == 255) return;
     const TensorDesc d = g.tensors[t];
     const int64_t i = idx - d.off;
     if (i >= (int64_t)d.rows * d.cols) return;
     T* wc = (T*)g.wcopy;
-    float pi = g.p[idx];
     if (ADAM) {
-        float gi = g.slabs[idx];
-        for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
         gi *= g.gscale;
-        const float mi = g.m[idx] + g.one_minus_b1 * (gi - g.m[idx]);
-        const float vi = g.v[idx] * g.b2 + g.one_minus_b2 * (gi * gi);
+        const float mi = m_old + g.one_minus_b1 * (gi - m_old);
+        const float vi = v_old * g.b2 + g.one_minus_b2 * (gi * gi);
         const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
         pi = pi - g.step_size * (mi / denom);
         g.p[idx] = pi; g.m[idx] = mi; g.v[idx] = vi;
