@@ -30,11 +30,42 @@ namespace dvae {
 namespace fused {
 
 
+// Philox4x32-10 (Salmon et al., SC'11) -> four standard normals by Box-Muller.  Counter = (frame lo, frame hi, step lo,
+// step hi << 8 | draw), key = seed: every frame of every step has its own stream, independent of tiling and grid.
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long frame, unsigned long long step, unsigned draw,
+                                               float (&out)[4]) {
+    unsigned c0 = (unsigned)frame, c1 = (unsigned)(frame >> 32), c2 = (unsigned)step, c3 = ((unsigned)(step >> 32) << 8) | draw;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float ra = sqrtf(-2.f * __logf(u0)), rb = sqrtf(-2.f * __logf(u2));
+    float sa, ca, sb, cb;
+    __sincosf(6.283185307179586f * u1, &sa, &ca);
+    __sincosf(6.283185307179586f * u3, &sb, &cb);
+    out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
+}
+// noise of latent features 4h .. 4h+3 (draw 2h) and 8+4h .. 8+4h+3 (draw 2h+1) of one frame: the C-tile ownership of wave 0
+__device__ __forceinline__ void frame_noise8(unsigned long long seed, unsigned long long frame, unsigned long long step, int h, float (&e)[8]) {
+    float a[4], b[4];
+    philox_normal4(seed, frame, step, 2u * h, a);
+    philox_normal4(seed, frame, step, 2u * h + 1u, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { e[j] = a[j]; e[4 + j] = b[j]; }
+}
+
 struct RowsArgs {
     const float* x; const float* y; const float* eps;
     int ldx, ldy, ydim;
     int fastx, fasty;      // rows are dense (ld == 513) and 16-byte aligned: whole-tile vector loads
     int64_t B, Bp;
+    unsigned long long rng_seed, rng_step;   // in-kernel reparametrisation noise (eps == nullptr)
     int ntiles;
     float invB, elbo_eps;
     const void *W1s, *W2s, *Wmvs, *W3s, *W4s, *W5s, *W5t, *W4t, *W3zt, *Wmvt, *W2t;
@@ -425,10 +456,16 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         float ep_r[8];
         if (wave == 0) {
             int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1;
-            const f32x4 e0 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 4 * h);
-            const f32x4 e1 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 8 + 4 * h);
+            if (g.eps != nullptr) {
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 4 * h);
+                const f32x4 e1 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 8 + 4 * h);
 #pragma unroll
-            for (int jq = 0; jq < 4; ++jq) { ep_r[jq] = live ? e0[jq] : 0.f; ep_r[4 + jq] = live ? e1[jq] : 0.f; }
+                for (int jq = 0; jq < 4; ++jq) { ep_r[jq] = live ? e0[jq] : 0.f; ep_r[4 + jq] = live ? e1[jq] : 0.f; }
+            } else {                                             // drawn here: no noise tensor, no extra launch
+                frame_noise8(g.rng_seed, (unsigned long long)br, g.rng_step, h, ep_r);
+#pragma unroll
+                for (int jq = 0; jq < 8; ++jq) ep_r[jq] = live ? ep_r[jq] : 0.f;
+            }
         }
         // ---------------- encoder layer 1: [x | y] -> h1 ----------------
         WPre<P, XP / KS> w1x;
@@ -914,7 +951,7 @@ struct ApplyArgs {
     const unsigned char* chunk_tensor; int64_t n_params;
     void* wcopy;
     float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
-    const double* partials; int npartials; int64_t B; float* losses3;
+    const double* partials; int npartials; int64_t B; float* losses3; double* accum;
     int info; float alpha, beta, gamma;
 };
 
@@ -938,6 +975,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
             const float recon = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)g.B);
             const float kl = (float)((red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (double)g.B);
             g.losses3[0] = recon + kl; g.losses3[1] = recon; g.losses3[2] = kl;
+            if (g.accum) { g.accum[0] += (double)(recon + kl); g.accum[1] += (double)recon; g.accum[2] += (double)kl; }
             if (g.info) {   // scripts/training_M2_info_vad.py:162-183
                 const float bc = (float)((red[0][2] + red[1][2] + red[2][2] + red[3][2]) / (double)g.B);
                 const float ba = (float)((red[0][3] + red[1][3] + red[2][3] + red[3][3]) / (double)g.B);
@@ -947,6 +985,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
                 g.losses3[5] = g.gamma * ba;                          // aux_loss
                 g.losses3[6] = aux_enc;
                 g.losses3[7] = 0.f;
+                if (g.accum) for (int q = 3; q < 8; ++q) g.accum[q] += (double)g.losses3[q];
             }
         }
         return;
@@ -1066,7 +1105,8 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
 }
 
 static bool g_prof = false;
-static thread_local bool g_eval_only = false;   // dvae_train_eval: skip the wgrad launch
+static thread_local bool g_eval_only = false;
+static thread_local long long g_rng_step_override = -1;   // dvae_train_step: its `step` argument numbers the noise draw   // dvae_train_eval: skip the wgrad launch
 static unsigned long long* g_dbg = nullptr;   // set by dvae_train_debug_stamps
 static double g_ms[4] = {0, 0, 0, 0};
 static int64_t g_calls[4] = {0, 0, 0, 0};
@@ -1254,7 +1294,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
         a.one_minus_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2);
         a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)adam_eps; a.gscale = (float)grad_scale;
     }
-    a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3;
+    a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3; a.accum = (double*)(uintptr_t)plan->loss_accum;
     a.info = plan->model == DVAE_MODEL_M2_INFO; a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
     const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
     if (plan->precision == DVAE_PREC_BF16) {
@@ -1322,7 +1362,7 @@ static int launch_rows(const RowsArgs& a, int grid, hipStream_t s) {
 
 extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                                 const float* y, int ldy, const float* eps_noise, float elbo_eps, int reduce_slabs, void* stream) {
-    DVAE_CHECK_ARG(plan && params && ws && x && eps_noise && ldx >= XD, "train_grads: bad argument");
+    DVAE_CHECK_ARG(plan && params && ws && x && ldx >= XD, "train_grads: bad argument");
     DVAE_CHECK_ARG(plan->y_dim == 0 || (y != nullptr && ldy >= plan->y_dim), "train_grads: y missing or ldy < y_dim");
     Layout L;
     make_layout(*plan, L);
@@ -1332,6 +1372,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     const int esz = bf ? 2 : 4;
     RowsArgs a;
     memset(&a, 0, sizeof(a));
+    a.rng_seed = plan->rng_seed; a.rng_step = g_rng_step_override >= 0 ? (unsigned long long)g_rng_step_override : plan->rng_step;
     a.x = x; a.y = y; a.eps = eps_noise; a.ldx = ldx; a.ldy = plan->y_dim ? ldy : 0; a.ydim = plan->y_dim;
     a.fastx = (ldx == XD) && (((uintptr_t)x & 15) == 0);
     a.fasty = (plan->y_dim == XD) && (ldy == XD) && (((uintptr_t)y & 15) == 0);
@@ -1424,7 +1465,9 @@ extern "C" int dvae_train_apply(const dvae_train_plan_t* plan, float* params, fl
 extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws,
                                const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
                                int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream) {
+    g_rng_step_override = step;
     int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, elbo_eps, 0, stream);
+    g_rng_step_override = -1;
     if (rc) return rc;
     return dvae_train_apply(plan, params, m, v, ws, 0, step, lr, beta1, beta2, adam_eps, 1.0, losses3, stream);
 }
@@ -1436,7 +1479,7 @@ extern "C" int dvae_train_debug_stamps(void* buf) {
 
 extern "C" int dvae_train_eval(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                                const float* y, int ldy, const float* eps_noise, float elbo_eps, float* losses3, void* stream) {
-    DVAE_CHECK_ARG(plan && params && ws && x && eps_noise && losses3, "train_eval: bad argument");
+    DVAE_CHECK_ARG(plan && params && ws && x && losses3, "train_eval: bad argument");
     // forward + loss sums only: the rows kernel also writes the stash, which is simply not consumed
     Layout L;
     make_layout(*plan, L);
@@ -1450,10 +1493,30 @@ extern "C" int dvae_train_eval(const dvae_train_plan_t* plan, const float* param
     ApplyArgs a;
     memset(&a, 0, sizeof(a));
     char* w = (char*)ws;
-    a.partials = (const double*)(w + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3;
+    a.partials = (const double*)(w + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3; a.accum = (double*)(uintptr_t)plan->loss_accum;
     a.info = plan->model == DVAE_MODEL_M2_INFO; a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
     hipLaunchKernelGGL((apply_kernel<float, true>), dim3(1), dim3(256), 0, (hipStream_t)stream, a);   // grid of 1 = the loss block only
     DVAE_LAUNCH_OK("apply_kernel(loss only)");
+    return 0;
+}
+
+namespace dvae { namespace fused {
+__global__ __launch_bounds__(256) void noise_kernel(unsigned long long seed, unsigned long long step, int64_t B, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one (frame, half) pair per thread
+    if (i >= 2 * B) return;
+    const int64_t frame = i >> 1; const int h = (int)(i & 1);
+    float e[8];
+    frame_noise8(seed, (unsigned long long)frame, step, h, e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[frame * ZD + 4 * h + j] = e[j]; out[frame * ZD + 8 + 4 * h + j] = e[4 + j]; }
+}
+} }
+
+extern "C" int dvae_train_noise(const dvae_train_plan_t* plan, uint64_t step, float* eps_out, void* stream) {
+    DVAE_CHECK_ARG(plan && eps_out, "train_noise: null argument");
+    hipLaunchKernelGGL(dvae::fused::noise_kernel, dim3((unsigned)((2 * plan->B + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)plan->rng_seed, (unsigned long long)step, plan->B, eps_out);
+    DVAE_LAUNCH_OK("noise_kernel");
     return 0;
 }
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "dvae_train_apply": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_vp, c_vp]),
     "dvae_train_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_d, c_d, c_d, c_d, c_vp, c_vp]),
     "dvae_train_eval": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_vp, c_vp]),
+    "dvae_train_noise": (c_i, [c_vp, ctypes.c_uint64, c_vp, c_vp]),
     "dvae_train_profile": (c_i, [c_i]),
     "dvae_train_debug_stamps": (c_i, [c_vp]),
     "dvae_train_profile_read": (c_i, [c_vp, c_vp]),

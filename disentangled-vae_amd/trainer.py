@@ -24,7 +24,8 @@ class TrainPlan(ctypes.Structure):
                 ("tensor_offset", ctypes.c_int64 * MAXT), ("tensor_rows", ctypes.c_int32 * MAXT), ("tensor_cols", ctypes.c_int32 * MAXT),
                 ("workspace_bytes", ctypes.c_int64), ("grad_offset_bytes", ctypes.c_int64), ("Bp", ctypes.c_int64),
                 ("rows_grid", ctypes.c_int64), ("flops_per_step", ctypes.c_double), ("min_hbm_bytes_per_step", ctypes.c_double),
-                ("info_alpha", ctypes.c_double), ("info_beta", ctypes.c_double), ("info_gamma", ctypes.c_double)]
+                ("info_alpha", ctypes.c_double), ("info_beta", ctypes.c_double), ("info_gamma", ctypes.c_double),
+                ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64), ("loss_accum", ctypes.c_uint64)]
 
 
 MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3}
@@ -93,6 +94,9 @@ class Trainer:
         go = self.plan.grad_offset_bytes
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
         self._copy_version = self._shared["version"]
+        rank = torch.distributed.get_rank(process_group) if (process_group is not None and torch.distributed.is_initialized()) else 0
+        base = int(seed) if seed is not None else (share.plan.rng_seed if share is not None else int(torch.initial_seed()))
+        self.plan.rng_seed = (base + (0 if share is not None else rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
         if share is None:
             if params is None:
                 params = self._reference_init(seed)
@@ -197,19 +201,19 @@ class Trainer:
         B = self.B
         if x.shape != (B, 513) or x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError(f"x must be a float32 CUDA tensor [{B}, 513]")
-        if eps_noise is None:
-            eps_noise = torch.randn((B, 16), dtype=torch.float32, device=x.device)
         if self.y_dim:
             if y is None or y.shape != (B, self.y_dim) or y.dtype != torch.float32:
                 raise ValueError(f"y must be a float32 CUDA tensor [{B}, {self.y_dim}]")
         x = x if x.stride(1) == 1 else x.contiguous()
-        eps_noise = eps_noise.contiguous()
+        if eps_noise is not None:           # None: the rows kernel draws the noise itself (Philox, see noise())
+            eps_noise = eps_noise.contiguous()
         yp, ldy = (None, 0)
         if self.y_dim:
             y = y if y.stride(1) == 1 else y.contiguous()
             yp, ldy = N.ptr(y), N.ld(y)
         self._sync_copies()
         self.step_count += 1
+        self.plan.rng_step = self.step_count
         self._shared["version"] += 1
         self._copy_version = self._shared["version"]
         plan = ctypes.byref(self.plan)
@@ -232,13 +236,30 @@ class Trainer:
     def evaluate(self, x, y=None, eps_noise=None):
         """Validation pass (scripts/training_M2.py:176-193): forward + elbo on a batch of the trainer's size, no
         backward, no update.  Returns a NEW device tensor [ELBO, recon, KL] (M2_info: 8 entries)."""
-        if eps_noise is None:
-            eps_noise = torch.randn((self.B, 16), dtype=torch.float32, device=x.device)
         self._sync_copies()
+        if eps_noise is None:               # drawn in the kernel, from a counter range the training steps never reach
+            self._shared["eval_count"] = self._shared.get("eval_count", 0) + 1
+            self.plan.rng_step = (1 << 40) + self._shared["eval_count"]
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         out = torch.zeros_like(self.losses)
         N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
-                                         N.ptr(eps_noise.contiguous()), self.elbo_eps, N.ptr(out), N.stream()), "dvae_train_eval")
+                                         N.ptr(None if eps_noise is None else eps_noise.contiguous()), self.elbo_eps, N.ptr(out), N.stream()),
+                "dvae_train_eval")
+        return out
+
+    def accumulate_losses(self, buf):
+        """Running sums for epoch logging without a host sync per step: `buf` is a float64 CUDA tensor of 8 elements
+        (or None to stop); every step() / evaluate() adds its loss scalars to it on the device."""
+        if buf is not None and not (buf.is_cuda and buf.dtype == torch.float64 and buf.numel() >= 8 and buf.is_contiguous()):
+            raise ValueError("accumulate_losses: need a contiguous float64 CUDA tensor with >= 8 elements")
+        self._accum = buf
+        self.plan.loss_accum = 0 if buf is None else buf.data_ptr()
+
+    def noise(self, step):
+        """The [B, 16] reparametrisation noise the rows kernel draws for training step `step` (1-based) when no
+        eps_noise is passed: Philox4x32-10 keyed by the trainer's seed (and rank), counter (frame, step)."""
+        out = torch.empty((self.B, 16), dtype=torch.float32, device=self.device)
+        N.check(self.lib.dvae_train_noise(ctypes.byref(self.plan), int(step), N.ptr(out), N.stream()), "dvae_train_noise")
         return out
 
     def grads_only(self, x, y, eps_noise, reduce=False):

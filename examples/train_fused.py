@@ -32,8 +32,9 @@ def synthetic(n, y_dim, seed):
 
 
 def run_epoch(data, trainers, train, shuffle):   # trainers: [main, optional fork for the last, shorter batch]
-    """One pass; returns mean (ELBO, recon, KL) over batches like the scripts (sum of batch means / number of batches)."""
-    tot = torch.zeros(3, dtype=torch.float64, device=data.device)
+    """One pass; returns mean (ELBO, recon, KL) over batches like the scripts (sum of batch means / number of batches).
+    The sums are kept on the device by the step itself: no host sync, no extra kernels per step."""
+    tot = torch.zeros(8, dtype=torch.float64, device=data.device)
     nb = 0
     for x, y in data.batches(trainers[0].B, shuffle=shuffle):
         tr = trainers[0]
@@ -41,10 +42,12 @@ def run_epoch(data, trainers, train, shuffle):   # trainers: [main, optional for
             if len(trainers) == 1 or trainers[1].B != x.shape[0]:
                 trainers[1:] = [tr.fork(x.shape[0])]
             tr = trainers[1]
-        out = tr.step(x, y) if train else tr.evaluate(x, y)
-        tot += out[:3].double()
+        tr.accumulate_losses(tot)
+        tr.step(x, y) if train else tr.evaluate(x, y)
         nb += 1
-    return (tot / nb).cpu().tolist()
+    for tr in trainers:
+        tr.accumulate_losses(None)
+    return (tot[:3] / nb).cpu().tolist()
 
 
 def main():

@@ -57,6 +57,15 @@ typedef struct {
        - beta*BCE(aux(z), y), aux_loss = gamma*BCE(aux(z.detach()), y).  dvae_train_plan sets the script's
        defaults (0, 10, 1); the caller may overwrite them before dvae_train_init. */
     double  info_alpha, info_beta, info_gamma;
+    /* Reparametrisation noise drawn inside the rows kernel when eps_noise == NULL: Philox4x32-10 keyed by rng_seed,
+       counter (frame index, rng_step, draw); standard normals by Box-Muller.  The caller bumps rng_step every step
+       (dvae_train_step uses its `step` argument instead).  dvae_train_noise reproduces the same numbers. */
+    uint64_t rng_seed;
+    uint64_t rng_step;
+    /* Optional running sums for epoch logging (the scripts' `total_elbo += loss.item()`, training_M2.py:148-150, without a
+       device-to-host sync per step): device pointer to 8 doubles, or 0.  dvae_train_apply / dvae_train_eval add the
+       step's loss scalars (same order as losses3) to it. */
+    uint64_t loss_accum;
 } dvae_train_plan_t;
 
 /* Fill `plan` for (model, y_dim, precision, B).  ksplit_hint 0 = choose.  Returns DVAE_E_UNSUPPORTED
@@ -68,7 +77,8 @@ int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_h
 int dvae_train_init(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream);
 
 /* rows kernel + wgrad kernel (+ slab reduction into slab 0 when reduce_slabs != 0).
- * x [B, 513] (ldx), y [B, y_dim] (ldy, may be NULL for M1), eps_noise [B, 16]: fp32 device tensors.
+ * x [B, 513] (ldx), y [B, y_dim] (ldy, may be NULL for M1), eps_noise [B, 16]: fp32 device tensors; eps_noise NULL = draw
+ * the noise in the kernel (the reference draws torch.randn(mu.size()) on the host and copies it, models.py:10-13).
  * elbo_eps is the `eps` of elbo(x, r, mu, logvar, eps) (packages/models/utils.py:73). */
 int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                      const float* y, int ldy, const float* eps_noise, float elbo_eps, int reduce_slabs, void* stream);
@@ -89,6 +99,9 @@ int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, floa
  * rows kernel + loss finalisation only.  losses3 as for dvae_train_apply. */
 int dvae_train_eval(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                     const float* y, int ldy, const float* eps_noise, float elbo_eps, float* losses3, void* stream);
+
+/* The [B, 16] standard normals the rows kernel draws for (plan->rng_seed, step) when eps_noise == NULL. */
+int dvae_train_noise(const dvae_train_plan_t* plan, uint64_t step, float* eps_out, void* stream);
 
 /* Rebuild the kernel-layout weight copies after `params` was written from outside (load_state_dict). */
 int dvae_train_repack(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream);

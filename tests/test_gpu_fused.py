@@ -251,3 +251,55 @@ def test_evaluate_is_forward_only_and_matches_step_losses():
     out, _ = vo.vae_loss_and_grads("M2", {k: v.astype(np.float64) for k, v in params.items()}, x.astype(np.float64),
                                    y.astype(np.float64), e.astype(np.float64))
     np.testing.assert_allclose(ev, [out["loss"], out["recon"], out["kl"]], rtol=1e-4)
+
+
+def test_in_kernel_noise_is_standard_normal_and_reproducible():
+    from scipy import stats
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    tr = trainer.Trainer("M2", dims, batch=4096, precision="fp32", seed=7)
+    n1, n2 = tr.noise(1).cpu().numpy(), tr.noise(2).cpu().numpy()
+    assert n1.shape == (4096, 16) and np.isfinite(n1).all()
+    assert np.array_equal(n1, tr.noise(1).cpu().numpy())                      # a pure function of (seed, step, frame)
+    assert not np.array_equal(n1, n2)
+    flat = np.concatenate([n1.ravel(), n2.ravel()])
+    assert abs(flat.mean()) < 0.01 and abs(flat.std() - 1) < 0.01
+    assert stats.kstest(flat, "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(n1.ravel(), n2.ravel())[0, 1]) < 0.02             # steps are independent streams
+    assert abs(np.corrcoef(n1[:, 0], n1[:, 1])[0, 1]) < 0.05                  # so are latent dimensions
+    other = trainer.Trainer("M2", dims, batch=4096, precision="fp32", seed=8).noise(1).cpu().numpy()
+    assert not np.array_equal(n1, other)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_step_without_noise_tensor_equals_step_on_the_drawn_noise(precision):
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 3)
+    x, y, _ = gu.make_batch(dims, 200, 4)
+    t = lambda a: torch.from_numpy(a).cuda()
+    a = trainer.Trainer("M2", dims, params, batch=200, precision=precision, seed=11)
+    b = trainer.Trainer("M2", dims, params, batch=200, precision=precision, seed=11)
+    for step in (1, 2):
+        la = a.step(t(x), t(y)).clone()                                       # noise drawn inside the rows kernel
+        lb = b.step(t(x), t(y), b.noise(step)).clone()                        # the same numbers, passed in
+        assert torch.equal(la, lb)
+    assert torch.equal(a.params, b.params)
+    e1, e2 = a.evaluate(t(x), t(y)), a.evaluate(t(x), t(y))
+    assert not torch.equal(e1, e2)                                            # validation noise advances too
+
+
+def test_device_side_loss_accumulation():
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    tr = trainer.Trainer("M2", dims, batch=96, precision="fp32", seed=2)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    acc = torch.zeros(8, dtype=torch.float64, device="cuda")
+    tr.accumulate_losses(acc)
+    want = np.zeros(3)
+    for _ in range(5):
+        x = torch.rand(96, 513, device="cuda", generator=g) + 0.01
+        y = (torch.rand(96, 1, device="cuda", generator=g) > 0.5).float()
+        want += tr.step(x, y).cpu().numpy()[:3].astype(np.float64)
+    want += tr.evaluate(x, y).cpu().numpy()[:3].astype(np.float64)
+    np.testing.assert_allclose(acc.cpu().numpy()[:3], want, rtol=1e-12)
+    tr.accumulate_losses(None)
+    tr.step(x, y)
+    np.testing.assert_allclose(acc.cpu().numpy()[:3], want, rtol=1e-12)     # detached: no more additions
