@@ -66,6 +66,7 @@ struct RowsArgs {
     int fastx, fasty;      // rows are dense (ld == 513) and 16-byte aligned: whole-tile vector loads
     int64_t B, Bp;
     unsigned long long rng_seed, rng_step;   // in-kernel reparametrisation noise (eps == nullptr)
+    const int64_t* rows;                      // optional gather: frame b of the step is row rows[b] of x / y (epoch shuffle without a copy)
     int ntiles;
     float invB, elbo_eps;
     const void *W1s, *W2s, *Wmvs, *W3s, *W4s, *W5s, *W5t, *W4t, *W3zt, *Wmvt, *W2t;
@@ -147,14 +148,14 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
 }
 
 // generic (edge tile / strided / unaligned input): global [32 frames][ncols] fp32 -> LDS as T, zero padded
-template <typename P>
+template <typename P, typename RowOf>
 __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, int ld, int ncols, int pcols, int64_t b0, int64_t B,
-                                                 typename P::T* U, int ldu, int tid, float* xf = nullptr) {
+                                                 typename P::T* U, int ldu, int tid, RowOf rowof, float* xf = nullptr) {
     const int total = TB * pcols;
     for (int idx = tid; idx < total; idx += 256) {
         const int row = idx / pcols, col = idx - row * pcols;
         float v = 0.f;
-        if (col < ncols && b0 + row < B) v = src[(b0 + row) * ld + col];
+        if (col < ncols && b0 + row < B) v = src[rowof(row) * ld + col];
         U[row * ldu + col] = P::cvt(v);
         if (xf && col < ncols) xf[row * ncols + col] = v;
     }
@@ -166,13 +167,14 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
 // dwordx4 loads at dword alignment.  Column 512 of row (t & 31) rides in slot 16.
 constexpr int NQ513 = 17;
 struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
-__device__ __forceinline__ void tile513_issue(const float* __restrict__ tile, f32x4 (&v)[NQ513], int tid) {
+template <typename RowOf>
+__device__ __forceinline__ void tile513_issue(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = tid + 256 * i;
-        v[i] = reinterpret_cast<const F4U*>(tile + (c >> 7) * XD + 4 * (c & 127))->v;
+        v[i] = reinterpret_cast<const F4U*>(base + rowof(c >> 7) * XD + 4 * (c & 127))->v;
     }
-    v[16][0] = tile[(tid & 31) * XD + XD - 1];
+    v[16][0] = base[rowof(tid & 31) * XD + XD - 1];
     __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
 }
 template <typename P, int PCOLS>
@@ -227,14 +229,14 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
 }
 
 // x[32 frames][f0 .. f0+127] (fp32) for the loss epilogue: 16 coalesced dwords per thread, addresses clamped
-__device__ __forceinline__ void xt_issue(const float* __restrict__ x, int ldx, int64_t b0, int64_t B, int f0, float (&xr)[16], int tid) {
+template <typename RowOf>
+__device__ __forceinline__ void xt_issue(const float* __restrict__ x, int ldx, RowOf rowof, int f0, float (&xr)[16], int tid) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int idx = tid + 256 * i;
         const int row = idx >> 7, col = idx & 127;
-        int64_t rg = b0 + row; rg = rg < B ? rg : B - 1;
         int cg = f0 + col; cg = cg < XD ? cg : XD - 1;
-        xr[i] = x[rg * ldx + cg];
+        xr[i] = x[rowof(row) * ldx + cg];          // rowof clamps rows past the batch
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     constexpr int OI = Ld<T>::nbias, OBC1 = OI, OBC2 = OI + HD, OWC3 = OI + 2 * HD, OBA1 = OI + 3 * HD, OBA2 = OI + 4 * HD, OWA3 = OI + 5 * HD, OS3 = OI + 6 * HD;
     __shared__ float red[16];
     __shared__ float red2[128];
+    __shared__ int64_t rowsrc[TB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -442,7 +445,18 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         const bool full = (b0 + TB) <= g.B;
         float rec_lane = 0.f, kl_lane = 0.f, bce_c = 0.f, bce_a = 0.f;
         float y_l = 0.f;
-        if (INFO) { int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1; y_l = g.y[br * g.ldy]; }
+        // source row of the tile's frame r (clamped to the batch): identity, or through the gather table
+        if (g.rows != nullptr) {
+            __syncthreads();                                 // previous tile's readers are done with rowsrc
+            if (tid < TB) { int64_t br = b0 + tid; br = br < g.B ? br : g.B - 1; rowsrc[tid] = g.rows[br]; }
+            __syncthreads();
+        }
+        auto rowof = [&](int r) -> int64_t {
+            if (g.rows != nullptr) return rowsrc[r];
+            const int64_t br = b0 + r;
+            return br < g.B ? br : g.B - 1;
+        };
+        if (INFO) y_l = g.y[rowof(l31) * g.ldy];
         f32x16 dzu;                                      // M2_info: d BCE_aux / d z (unit scale), wave 0
         // per-iteration opaque copy of the thread id: stops the compiler from hoisting the ~70 per-thread
         // staging addresses out of the tile loop (they would live across the whole loop and spill)
@@ -474,17 +488,17 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         f32x4 yv[NQ513];
         if (g.fastx && full) {
             f32x4 xv[NQ513];
-            tile513_issue(g.x + b0 * XD, xv, tl);
+            tile513_issue(g.x, rowof, xv, tl);
             if constexpr (Y513 && P::EARLY_Y) {
-                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);      // y tile in flight under the x commit and the x GEMM
+                if (yfast) tile513_issue(g.y, rowof, yv, tl);      // y tile in flight under the x commit and the x GEMM
             }
             if (bias_pending) { store_bias_table(); bias_pending = false; }
             tile513_commit<P, XP>(xv, U, LDU, tl, P::XFULL ? Xt : nullptr);
         } else {
             if (bias_pending) { store_bias_table(); bias_pending = false; }
-            load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, P::XFULL ? Xt : nullptr);
+            load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, P::XFULL ? Xt : nullptr);
             if constexpr (Y513 && P::EARLY_Y) {
-                if (yfast) tile513_issue(g.y + b0 * XD, yv, tl);
+                if (yfast) tile513_issue(g.y, rowof, yv, tl);
             }
         }
         __syncthreads();
@@ -513,10 +527,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (YP > 0) {
             __syncthreads();
             if (Y513 && yfast) {
-                if constexpr (!P::EARLY_Y) tile513_issue(g.y + b0 * XD, yv, tl);
+                if constexpr (!P::EARLY_Y) tile513_issue(g.y, rowof, yv, tl);
                 tile513_commit<P, XP>(yv, U, LDU, tl);
             } else {
-                load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl);
+                load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl, rowof);
             }
             __syncthreads();
             if (YENC) {
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         WPre<P, HD / KS, P::PRE128> w5;
         wprefetch<P, HD / KS>(w5, wrs, woff(W5s, wave_u * TSTEP), S17);
         float xr[16];
-        if (!P::XFULL) xt_issue(g.x, g.ldx, b0, g.B, 0, xr, tl);
+        if (!P::XFULL) xt_issue(g.x, g.ldx, rowof, 0, xr, tl);
         float d2r[16];
         bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             for (int it = 0; it < (NT_OUT + 3) / 4; ++it) {
                 xt_commit(xr, Xt, LDX, b0, g.B, 128 * it, tl);
                 __syncthreads();
-                if (it + 1 < (NT_OUT + 3) / 4) xt_issue(g.x, g.ldx, b0, g.B, 128 * (it + 1), xr, tl);
+                if (it + 1 < (NT_OUT + 3) / 4) xt_issue(g.x, g.ldx, rowof, 128 * (it + 1), xr, tl);
                 const int t = 4 * it + wave_u;
                 if (t < NT_OUT) out_tile(t, Xt, LDX, 32 * wave, 127);
                 __syncthreads();
@@ -1372,6 +1386,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     const int esz = bf ? 2 : 4;
     RowsArgs a;
     memset(&a, 0, sizeof(a));
+    a.rows = (const int64_t*)(uintptr_t)plan->row_index;
     a.rng_seed = plan->rng_seed; a.rng_step = g_rng_step_override >= 0 ? (unsigned long long)g_rng_step_override : plan->rng_step;
     a.x = x; a.y = y; a.eps = eps_noise; a.ldx = ldx; a.ldy = plan->y_dim ? ldy : 0; a.ydim = plan->y_dim;
     a.fastx = (ldx == XD) && (((uintptr_t)x & 15) == 0);

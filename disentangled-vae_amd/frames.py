@@ -76,6 +76,19 @@ class DeviceFrames:
         self.last_perm = perm
         return self._xs, self._ys
 
+    def index_batches(self, batch, shuffle=True, drop_last=False, generator=None):
+        """Yields int64 row-index tensors [b] for `Trainer.step(data.x, data.y, rows=idx)`: the rows kernel gathers the
+        frames itself (2 KB contiguous per frame), so an epoch's shuffle costs one randperm instead of a copy of the set."""
+        n = len(self)
+        with torch.cuda.device(self.device):
+            order = torch.randperm(n, device=self.device, generator=generator) if shuffle else torch.arange(n, device=self.device)
+        self.last_perm = order
+        for s in range(0, n, batch):
+            e = min(n, s + batch)
+            if e - s < batch and drop_last:
+                return
+            yield order[s:e]
+
     def batches(self, batch, shuffle=True, drop_last=False, generator=None):
         """Yields (x [b,513], y [b,y_dim] or None) contiguous device views, b == batch except possibly the last."""
         x, y = self.shuffled(generator) if shuffle else (self.x, self.y)

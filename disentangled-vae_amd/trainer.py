@@ -25,7 +25,8 @@ class TrainPlan(ctypes.Structure):
                 ("workspace_bytes", ctypes.c_int64), ("grad_offset_bytes", ctypes.c_int64), ("Bp", ctypes.c_int64),
                 ("rows_grid", ctypes.c_int64), ("flops_per_step", ctypes.c_double), ("min_hbm_bytes_per_step", ctypes.c_double),
                 ("info_alpha", ctypes.c_double), ("info_beta", ctypes.c_double), ("info_gamma", ctypes.c_double),
-                ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64), ("loss_accum", ctypes.c_uint64)]
+                ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64), ("loss_accum", ctypes.c_uint64),
+                ("row_index", ctypes.c_uint64)]
 
 
 MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3}
@@ -197,13 +198,23 @@ class Trainer:
     _reduced = False
 
     # ---- one train step ----
-    def step(self, x, y=None, eps_noise=None):
+    def _check_inputs(self, x, y, rows):
+        """rows=None: x [B,513], y [B,y_dim] are the batch.  rows = int64 CUDA tensor [B]: x / y are a whole frame store
+        ([N,513], [N,y_dim]) and frame b of the step is row rows[b] (gathered inside the kernel: no copy)."""
         B = self.B
-        if x.shape != (B, 513) or x.dtype != torch.float32 or not x.is_cuda:
-            raise ValueError(f"x must be a float32 CUDA tensor [{B}, 513]")
+        n = B if rows is None else x.shape[0]
+        if x.ndim != 2 or x.shape != (n, 513) or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError(f"x must be a float32 CUDA tensor [{n if rows is not None else B}, 513]")
         if self.y_dim:
-            if y is None or y.shape != (B, self.y_dim) or y.dtype != torch.float32:
-                raise ValueError(f"y must be a float32 CUDA tensor [{B}, {self.y_dim}]")
+            if y is None or y.shape != (n, self.y_dim) or y.dtype != torch.float32:
+                raise ValueError(f"y must be a float32 CUDA tensor [{n}, {self.y_dim}]")
+        if rows is not None:
+            if not (rows.is_cuda and rows.dtype == torch.int64 and rows.shape == (B,) and rows.is_contiguous()):
+                raise ValueError(f"rows must be a contiguous int64 CUDA tensor [{B}]")
+        self.plan.row_index = 0 if rows is None else rows.data_ptr()
+
+    def step(self, x, y=None, eps_noise=None, rows=None):
+        self._check_inputs(x, y, rows)
         x = x if x.stride(1) == 1 else x.contiguous()
         if eps_noise is not None:           # None: the rows kernel draws the noise itself (Philox, see noise())
             eps_noise = eps_noise.contiguous()
@@ -233,9 +244,10 @@ class Trainer:
             self._reduced = True
         return self.losses
 
-    def evaluate(self, x, y=None, eps_noise=None):
+    def evaluate(self, x, y=None, eps_noise=None, rows=None):
         """Validation pass (scripts/training_M2.py:176-193): forward + elbo on a batch of the trainer's size, no
         backward, no update.  Returns a NEW device tensor [ELBO, recon, KL] (M2_info: 8 entries)."""
+        self._check_inputs(x, y, rows)
         self._sync_copies()
         if eps_noise is None:               # drawn in the kernel, from a counter range the training steps never reach
             self._shared["eval_count"] = self._shared.get("eval_count", 0) + 1

@@ -36,14 +36,14 @@ def run_epoch(data, trainers, train, shuffle):   # trainers: [main, optional for
     The sums are kept on the device by the step itself: no host sync, no extra kernels per step."""
     tot = torch.zeros(8, dtype=torch.float64, device=data.device)
     nb = 0
-    for x, y in data.batches(trainers[0].B, shuffle=shuffle):
+    for rows in data.index_batches(trainers[0].B, shuffle=shuffle):     # the rows kernel gathers the frames itself
         tr = trainers[0]
-        if x.shape[0] != tr.B:                                  # last, shorter batch: same parameters, its own plan
-            if len(trainers) == 1 or trainers[1].B != x.shape[0]:
-                trainers[1:] = [tr.fork(x.shape[0])]
+        if rows.shape[0] != tr.B:                               # last, shorter batch: same parameters, its own plan
+            if len(trainers) == 1 or trainers[1].B != rows.shape[0]:
+                trainers[1:] = [tr.fork(rows.shape[0])]
             tr = trainers[1]
         tr.accumulate_losses(tot)
-        tr.step(x, y) if train else tr.evaluate(x, y)
+        tr.step(data.x, data.y, rows=rows) if train else tr.evaluate(data.x, data.y, rows=rows)
         nb += 1
     for tr in trainers:
         tr.accumulate_losses(None)

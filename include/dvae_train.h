@@ -66,6 +66,10 @@ typedef struct {
        device-to-host sync per step): device pointer to 8 doubles, or 0.  dvae_train_apply / dvae_train_eval add the
        step's loss scalars (same order as losses3) to it. */
     uint64_t loss_accum;
+    /* Optional gather (epoch shuffle without copying the data set): device pointer to B int64 row numbers, or 0.
+       When set, x and y are the whole frame store (rows of ldx / ldy floats) and frame b of the step is row
+       row_index[b]; the caller guarantees every index is in range. */
+    uint64_t row_index;
 } dvae_train_plan_t;
 
 /* Fill `plan` for (model, y_dim, precision, B).  ksplit_hint 0 = choose.  Returns DVAE_E_UNSUPPORTED

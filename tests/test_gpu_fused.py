@@ -303,3 +303,23 @@ def test_device_side_loss_accumulation():
     tr.accumulate_losses(None)
     tr.step(x, y)
     np.testing.assert_allclose(acc.cpu().numpy()[:3], want, rtol=1e-12)     # detached: no more additions
+
+
+@pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "fp32"), ("M2", 513, "bf16"), ("M1", 0, "bf16"), ("M2_info", 1, "fp32")])
+def test_in_kernel_row_gather_equals_gathered_batch(model, y_dim, precision):
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 5)
+    n, B = 700, 200                                             # B not a multiple of 32: edge tile goes through the gather too
+    x, y, e = gu.make_batch(dims, n, 6)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    rows = torch.randperm(n, device="cuda", generator=g)[:B].contiguous()
+    a = trainer.Trainer(model, dims, params, batch=B, precision=precision, seed=3)
+    b = trainer.Trainer(model, dims, params, batch=B, precision=precision, seed=3)
+    X, Y, E = t(x), t(y), t(e)[:B].contiguous()
+    la = a.step(X, Y, E, rows=rows).clone()
+    lb = b.step(X[rows].contiguous(), None if Y is None else Y[rows].contiguous(), E).clone()
+    assert torch.equal(la, lb) and torch.equal(a.params, b.params)
+    assert torch.equal(a.evaluate(X, Y, E, rows=rows), b.evaluate(X[rows].contiguous(), None if Y is None else Y[rows].contiguous(), E))
+    with pytest.raises(ValueError):
+        a.step(X, Y, E, rows=rows[:10])
