@@ -323,3 +323,38 @@ def test_in_kernel_row_gather_equals_gathered_batch(model, y_dim, precision):
     assert torch.equal(a.evaluate(X, Y, E, rows=rows), b.evaluate(X[rows].contiguous(), None if Y is None else Y[rows].contiguous(), E))
     with pytest.raises(ValueError):
         a.step(X, Y, E, rows=rows[:10])
+
+
+@pytest.mark.parametrize("model,y_dim,precision,tol", [("M2", 513, "fp32", 2e-4), ("M2", 1, "bf16", 2e-2), ("M2_info", 1, "fp32", 5e-4)])
+def test_long_trajectory_tracks_the_cpu_reference_loop(model, y_dim, precision, tol):
+    """120 consecutive steps (lr 1e-3: the parameters move by ~0.1) against the torch-CPU restatement of the reference
+    loop on the same batches and noise: Adam moments, bias correction and the weight-copy refresh over many steps."""
+    from oracle import torch_ref as tref
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 9)
+    B, nsteps, lr = 256, 120, 1e-3
+    x, y, e = gu.make_batch(dims, B * 4, 10)
+    tp = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    ref = tref.Stepper(model, tp, lr=lr)
+    tr = trainer.Trainer(model, dims, params, batch=B, precision=precision, lr=lr)
+    rng = np.random.default_rng(0)
+    lr_hist, lf_hist = [], []
+    for s in range(nsteps):
+        sl = slice((s % 4) * B, (s % 4 + 1) * B)
+        en = rng.standard_normal((B, 16)).astype(np.float32)
+        xb, yb = x[sl], (None if y is None else y[sl])
+        out = ref.step(torch.from_numpy(xb), None if yb is None else torch.from_numpy(yb), torch.from_numpy(en))
+        lf = tr.step(torch.from_numpy(xb).cuda(), None if yb is None else torch.from_numpy(yb).cuda(), torch.from_numpy(en).cuda())
+        lr_hist.append(out[0]); lf_hist.append(float(lf[0]))
+    lr_hist, lf_hist = np.array(lr_hist), np.array(lf_hist)
+    assert lr_hist[-1] < 0.9 * lr_hist[0]                                        # it is actually learning
+    np.testing.assert_allclose(lf_hist, lr_hist, rtol=tol)
+    got = tr.state_dict_numpy()
+    # Adam turns a gradient whose sign is rounding noise into a +-lr step, so single parameters may differ by a few lr;
+    # the population must not: RMS drift against RMS movement, and the share of parameters off by more than 10 lr
+    mv = np.concatenate([(tp[k].detach().numpy() - params[k]).ravel() for k in params])
+    dr = np.concatenate([(got[k] - tp[k].detach().numpy()).ravel() for k in params])
+    rms_moved, rms_drift = float(np.sqrt((mv ** 2).mean())), float(np.sqrt((dr ** 2).mean()))
+    assert rms_moved > 0.01, rms_moved
+    assert rms_drift < (0.08 if precision == "bf16" else 0.02) * rms_moved, (rms_moved, rms_drift)
+    assert (np.abs(dr) > 10 * lr).mean() < (0.02 if precision == "bf16" else 2e-3), float((np.abs(dr) > 10 * lr).mean())
