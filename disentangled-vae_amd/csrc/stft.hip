@@ -8,6 +8,7 @@
 // buffer, then a gather overlap-add that replays librosa's float32
 // frame-by-frame accumulation order exactly (deterministic, no atomics).
 #include <float.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace dvae {
@@ -90,6 +91,164 @@ __global__ __launch_bounds__(256) void stft_pow2_kernel(const TIN* __restrict__ 
             store_bin(out, layout, T, F, t, M - k, cconj(csub(e, wo)));
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// nfft = 1024 (every caller of the reference): ONE WAVE per frame.  The 512-point complex FFT is three radix-8
+// Stockham passes with 8 points per lane in registers; lanes exchange data through a private LDS buffer between
+// passes (no workgroup barrier anywhere: a wave's LDS accesses are ordered), the window and all twiddles live in
+// registers for the whole launch.  Double precision throughout (the reference transforms float64 audio and only
+// then casts to complex64).  Power frames ([T][513], the training layout) leave as 256-byte runs per wave; the
+// complex [513][T] layout is staged through LDS 16 frames at a time so each bin's 16 frames leave as one 128-byte run.
+__device__ __forceinline__ cd cmulc(cd a, double wr, double wi) { return cd{a.x * wr - a.y * wi, a.x * wi + a.y * wr}; }
+
+// in-place 8-point DFT (forward), natural-order output
+__device__ __forceinline__ void dft8(cd (&a)[8]) {
+    constexpr double H = 0.70710678118654752440;
+    cd b[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b[i] = cadd(a[i], a[i + 4]); }
+    { const cd d = csub(a[0], a[4]); b[4] = d; }
+    { const cd d = csub(a[1], a[5]); b[5] = cd{(d.x + d.y) * H, (d.y - d.x) * H}; }        // * (1 - i)/sqrt2
+    { const cd d = csub(a[2], a[6]); b[6] = cd{d.y, -d.x}; }                               // * -i
+    { const cd d = csub(a[3], a[7]); b[7] = cd{(d.y - d.x) * H, -(d.x + d.y) * H}; }       // * (-1 - i)/sqrt2
+    cd c[8];
+#pragma unroll
+    for (int q = 0; q < 8; q += 4) {
+        c[q] = cadd(b[q], b[q + 2]); c[q + 1] = cadd(b[q + 1], b[q + 3]);
+        c[q + 2] = csub(b[q], b[q + 2]);
+        const cd d = csub(b[q + 1], b[q + 3]); c[q + 3] = cd{d.y, -d.x};                   // * -i
+    }
+    a[0] = cadd(c[0], c[1]); a[4] = csub(c[0], c[1]); a[2] = cadd(c[2], c[3]); a[6] = csub(c[2], c[3]);
+    a[1] = cadd(c[4], c[5]); a[5] = csub(c[4], c[5]); a[3] = cadd(c[6], c[7]); a[7] = csub(c[6], c[7]);
+}
+
+__device__ __forceinline__ int padidx(int i) { return i + (i >> 3); }     // one double of padding per 8: strides 8 and 64 both conflict-free
+
+constexpr int STFT_FR = 16;        // frames staged per workgroup pass of the complex layout
+
+template <typename TIN, int LAYOUT>
+__global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window,
+                                                        int hop, int64_t T, void* out) {
+    constexpr int M = 512, F = 513;
+    __shared__ double lre[4][M + 64], lim[4][M + 64];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* stage = reinterpret_cast<float2*>(smem);              // LAYOUT 0: [F][STFT_FR + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* re = lre[wave];
+    double* im = lim[wave];
+    // per-lane constants
+    double wa[8], wb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)]; wb[r] = window[2 * (lane + 64 * r) + 1]; }
+    double t1r[8], t1i[8], t2r[8], t2i[8];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        sincospi(-2.0 * (double)(r * (lane & 7)) / 64.0, &t1i[r], &t1r[r]);      // pass 1 (Ns = 8): exp(-2 pi i r k / 64), k = lane & 7
+        sincospi(-2.0 * (double)(r * lane) / 512.0, &t2i[r], &t2r[r]);           // pass 2 (Ns = 64): exp(-2 pi i r lane / 512)
+    }
+    double sr[5], si[5];                                                           // split twiddles exp(-2 pi i k / 1024), k = lane + 64 r; [4]: k = 256
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sincospi(-2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);
+    sr[4] = 0.0; si[4] = -1.0;
+
+    // raw sample pairs of frame t (the zero end-pad is implied past n); requested one frame ahead of the transform
+    struct TIN2 { TIN a, b; };
+    auto fetch = [&](int64_t t, TIN2 (&raw)[8]) {
+        const int64_t base = t * hop;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t s0 = base + 2 * (lane + 64 * r);
+            if (s0 + 1 < n) raw[r] = *reinterpret_cast<const TIN2*>(x + s0);      // hop and the pair offset are even: aligned pair loads
+            else { raw[r].a = s0 < n ? x[s0] : (TIN)0; raw[r].b = (TIN)0; }
+        }
+    };
+    auto one_frame = [&](int64_t t, const TIN2 (&raw)[8], auto&& emit) {
+        cd v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = cd{(double)raw[r].a * wa[r], (double)raw[r].b * wb[r]};
+        // pass 0 (Ns = 1): no twiddles; outputs to index lane*8 + r
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane * 8 + r); re[i] = v[r].x; im[i] = v[r].y; }
+        __builtin_amdgcn_wave_barrier();
+        // pass 1 (Ns = 8)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t1r[r], t1i[r]);
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int j0 = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = padidx(j0 + 8 * r); re[i] = v[r].x; im[i] = v[r].y; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 2 (Ns = 64): outputs z[lane + 64 r] stay in registers
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t2r[r], t2i[r]);
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); re[i] = v[r].x; im[i] = v[r].y; }
+        __builtin_amdgcn_wave_barrier();
+        // real-FFT split: X[k] = E + W^k O, X[M-k] = conj(E - W^k O), partner z[M-k] from LDS
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            const int pi = padidx((M - k) & (M - 1));
+            const cd zk = v[r], zc = cd{re[pi], -im[pi]};
+            const cd e = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y)};
+            const cd d = csub(zk, zc);
+            const cd wo = cmulc(cd{0.5 * d.y, -0.5 * d.x}, sr[r], si[r]);
+            emit(k, cadd(e, wo));
+            emit(M - k, cconj(csub(e, wo)));
+        }
+        if (lane == 0) {                                         // k = 256 (its own partner): X = E + (-i) O
+            const cd zk = v[4];
+            emit(256, cd{zk.x, -zk.y});
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    TIN2 cur[8], nxt[8];
+    if (LAYOUT == 1) {
+        float* o = (float*)out;
+        const int64_t stride = (int64_t)gridDim.x * 4;
+        int64_t t = (int64_t)blockIdx.x * 4 + wave;
+        if (t < T) fetch(t, cur);
+        for (; t < T; t += stride) {
+            if (t + stride < T) fetch(t + stride, nxt);          // next frame's samples in flight under this frame's transform
+            one_frame(t, cur, [&](int f, cd X) {
+                const float a = hypotf((float)X.x, (float)X.y);   // np.abs(complex64) ** 2
+                o[t * F + f] = a * a;
+            });
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
+        }
+    } else {
+        float2* o = (float2*)out;
+        for (int64_t t0 = (int64_t)blockIdx.x * STFT_FR; t0 < T; t0 += (int64_t)gridDim.x * STFT_FR) {
+            if (t0 + wave < T) fetch(t0 + wave, cur);
+            for (int q = wave; q < STFT_FR; q += 4) {
+                const int64_t t = t0 + q;
+                if (q + 4 < STFT_FR && t + 4 < T) fetch(t + 4, nxt);
+                if (t < T) one_frame(t, cur, [&](int f, cd X) { stage[f * (STFT_FR + 1) + q] = float2{(float)X.x, (float)X.y}; });
+#pragma unroll
+                for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
+            }
+            __syncthreads();
+            const int nq = (int)(T - t0 < STFT_FR ? T - t0 : STFT_FR);
+            for (int idx = threadIdx.x; idx < F * STFT_FR; idx += 256) {
+                const int f = idx / STFT_FR, q = idx - f * STFT_FR;
+                if (q < nq) o[(int64_t)f * T + t0 + q] = stage[f * (STFT_FR + 1) + q];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -239,7 +398,25 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (int)(T < 2048 ? T : 2048);
     const int lg = ilog2_exact(nfft);
-    if (lg >= 3 && nfft <= 2048) {
+    static const bool legacy = getenv("DVAE_STFT_LEGACY") != nullptr;       // A/B switch for the workgroup-per-frame kernel
+    if (nfft == 1024 && !legacy) {
+        if (layout == 1) {
+            const int wb = (int)(cdiv(T, 4) < 4096 ? cdiv(T, 4) : 4096);
+            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, out);
+            else hipLaunchKernelGGL((stft1024_kernel<float, 1>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, out);
+        } else {
+            const int wb = (int)(cdiv(T, STFT_FR) < 2048 ? cdiv(T, STFT_FR) : 2048);
+            const size_t lds = (size_t)513 * (STFT_FR + 1) * sizeof(float2);
+            static bool attr_done = false;
+            if (!attr_done) {
+                DVAE_HIP(hipFuncSetAttribute((const void*)stft1024_kernel<double, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                DVAE_HIP(hipFuncSetAttribute((const void*)stft1024_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_done = true;
+            }
+            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 0>), dim3(wb), dim3(256), lds, s, (const double*)x, n, window, hop, T, out);
+            else hipLaunchKernelGGL((stft1024_kernel<float, 0>), dim3(wb), dim3(256), lds, s, (const float*)x, n, window, hop, T, out);
+        }
+    } else if (lg >= 3 && nfft <= 2048) {
         const size_t lds = (size_t)(nfft / 2) * 2 * sizeof(cd) + (size_t)nfft * sizeof(double);
         if (in_f64)
             hipLaunchKernelGGL((stft_pow2_kernel<double>), dim3(blocks), dim3(256), lds, s, (const double*)x, n, window, nfft, lg - 1, hop, T, out, layout);
