@@ -130,7 +130,7 @@ constexpr int STFT_FR = 16;        // frames staged per workgroup pass of the co
 
 template <typename TIN, int LAYOUT>
 __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window,
-                                                        int hop, int64_t T, void* out) {
+                                                        int hop, int64_t T, int chunk, void* out) {
     constexpr int M = 512, F = 513;
     __shared__ double lre[4][M + 64], lim[4][M + 64];
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,6 +161,19 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
         for (int r = 0; r < 8; ++r) {
             const int64_t s0 = base + 2 * (lane + 64 * r);
             if (s0 + 1 < n) raw[r] = *reinterpret_cast<const TIN2*>(x + s0);      // hop and the pair offset are even: aligned pair loads
+            else { raw[r].a = s0 < n ? x[s0] : (TIN)0; raw[r].b = (TIN)0; }
+        }
+    };
+    // consecutive frames overlap by nfft - hop samples: with hop = 256 (128 pairs = 2 slots of 64 lanes) pair slot r of
+    // frame t+1 is slot r+2 of frame t IN THE SAME LANE, so a wave walking consecutive frames loads only slots 6 and 7
+    auto advance = [&](int64_t tnext, const TIN2 (&prev)[8], TIN2 (&raw)[8]) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) raw[r] = prev[r + 2];
+        const int64_t base = tnext * hop;
+#pragma unroll
+        for (int r = 6; r < 8; ++r) {
+            const int64_t s0 = base + 2 * (lane + 64 * r);
+            if (s0 + 1 < n) raw[r] = *reinterpret_cast<const TIN2*>(x + s0);
             else { raw[r].a = s0 < n ? x[s0] : (TIN)0; raw[r].b = (TIN)0; }
         }
     };
@@ -218,13 +231,17 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
     TIN2 cur[8], nxt[8];
     if (LAYOUT == 1) {
         float* o = (float*)out;
-        const int64_t stride = (int64_t)gridDim.x * 4;
-        int64_t t = (int64_t)blockIdx.x * 4 + wave;
-        if (t < T) fetch(t, cur);
-        for (; t < T; t += stride) {
-            if (t + stride < T) fetch(t + stride, nxt);          // next frame's samples in flight under this frame's transform
+        // each wave walks `chunk` consecutive frames (chunk chosen by the host so that the launch still fills the chip)
+        const int64_t tb = ((int64_t)blockIdx.x * 4 + wave) * chunk;
+        const int64_t te = tb + chunk < T ? tb + chunk : T;
+        if (tb < te) fetch(tb, cur);
+        for (int64_t t = tb; t < te; ++t) {
+            if (t + 1 < te) { if (hop == 256) advance(t + 1, cur, nxt); else fetch(t + 1, nxt); }   // in flight under this frame's transform
             one_frame(t, cur, [&](int f, cd X) {
-                const float a = hypotf((float)X.x, (float)X.y);   // np.abs(complex64) ** 2
+                // np.abs(complex64) ** 2: float32 magnitude, then its square.  The magnitudes here are far from
+                // overflow, so the correctly rounded square root of re^2 + im^2 stands in for hypotf (30 instructions)
+                const float re32 = (float)X.x, im32 = (float)X.y;
+                const float a = __fsqrt_rn(fmaf(re32, re32, im32 * im32));
                 o[t * F + f] = a * a;
             });
 #pragma unroll
@@ -233,10 +250,11 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
     } else {
         float2* o = (float2*)out;
         for (int64_t t0 = (int64_t)blockIdx.x * STFT_FR; t0 < T; t0 += (int64_t)gridDim.x * STFT_FR) {
-            if (t0 + wave < T) fetch(t0 + wave, cur);
-            for (int q = wave; q < STFT_FR; q += 4) {
+            constexpr int PW = STFT_FR / 4;                           // consecutive frames per wave
+            if (t0 + wave * PW < T) fetch(t0 + wave * PW, cur);
+            for (int q = wave * PW; q < (wave + 1) * PW; ++q) {
                 const int64_t t = t0 + q;
-                if (q + 4 < STFT_FR && t + 4 < T) fetch(t + 4, nxt);
+                if (q + 1 < (wave + 1) * PW && t + 1 < T) { if (hop == 256) advance(t + 1, cur, nxt); else fetch(t + 1, nxt); }
                 if (t < T) one_frame(t, cur, [&](int f, cd X) { stage[f * (STFT_FR + 1) + q] = float2{(float)X.x, (float)X.y}; });
 #pragma unroll
                 for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
@@ -401,9 +419,12 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
     static const bool legacy = getenv("DVAE_STFT_LEGACY") != nullptr;       // A/B switch for the workgroup-per-frame kernel
     if (nfft == 1024 && !legacy) {
         if (layout == 1) {
-            const int wb = (int)(cdiv(T, 4) < 4096 ? cdiv(T, 4) : 4096);
-            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, out);
-            else hipLaunchKernelGGL((stft1024_kernel<float, 1>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, out);
+            // one round of waves: 256 CUs x 4 SIMDs x 2 resident waves = 2048 slots; a wave takes ceil(T / 2048) frames
+            int chunk = (int)cdiv(T, 2048);
+            chunk = chunk < 1 ? 1 : chunk;
+            const int wb = (int)cdiv(T, (int64_t)4 * chunk);
+            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, chunk, out);
+            else hipLaunchKernelGGL((stft1024_kernel<float, 1>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, chunk, out);
         } else {
             const int wb = (int)(cdiv(T, STFT_FR) < 2048 ? cdiv(T, STFT_FR) : 2048);
             const size_t lds = (size_t)513 * (STFT_FR + 1) * sizeof(float2);
@@ -413,8 +434,8 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
                 DVAE_HIP(hipFuncSetAttribute((const void*)stft1024_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_done = true;
             }
-            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 0>), dim3(wb), dim3(256), lds, s, (const double*)x, n, window, hop, T, out);
-            else hipLaunchKernelGGL((stft1024_kernel<float, 0>), dim3(wb), dim3(256), lds, s, (const float*)x, n, window, hop, T, out);
+            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 0>), dim3(wb), dim3(256), lds, s, (const double*)x, n, window, hop, T, 1, out);
+            else hipLaunchKernelGGL((stft1024_kernel<float, 0>), dim3(wb), dim3(256), lds, s, (const float*)x, n, window, hop, T, 1, out);
         }
     } else if (lg >= 3 && nfft <= 2048) {
         const size_t lds = (size_t)(nfft / 2) * 2 * sizeof(cd) + (size_t)nfft * sizeof(double);
