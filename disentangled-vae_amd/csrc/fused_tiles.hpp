@@ -30,6 +30,7 @@ struct PolF32 {
     static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
     static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
     static constexpr int PRE128 = 2;   // the same for the 128-deep layers
+    static constexpr int PREBIG = 2;   // long GEMMs whose prefetch site has registers to spare
     static constexpr int WRING = 4;    // wgrad: k-steps of operand fragments in flight per wave
     static constexpr bool EARLY_Y = false;
     static constexpr bool XFULL = false;   // fp32 x tile does not fit LDS next to fp32 activations: streamed in 128-column slices
@@ -55,6 +56,10 @@ struct PolBF16 {
     static constexpr int KSTEP = 16;
     static constexpr int PD = 16;
     static constexpr int PRE = 6;
+#ifndef DVAE_PREBIG_BF16
+#define DVAE_PREBIG_BF16 12
+#endif
+    static constexpr int PREBIG = DVAE_PREBIG_BF16;
     static constexpr int PRE128 = 8;   // 128-deep layers: the whole weight tile of a wave (8 fragments) is requested ahead; with 6, the
                                        // last two arrive one L2 round trip (~0.5 us) after the GEMM starts, in every one of ~12 such phases
 #ifndef DVAE_WRING_BF16

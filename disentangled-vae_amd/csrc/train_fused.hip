@@ -571,6 +571,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(5);
         // ---------------- heads + reparametrisation (wave 0): rows 0-15 mu, 16-31 log_var ----------------
         float mu_r[8], lv_r[8], sd_r[8];
+        // the label block of decoder layer 1 (33 k-steps) does not depend on z: its first fragments are requested here,
+        // a whole phase ahead (three of the four waves idle through the heads anyway)
+        WPre<P, (YP > 0 ? YP : KS) / KS, P::PREBIG> w3y;
+        if (YP > 0) wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
         if (wave == 0) {
             zero_acc<P>(acc);
             gemm_block<P, HD / KS>(acc, wmv, wrs, Wmvr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
@@ -607,11 +611,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         zero_acc<P>(acc);
         gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (!INFO && wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h); });
         WPre<P, HD / KS, P::PRE128> w4;
-        if (YP > 0) {
-            WPre<P, YP / KS> w3y;
-            wprefetch<P, YP / KS>(w3y, wrs, woff(W3r, KB3), S4);
-            gemm_block<P, YP / KS>(acc, w3y, wrs, woff(W3r, KB3), Ur, S4);
-        }
+        if (YP > 0) gemm_block<P, (YP > 0 ? YP : KS) / KS>(acc, w3y, wrs, woff(W3r, KB3), Ur, S4);
         wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
         float d1r[16];
         bias16(Bias + OB3, fb, h, bv);
