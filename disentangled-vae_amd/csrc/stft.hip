@@ -126,6 +126,45 @@ __device__ __forceinline__ void dft8(cd (&a)[8]) {
 
 __device__ __forceinline__ int padidx(int i) { return i + (i >> 3); }     // one double of padding per 8: strides 8 and 64 both conflict-free
 
+// 512-point complex forward FFT of one wave: v[r] = x[lane + 64 r] in, X[lane + 64 r] out (both natural order), three
+// radix-8 Stockham passes; re / im: the wave's private padded LDS exchange buffers (512 + 64 doubles each).
+struct Fft512 {
+    double t1r[8], t1i[8], t2r[8], t2i[8];
+    __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+            sincospi(-2.0 * (double)(r * (lane & 7)) / 64.0, &t1i[r], &t1r[r]);      // pass 1 (Ns = 8): exp(-2 pi i r k / 64), k = lane & 7
+            sincospi(-2.0 * (double)(r * lane) / 512.0, &t2i[r], &t2r[r]);           // pass 2 (Ns = 64): exp(-2 pi i r lane / 512)
+        }
+    }
+    __device__ __forceinline__ void run(cd (&v)[8], double* re, double* im, int lane) const {
+        // pass 0 (Ns = 1): no twiddles; outputs to index lane*8 + r
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane * 8 + r); re[i] = v[r].x; im[i] = v[r].y; }
+        __builtin_amdgcn_wave_barrier();
+        // pass 1 (Ns = 8)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t1r[r], t1i[r]);
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int j0 = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = padidx(j0 + 8 * r); re[i] = v[r].x; im[i] = v[r].y; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 2 (Ns = 64): outputs X[lane + 64 r] stay in registers
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t2r[r], t2i[r]);
+        dft8(v);
+    }
+};
+
 constexpr int STFT_FR = 16;        // frames staged per workgroup pass of the complex layout
 
 template <typename TIN, int LAYOUT>
@@ -142,12 +181,8 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
     double wa[8], wb[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)]; wb[r] = window[2 * (lane + 64 * r) + 1]; }
-    double t1r[8], t1i[8], t2r[8], t2i[8];
-#pragma unroll
-    for (int r = 1; r < 8; ++r) {
-        sincospi(-2.0 * (double)(r * (lane & 7)) / 64.0, &t1i[r], &t1r[r]);      // pass 1 (Ns = 8): exp(-2 pi i r k / 64), k = lane & 7
-        sincospi(-2.0 * (double)(r * lane) / 512.0, &t2i[r], &t2r[r]);           // pass 2 (Ns = 64): exp(-2 pi i r lane / 512)
-    }
+    Fft512 fft;
+    fft.init(lane);
     double sr[5], si[5];                                                           // split twiddles exp(-2 pi i k / 1024), k = lane + 64 r; [4]: k = 256
 #pragma unroll
     for (int r = 0; r < 4; ++r) sincospi(-2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);
@@ -181,30 +216,7 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
         cd v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = cd{(double)raw[r].a * wa[r], (double)raw[r].b * wb[r]};
-        // pass 0 (Ns = 1): no twiddles; outputs to index lane*8 + r
-        dft8(v);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { const int i = padidx(lane * 8 + r); re[i] = v[r].x; im[i] = v[r].y; }
-        __builtin_amdgcn_wave_barrier();
-        // pass 1 (Ns = 8)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t1r[r], t1i[r]);
-        dft8(v);
-        __builtin_amdgcn_wave_barrier();
-        {
-            const int j0 = (lane >> 3) * 64 + (lane & 7);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { const int i = padidx(j0 + 8 * r); re[i] = v[r].x; im[i] = v[r].y; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // pass 2 (Ns = 64): outputs z[lane + 64 r] stay in registers
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t2r[r], t2i[r]);
-        dft8(v);
+        fft.run(v, re, im, lane);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); re[i] = v[r].x; im[i] = v[r].y; }
@@ -300,6 +312,59 @@ __global__ __launch_bounds__(256) void stft_dft_kernel(const TIN* __restrict__ x
                 idx += f; if (idx >= nfft) idx -= nfft;
             }
             store_bin(out, layout, T, F, t, f, cd{re, im});
+        }
+    }
+}
+
+// nfft = 1024: frames[t][m] = window[m] * irfft(S[:, t])[m] with ONE WAVE per frame (same FFT core, run on the
+// conjugate: ifft(Z) = conj(fft(conj Z)) / M).  S is [bin][T]: a workgroup stages 16 consecutive frames through LDS
+// (one 128-byte run per bin) and its four waves take four frames each.
+constexpr int ISTFT_FR = 8;       // frames staged per workgroup pass: 37 KB + 37 KB of exchange buffers = two workgroups per CU
+__global__ __launch_bounds__(256) void istft1024_frames_kernel(const float2* __restrict__ S, int64_t T, int64_t ldT,
+                                                               const double* __restrict__ window, double* __restrict__ frames) {
+    constexpr int M = 512, F = 513, PW = ISTFT_FR / 4;
+    __shared__ double lre[4][M + 64], lim[4][M + 64];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* stage = reinterpret_cast<float2*>(smem);              // [F][ISTFT_FR + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* re = lre[wave];
+    double* im = lim[wave];
+    double wa[8], wb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)] * (1.0 / M); wb[r] = window[2 * (lane + 64 * r) + 1] * (1.0 / M); }
+    Fft512 fft;
+    fft.init(lane);
+    double sr[8], si[8];                                          // exp(+2 pi i k / 1024), k = lane + 64 r
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sincospi(2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);
+    for (int64_t t0 = (int64_t)blockIdx.x * ISTFT_FR; t0 < T; t0 += (int64_t)gridDim.x * ISTFT_FR) {
+        const int nq = (int)(T - t0 < ISTFT_FR ? T - t0 : ISTFT_FR);
+        __syncthreads();                                          // the previous block's readers are done with `stage`
+        for (int idx = threadIdx.x; idx < F * ISTFT_FR; idx += 256) {
+            const int f = idx / ISTFT_FR, q = idx - f * ISTFT_FR;
+            if (q < nq) stage[f * (ISTFT_FR + 1) + q] = S[(int64_t)f * ldT + t0 + q];
+        }
+        __syncthreads();
+        for (int q = wave * PW; q < (wave + 1) * PW && q < nq; ++q) {
+            cd v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                const float2 a = stage[k * (ISTFT_FR + 1) + q], b = stage[(M - k) * (ISTFT_FR + 1) + q];
+                cd xk = cd{(double)a.x, (double)a.y}, xc = cd{(double)b.x, -(double)b.y};   // X[k], conj(X[M-k])
+                if (k == 0) { xk.y = 0.0; xc.y = 0.0; }                                      // C2R ignores imag of DC / Nyquist
+                const cd e = cd{0.5 * (xk.x + xc.x), 0.5 * (xk.y + xc.y)};
+                const cd o = cmulc(cd{0.5 * (xk.x - xc.x), 0.5 * (xk.y - xc.y)}, sr[r], si[r]);
+                v[r] = cd{e.x - o.y, -(e.y + o.x)};               // conj(E + i O)
+            }
+            fft.run(v, re, im, lane);
+            double* dst = frames + (t0 + q) * 1024;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = lane + 64 * r;
+                reinterpret_cast<double2*>(dst)[i] = double2{wa[r] * v[r].x, -wb[r] * v[r].y};   // conj, 1/M folded into the window
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -467,7 +532,17 @@ extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* w
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (int)(T < 2048 ? T : 2048);
     const int lg = ilog2_exact(nfft);
-    if (lg >= 3) {
+    static const bool legacy = getenv("DVAE_STFT_LEGACY") != nullptr;
+    if (nfft == 1024 && !legacy) {
+        const size_t lds = (size_t)513 * (ISTFT_FR + 1) * sizeof(float2);
+        static bool attr_done = false;
+        if (!attr_done) {
+            DVAE_HIP(hipFuncSetAttribute((const void*)istft1024_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        const int wb = (int)(cdiv(T, ISTFT_FR) < 4096 ? cdiv(T, ISTFT_FR) : 4096);
+        hipLaunchKernelGGL(istft1024_frames_kernel, dim3(wb), dim3(256), lds, s, (const float2*)S, T, ldT, window, (double*)ws);
+    } else if (lg >= 3) {
         const size_t lds = (size_t)(nfft / 2) * 2 * sizeof(cd) + (size_t)nfft * sizeof(double);
         hipLaunchKernelGGL(istft_frames_pow2_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, ldT, window, nfft, lg - 1, (double*)ws);
     } else {
