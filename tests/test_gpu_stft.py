@@ -127,3 +127,24 @@ def test_large_batch_of_frames_linearity():
     t = 1234
     fr = a[t * 256:t * 256 + 1024] * np.hanning(1025)[:1024]
     np.testing.assert_allclose(Sa[:, t], np.fft.rfft(fr).astype(np.complex64), rtol=0, atol=2e-6 * np.abs(Sa[:, t]).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_long_audio_many_frames_per_wave(dtype):
+    """>2048 frames: each wave walks several consecutive frames and carries 6 of its 8 sample pairs over from one
+    frame to the next (power layout), and the complex layout runs many staged blocks; the last frame straddles the
+    end pad.  Also ISTFT of the same length (staged blocks of 8 frames) back to the signal."""
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    n = 16000 * 95 + 37                                     # 5 936 frames -> 3 frames per wave
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(n) * np.exp(0.5 * rng.standard_normal(n))).astype(dtype)
+    ref = so.stft(x.astype(np.float64), **KW)
+    got = ps.stft(x, **KW)
+    assert got.shape == ref.shape and got.shape[1] > 2 * 2048
+    _c64_close(got, ref, 2e-7)
+    P = H.stft_numpy(x, 16000, 64e-3, "hann", 0.25, False, "reflect", True, "complex64", layout=1)
+    np.testing.assert_allclose(P, (np.abs(ref) ** 2).T, rtol=2e-6, atol=1e-10)
+    y = ps.istft(got, max_len=n, **KW)
+    lo, hi = 1024, n - 1280
+    np.testing.assert_allclose(y[lo:hi], x[lo:hi].astype(np.float32), atol=2e-5 * np.abs(x).max())
