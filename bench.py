@@ -21,7 +21,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
 import torch
 
 # exact train FLOPs per frame (fwd + dW + dX, no dX into data): SURVEY.md 8d / BASELINE.md 2

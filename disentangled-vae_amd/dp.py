@@ -3,7 +3,6 @@ so rank k takes rows [k*B, (k+1)*B) of the global batch, every rank holds a full
 0.17-0.30 M parameters, and the only exchange per step is ONE all-reduce (sum) of the flat fp32
 gradient buffer, scaled by 1/world before an identical Adam step on every rank.  On the GPU node the
 process group is RCCL over xGMI (backend "nccl"); the same code runs on gloo for CPU tests."""
-import torch
 import torch.distributed as dist
 
 

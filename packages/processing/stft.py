@@ -9,7 +9,6 @@ as the reference makes them; the transforms are hand-written HIP kernels
 librosa is not imported and there is no CPU transform: without a GPU these
 functions raise.
 """
-import numpy as np
 import torch
 
 from packages import _native

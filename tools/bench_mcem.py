@@ -7,7 +7,7 @@ reference runs N * (niter * 2 * (n_e + b_e) + niter * n_e + 2 * (n_wf + b_wf) + 
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-import numpy as np, torch
+import torch
 import golden_util as gu, mcem_cases as mc
 from impl_modules import build_model
 from packages.models import mcem

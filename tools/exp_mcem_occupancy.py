@@ -3,7 +3,7 @@ per CU (256 CUs): shows what co-resident workgroups buy for the kernel variant c
 import importlib, os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-import numpy as np, torch
+import torch
 import golden_util as gu
 from impl_modules import build_model
 dev = importlib.import_module("disentangled-vae_amd.mcem")
