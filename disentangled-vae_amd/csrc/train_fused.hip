@@ -1171,9 +1171,11 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     const int64_t maxg = 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
     plan->rows_grid = ntiles < maxg ? ntiles : maxg;
     int ks = ksplit_hint;
-    // bf16: 8 slices (one per XCD).  fp32: the MFMA-bound wgrad needs a wave on every SIMD (>= 1024 wave jobs): 16.
+    // bf16: 8 slices up to 8192 frames (more slices = more slabs for the apply pass to sum); 12 beyond: 80 groups x 12 = 960
+    // single-wave jobs fill the 1024 wave slots in one round (wgrad 164 -> 124 us at 65 536 frames, 2.49 -> 1.80 ms at 2^20).
+    // fp32: the MFMA-bound wgrad needs a wave on every SIMD (>= 1024 wave jobs): 16.
     if (ks <= 0) {
-        const int cap = precision == DVAE_PREC_BF16 ? 8 : 16;
+        const int cap = precision == DVAE_PREC_BF16 ? (plan->Bp > 12288 ? 12 : 8) : 16;
         ks = (int)(plan->Bp / (precision == DVAE_PREC_BF16 ? 1024 : 512)); if (ks < 1) ks = 1; if (ks > cap) ks = cap;
     }
     if (ks > 64) ks = 64;
