@@ -380,3 +380,43 @@ def test_persistent_tile_loop_equals_the_sum_of_its_halves(precision):
     for k in full:
         parts = 0.5 * (a[k] + b[k])
         assert np.abs(full[k] - parts).max() <= 1e-4 * np.abs(parts).max() + 1e-12, k   # summation order differs (slices, halves)
+
+
+@pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 1000, "bf16"), ("M2", 513, 33, "fp32"), ("M2_info", 1, 257, "bf16"),
+                                                       ("M1", 0, 8192, "bf16"), ("M2", 1, 20000, "fp32")])
+def test_kernels_stay_inside_their_buffers(model, y_dim, B, precision):
+    """Guard bands around the workspace, the parameter / moment buffers and the loss scalars survive train steps
+    (stash tiles, gradient slabs, weight copies and partial sums are all addressed by hand in the kernels)."""
+    import ctypes
+    N = importlib.import_module("disentangled-vae_amd.native")
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    tr = trainer.Trainer(model, dims, batch=B, precision=precision, seed=1)
+    G = 1 << 16                                              # 64 KiB of guard on each side
+
+    def guarded(nbytes, dtype):
+        raw = torch.full((nbytes + 2 * G,), 0xA5, dtype=torch.uint8, device="cuda")
+        return raw, raw[G:G + nbytes].view(dtype)
+    raw_ws, ws = guarded(tr.plan.workspace_bytes, torch.uint8)
+    raws = {"ws": raw_ws}
+    for name in ("params", "m", "v"):
+        raw, view = guarded(4 * tr.plan.n_params, torch.float32)
+        view.copy_(getattr(tr, name))
+        setattr(tr, name, view)
+        raws[name] = raw
+    raw_l, losses = guarded(4 * tr.losses.numel(), torch.float32)
+    tr.losses = losses
+    raws["losses"] = raw_l
+    tr.ws = ws
+    go = tr.plan.grad_offset_bytes
+    tr.flat_grad = tr.ws[go:go + 4 * tr.plan.n_params].view(torch.float32)
+    N.check(tr.lib.dvae_train_init(ctypes.byref(tr.plan), N.ptr(tr.params), N.ptr(tr.ws), N.stream()), "dvae_train_init")
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    x = torch.rand(B, 513, device="cuda", generator=g) + 0.01
+    y = (torch.rand(B, y_dim, device="cuda", generator=g) > 0.5).float() if y_dim else None
+    for _ in range(3):
+        out = tr.step(x, y)
+    tr.evaluate(x, y)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    for name, raw in raws.items():
+        assert bool((raw[:G] == 0xA5).all()) and bool((raw[-G:] == 0xA5).all()), f"{name}: guard band overwritten"
