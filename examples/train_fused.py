@@ -1,4 +1,4 @@
-"""The reference's training loop (scripts/training_M1.py / training_M2.py: epochs of train batches, a validation pass,
+"""The reference's training loop (scripts/training_M1.py / training_M2.py / training_M2_info_vad.py: epochs of train batches, a validation pass,
 one checkpoint per epoch named `<M>_epoch_{:03d}_vloss_{:.2f}.pt`, the same two log files) on the MI355X-native path:
 GPU-resident frame store (disentangled-vae_amd/frames.py) + fused train step (disentangled-vae_amd/trainer.py).
 
@@ -52,7 +52,7 @@ def run_epoch(data, trainers, train, shuffle):   # trainers: [main, optional for
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", choices=["M1", "M2"], default="M2")
+    ap.add_argument("--model", choices=["M1", "M2", "M2_info"], default="M2")
     ap.add_argument("--labels", choices=["vad_labels", "ibm_labels"], default="ibm_labels")
     ap.add_argument("--h5", default=None)
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic training frames instead of --h5")
@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--out", default="models/fused_run")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
+    if a.model == "M2_info":
+        a.labels = "vad_labels"                     # scripts/training_M2_info_vad.py: VAD labels, alpha 0 / beta 10 / gamma 1
     y_dim = 0 if a.model == "M1" else (1 if a.labels == "vad_labels" else 513)
     if a.h5:
         train, valid = DeviceFrames.from_hdf5(a.h5, "train"), DeviceFrames.from_hdf5(a.h5, "validation")
