@@ -98,3 +98,30 @@ def test_fused_front_end_writes_training_layout(labels):
     else:
         ref = unpack(utt + "_ibm").T
         assert Y.shape == ref.shape and (Y.cpu().numpy() != ref).mean() < 1e-5
+
+
+def test_train_set_builder_example(tmp_path):
+    """examples/build_train_set.py: reference dataset names / orientation, labels and statistics as the oracle computes them."""
+    import subprocess, sys
+    from scipy.io import wavfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lst, paths = tmp_path / "list.txt", []
+    for utt in UTTS[:2]:
+        p = str(tmp_path / f"{utt}.wav"); wavfile.write(p, 16000, FIX[utt + "_wav_i16"]); paths.append(p)
+    lst.write_text("\n".join(paths))
+    out = str(tmp_path / "set.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "build_train_set.py"), "--wav-list", str(lst), "--labels", "ibm_labels",
+                        "--split", "train", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(out)
+    P = [to.reference_front_end(FIX[u + "_wav_i16"])[2] for u in UTTS[:2]]
+    Xref = np.concatenate(P, axis=1).astype(np.float32)
+    assert d["X_train"].shape == Xref.shape and d["Y_train"].shape == Xref.shape
+    np.testing.assert_allclose(d["X_train"], Xref, rtol=2e-5, atol=1e-9)
+    Yref = np.concatenate([unpack(u + "_ibm") for u in UTTS[:2]], axis=1)
+    assert (d["Y_train"] != Yref).mean() < 1e-5
+    n = Xref.shape[1]
+    mean = Xref.astype(np.float64).sum(1) / n
+    std = np.sqrt((np.sum(Xref.astype(np.float64) ** 2, 1) - n * mean ** 2) / (n - 1))
+    np.testing.assert_allclose(d["X_train_mean"][:, 0], mean, rtol=1e-4)
+    np.testing.assert_allclose(d["X_train_std"][:, 0], std, rtol=1e-4)
