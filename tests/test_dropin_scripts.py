@@ -106,3 +106,19 @@ def test_training_M2_info_runs_unchanged(tmp_path, monkeypatch):
     assert len(saved["sd"]) == 26 and sum(v.numel() for v in saved["sd"].values()) == 272675
     log = open(tmp_path / "models" / os.listdir(tmp_path / "models")[0] / "output_batch.log").read()
     assert "Classif.: 0.000" in log                                      # alpha = 0 (quirk Q4)
+
+
+def test_training_M2_info_pretrain_runs_unchanged(tmp_path, monkeypatch):
+    """The pretrain variant loads a checkpoint, keeps its classifier tensors (key filter, training_M2_info_vad_pretrain.py:102-112)
+    and trains on: the filtered tensors must land in the model that is saved."""
+    from packages.models.models import DeepGenerativeModel_v5
+    torch.manual_seed(3)
+    donor = DeepGenerativeModel_v5([513, 1, 16, [128, 128]]).state_dict()
+    donor = {k: v.clone() + 1.0 for k, v in donor.items()}                  # recognisable values
+    monkeypatch.setattr(torch, "load", lambda *a, **k: donor)
+    saved = _run("training_M2_info_vad_pretrain.py", 1, tmp_path, monkeypatch)
+    assert len(saved["sd"]) == 26
+    k = "enc_dec_clf.classifier.hidden.1.weight"
+    # alpha = 0: the classifier receives exactly zero gradients, so Adam leaves the loaded tensors untouched (quirks Q4, Q5)
+    assert torch.equal(saved["sd"][k], donor[k])
+    assert not torch.equal(saved["sd"]["enc_dec_clf.encoder.hidden.0.weight"], donor["enc_dec_clf.encoder.hidden.0.weight"])
