@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--y-dim", type=int, default=None, help="label width (M2 default 513 = IBM labels, the script default)")
     ap.add_argument("--batch", type=int, default=8192, help="frames per step per GPU")
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
     ap.add_argument("--pool-gb", type=float, default=1.0)
     ap.add_argument("--ksplit", type=int, default=0, help="frame-axis slices of the weight-gradient kernel (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -26,6 +26,7 @@ struct PolF32 {
     typedef f32x4 Frag;
     typedef f32x4 Pack4;
     static constexpr int E = 4;        // elements per 16-byte fragment
+    static constexpr int NP = 1;       // operand planes (2 = bf16 hi + lo, see PolX3)
     static constexpr int KSTEP = 8;    // reduction depth per fragment pair
     static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
     static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
@@ -53,6 +54,7 @@ struct PolBF16 {
     typedef bf16x8 Frag;
     typedef bf16x4 Pack4;
     static constexpr int E = 8;
+    static constexpr int NP = 1;
     static constexpr int KSTEP = 16;
     static constexpr int PD = 16;
     static constexpr int PRE = 6;
@@ -89,6 +91,23 @@ struct PolBF16 {
     static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 };
 
+// Split-bf16 ("bf16x3"): every MFMA operand is a PAIR of bf16 planes, v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
+// (16 mantissa bits), and a product takes three MFMAs: hi*hi + lo*hi + hi*lo (lo*lo is below fp32 resolution).
+// tools/exp_precision.py: with ANY operand role left at one bf16 the weight gradients are off by 2e-3..4e-2 of their
+// maximum at 8192 frames; with every operand split they hold 1e-4 (losses 1e-7) -- the parity-grade throughput mode,
+// at 3/16 of the fp32-MFMA cost.  Planes sit at fixed offsets: LDS activations `Pl<P>::lds` elements apart, weight
+// copies and stash tiles a run-time plane stride apart; the layouts inside a plane are exactly PolBF16's.
+struct PolX3 : PolBF16 {
+    static constexpr int NP = 2;
+    static constexpr int PD = 8;       // k-steps of weight fragments in flight (x 2 planes = the registers of PolBF16's 16)
+    static constexpr int PRE = 3;
+    static constexpr int PRE128 = 4;
+    static constexpr int PREBIG = 6;
+    static constexpr int WRING = 4;
+    static constexpr bool EARLY_Y = false;
+    static constexpr bool XFULL = false;   // two operand planes fill the LDS: the fp32 x tile streams in 128-column slices
+};
+
 // LDS row strides (elements): an odd number of 16-byte slots per row
 template <typename T> struct Ld {
     static constexpr int per16 = 16 / (int)sizeof(T);
@@ -100,8 +119,13 @@ template <typename T> struct Ld {
     static constexpr int ninfo = 6 * HD + 8;         // M2_info: bc1 bc2 wc3 ba1 ba2 wa3, bc3, ba3
     static constexpr int xf_floats = (TB * XD + 63) / 64 * 64;
     static constexpr int xt_floats = (TB * xt + 63) / 64 * 64;
-    static constexpr size_t bytes_slices = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xt_floats + nbias + ninfo) * sizeof(float) + 64;
-    static constexpr size_t bytes_full = (size_t)TB * (u + 2 * hh + z) * sizeof(T) + (size_t)(xf_floats + nbias + ninfo) * sizeof(float) + 64;
+    static constexpr int act_elems = TB * (u + 2 * hh + z);      // one plane of U | Ha | Hb | Zb
+    static constexpr size_t float_bytes(bool xfull) { return (size_t)((xfull ? xf_floats : xt_floats) + nbias + ninfo) * sizeof(float) + 64; }
+};
+// LDS plane stride (elements) between the hi and lo images of the activation buffers; dynamic LDS bytes of the rows kernel
+template <typename P> struct Pl {
+    static constexpr int lds = P::NP == 2 ? Ld<typename P::T>::act_elems : 0;
+    static constexpr size_t bytes = (size_t)Ld<typename P::T>::act_elems * P::NP * sizeof(typename P::T) + Ld<typename P::T>::float_bytes(P::XFULL);
 };
 
 __device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -110,7 +134,7 @@ __device__ __forceinline__ int feat_of(int r, int h) { return (r & 3) + 8 * (r >
 // next layer's first fragments are in flight across the current layer's epilogue and barrier).
 template <typename P, int NSTEPS, int PREN = P::PRE> struct WPre {
     static constexpr int N = NSTEPS < PREN ? NSTEPS : PREN;
-    typename P::Frag a[N > 0 ? N : 1];
+    typename P::Frag a[N > 0 ? N : 1][P::NP];
 };
 
 // Weight fragments are fetched with buffer loads: one resource descriptor for the whole weight-copy
@@ -119,18 +143,36 @@ template <typename P, int NSTEPS, int PREN = P::PRE> struct WPre {
 // whenever the k-step stride exceeds the 4 KB immediate range, spills them, and reloads each from
 // scratch behind an s_waitcnt vmcnt(0) in front of every weight load (measured: 600 cycles per k-step).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-struct WRef { int voff; unsigned soff; };      // per-lane byte offset (VGPR), wave-uniform byte offset (SGPR)
+struct WRef { int voff; unsigned soff; unsigned pl; };      // per-lane byte offset (VGPR), wave-uniform byte offset (SGPR), byte stride between operand planes (SGPR)
 
 template <typename P>
 __device__ __forceinline__ typename P::Frag wload(__amdgpu_buffer_rsrc_t rs, WRef r, unsigned step_bytes) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, r.voff, r.soff + step_bytes, 0);
     return __builtin_bit_cast(typename P::Frag, v);
 }
+// all planes of one weight fragment
+template <typename P>
+__device__ __forceinline__ void wloadp(typename P::Frag (&a)[P::NP], __amdgpu_buffer_rsrc_t rs, WRef r, unsigned step_bytes) {
+    a[0] = wload<P>(rs, r, step_bytes);
+    if constexpr (P::NP == 2) a[1] = wload<P>(rs, r, step_bytes + r.pl);
+}
+// all planes of one LDS activation fragment
+template <typename P>
+__device__ __forceinline__ void bloadp(typename P::Frag (&b)[P::NP], const typename P::T* p) {
+    b[0] = *reinterpret_cast<const typename P::Frag*>(p);
+    if constexpr (P::NP == 2) b[1] = *reinterpret_cast<const typename P::Frag*>(p + Pl<P>::lds);
+}
+// acc += a * b over all plane pairs that matter: hi*hi, lo*hi, hi*lo
+template <typename P>
+__device__ __forceinline__ void mmap(f32x16& acc, const typename P::Frag (&a)[P::NP], const typename P::Frag (&b)[P::NP]) {
+    if constexpr (P::NP == 2) { P::mma(acc, a[1], b[0]); P::mma(acc, a[0], b[1]); }
+    P::mma(acc, a[0], b[0]);
+}
 
 template <typename P, int NSTEPS, int PREN>
 __device__ __forceinline__ void wprefetch(WPre<P, NSTEPS, PREN>& w, __amdgpu_buffer_rsrc_t rs, WRef wr, unsigned WSTR) {
 #pragma unroll
-    for (int i = 0; i < WPre<P, NSTEPS, PREN>::N; ++i) w.a[i] = wload<P>(rs, wr, i * WSTR);
+    for (int i = 0; i < WPre<P, NSTEPS, PREN>::N; ++i) wloadp<P>(w.a[i], rs, wr, i * WSTR);
     // hipcc otherwise sinks these loads down to their first use (after the epilogue and barrier)
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -155,11 +197,13 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PR
     // activation fragments are read from LDS BD k-steps ahead; BD divides D so ring slots are static across laps
     constexpr int BD = D % 4 == 0 ? 4 : (D % 3 == 0 ? 3 : (D % 2 == 0 ? 2 : 1));
     static_assert(NIT <= 1 || D % BD == 0, "B ring must divide the weight ring");
-    Frag a[D > 0 ? D : 1];
+    Frag a[D > 0 ? D : 1][P::NP];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        if (i < WPre<P, NSTEPS, PREN>::N) a[i] = w.a[i];
-        else a[i] = wload<P>(rs, wr, i * WSTR);
+        if (i < WPre<P, NSTEPS, PREN>::N) {
+#pragma unroll
+            for (int q = 0; q < P::NP; ++q) a[i][q] = w.a[i][q];
+        } else wloadp<P>(a[i], rs, wr, i * WSTR);
     }
     // Order pins: without them hipcc moves every weight load down to just above the MFMA that
     // consumes it (one exposed L2 round trip per k-step, measured 150 ns/step instead of ~30).
@@ -168,19 +212,19 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PR
     __builtin_amdgcn_sched_barrier(0);
     // B ring: with the order pinned, an LDS read issued right before its MFMA exposes the full LDS
     // latency every k-step (measured ~250 cycles/step on an idle chip); keep BD reads in flight instead.
-    Frag bq[BD];
+    Frag bq[BD][P::NP];
 #pragma unroll
     for (int i = 0; i < BD; ++i)
-        if (i < NSTEPS) bq[i] = *reinterpret_cast<const Frag*>(brow + i * STR);
+        if (i < NSTEPS) bloadp<P>(bq[i], brow + i * STR);
     if (NIT > 1) {
 #pragma unroll 1
         for (int c = 0; c < NIT - 1; ++c) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                P::mma(acc, a[i], bq[i % BD]);
+                mmap<P>(acc, a[i], bq[i % BD]);
                 // D is a multiple of BD whenever NIT > 1, so slot i % BD is static across laps
-                bq[i % BD] = *reinterpret_cast<const Frag*>(brow + (c * D + i + BD) * STR);
-                a[i] = wload<P>(rs, wr, ((c + 1) * D + i) * WSTR);
+                bloadp<P>(bq[i % BD], brow + (c * D + i + BD) * STR);
+                wloadp<P>(a[i], rs, wr, ((c + 1) * D + i) * WSTR);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -189,17 +233,17 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PR
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             constexpr int base = (NIT - 1) * D;
-            P::mma(acc, a[i], bq[(base + i) % BD]);
-            if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
-            if (i < REM) a[i] = wload<P>(rs, wr, (NIT * D + i) * WSTR);
+            mmap<P>(acc, a[i], bq[(base + i) % BD]);
+            if (base + i + BD < NSTEPS) bloadp<P>(bq[(base + i) % BD], brow + (base + i + BD) * STR);
+            if (i < REM) wloadp<P>(a[i], rs, wr, (NIT * D + i) * WSTR);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
         constexpr int base = NIT * D;
-        P::mma(acc, a[i], bq[(base + i) % BD]);
-        if (base + i + BD < NSTEPS) bq[(base + i) % BD] = *reinterpret_cast<const Frag*>(brow + (base + i + BD) * STR);
+        mmap<P>(acc, a[i], bq[(base + i) % BD]);
+        if (base + i + BD < NSTEPS) bloadp<P>(bq[(base + i) % BD], brow + (base + i + BD) * STR);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -252,6 +296,12 @@ __device__ __forceinline__ void put_lds(const float (&v)[16], typename P::T* lds
         Pack4 p;
         p[0] = P::cvt(v[4 * gq]); p[1] = P::cvt(v[4 * gq + 1]); p[2] = P::cvt(v[4 * gq + 2]); p[3] = P::cvt(v[4 * gq + 3]);
         *reinterpret_cast<Pack4*>(lds + l31 * ldl + fbase + 8 * gq + 4 * h) = p;
+        if constexpr (P::NP == 2) {          // lo plane: what the hi plane rounded away
+            Pack4 q;
+            q[0] = P::cvt(v[4 * gq] - (float)p[0]); q[1] = P::cvt(v[4 * gq + 1] - (float)p[1]);
+            q[2] = P::cvt(v[4 * gq + 2] - (float)p[2]); q[3] = P::cvt(v[4 * gq + 3] - (float)p[3]);
+            *reinterpret_cast<Pack4*>(lds + Pl<P>::lds + l31 * ldl + fbase + 8 * gq + 4 * h) = q;
+        }
     }
 }
 

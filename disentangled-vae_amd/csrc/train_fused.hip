@@ -74,6 +74,8 @@ struct RowsArgs {
     const float* w5last;   // fp32 row 512 of the output layer (the one real feature of the 17th 32-row tile)
     void *xT, *yT, *h1T, *h2T, *dh1T, *dh2T, *dmlvT, *zT, *d1T, *d2T, *dd1T, *dd2T, *daT;
     const void* wcopy; int64_t wcopy_bytes;   // whole weight-copy buffer (one buffer descriptor)
+    int64_t spl;                              // stash: elements between the hi and lo operand planes (PolX3)
+    unsigned wpl_bytes;                       // weight copies: bytes between the planes
     // M2_info (DeepGenerativeModel_v5): classifier on x, auxiliary classifier on z (both 128-128-1, relu/relu/sigmoid)
     const void *Wc1s, *Wc2s, *Wc2t, *Wa1s, *Wa1t, *Wa2s, *Wa2t;
     const float *bc1, *bc2, *wc3, *bc3, *ba1, *ba2, *wa3, *ba3;
@@ -103,7 +105,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
 }
 
 template <typename P>
-__device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr,
+__device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr, int64_t spl,
                                            int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
@@ -114,22 +116,35 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
         const int i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
         const T* blk = lds + q * ldl + fbase + 16 * cg + 4 * pp;
         const bool keep = fbase + l31 < col_limit;
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int i = 0; i < TB / (2 * E); ++i) {
             const int gq = h + 2 * i;                      // frame group: frames gq*8 .. gq*8+7
-            const s16x4 lo = lds_tr16(blk + (8 * gq) * ldl), hi = lds_tr16(blk + (8 * gq + 4) * ldl);
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-            s16x8 raw = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            Frag f = __builtin_bit_cast(Frag, raw);
+            Frag f[P::NP];
+#pragma unroll
+            for (int pl = 0; pl < P::NP; ++pl) {
+                const T* bp = blk + pl * Pl<P>::lds;
+                const s16x4 r0 = lds_tr16(bp + (8 * gq) * ldl), r1 = lds_tr16(bp + (8 * gq + 4) * ldl);
+                s16x8 raw = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                f[pl] = __builtin_bit_cast(Frag, raw);
+            }
             if (scale != 1.f) {
 #pragma unroll
-                for (int j = 0; j < E; ++j) f[j] = P::cvt((float)f[j] * scale);
+                for (int j = 0; j < E; ++j) {
+                    if constexpr (P::NP == 2) {
+                        const float v = ((float)f[0][j] + (float)f[1][j]) * scale;
+                        f[0][j] = P::cvt(v); f[1][j] = P::cvt(v - (float)f[0][j]);
+                    } else f[0][j] = P::cvt((float)f[0][j] * scale);
+                }
             }
             if (!keep) {
 #pragma unroll
-                for (int j = 0; j < E; ++j) f[j] = P::cvt(0.f);
+                for (int pl = 0; pl < P::NP; ++pl)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) f[pl][j] = P::cvt(0.f);
             }
-            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
+#pragma unroll
+            for (int pl = 0; pl < P::NP; ++pl) *reinterpret_cast<Frag*>(dst + pl * spl + gq * 32 * E) = f[pl];
         }
     } else {
 #pragma unroll
@@ -156,7 +171,9 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
         const int row = idx / pcols, col = idx - row * pcols;
         float v = 0.f;
         if (col < ncols && b0 + row < B) v = src[rowof(row) * ld + col];
-        U[row * ldu + col] = P::cvt(v);
+        const typename P::T vh = P::cvt(v);
+        U[row * ldu + col] = vh;
+        if constexpr (P::NP == 2) U[Pl<P>::lds + row * ldu + col] = P::cvt(v - (float)vh);
         if (xf && col < ncols) xf[row * ncols + col] = v;
     }
 }
@@ -191,22 +208,31 @@ __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename
         Pack4 pk;
         pk[0] = P::cvt(v[i][0]); pk[1] = P::cvt(v[i][1]); pk[2] = P::cvt(v[i][2]); pk[3] = P::cvt(v[i][3]);
         *reinterpret_cast<Pack4*>(U + row * ldu + col) = pk;
+        if constexpr (P::NP == 2) {
+            Pack4 pl;
+            pl[0] = P::cvt(v[i][0] - (float)pk[0]); pl[1] = P::cvt(v[i][1] - (float)pk[1]);
+            pl[2] = P::cvt(v[i][2] - (float)pk[2]); pl[3] = P::cvt(v[i][3] - (float)pk[3]);
+            *reinterpret_cast<Pack4*>(U + Pl<P>::lds + row * ldu + col) = pl;
+        }
     }
     constexpr int PADC = PCOLS - XD;                            // column 512, then PADC zero columns
     if (tid < TB) {
         if (xf) xf[tid * XD + XD - 1] = v[16][0];
-        U[tid * ldu + XD - 1] = P::cvt(v[16][0]);
+        const typename P::T vh = P::cvt(v[16][0]);
+        U[tid * ldu + XD - 1] = vh;
+        if constexpr (P::NP == 2) U[Pl<P>::lds + tid * ldu + XD - 1] = P::cvt(v[16][0] - (float)vh);
     }
     for (int idx = tid; idx < TB * PADC; idx += 256) {
         const int r = idx / PADC, c = XD + idx - r * PADC;
         U[r * ldu + c] = P::cvt(0.f);
+        if constexpr (P::NP == 2) U[Pl<P>::lds + r * ldu + c] = P::cvt(0.f);
     }
 }
 
 // LDS U[frame][col] -> fragment-major stash (see put_tile), 16 bytes (E frames of one feature) per
 // store; feature rows up to `srows` (multiple of 32) are written, columns >= pcols as zeros
 template <typename P>
-__device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, int pcols, int srows, typename P::T* stash,
+__device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, int pcols, int srows, typename P::T* stash, int64_t spl,
                                                int64_t Bp, int64_t b0, int tid) {
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
@@ -214,7 +240,7 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
         // one wave per 32-feature tile (wave-uniform loop: EXEC stays all ones for the transposing reads)
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         for (int ft = wave; ft < srows / 32; ft += 4)
-            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, b0, lane & 31, lane >> 5, 1.f, pcols);
+            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, spl, b0, lane & 31, lane >> 5, 1.f, pcols);
         return;
     }
     constexpr int groups = TB / E;
@@ -262,7 +288,7 @@ struct SideArgs {
     bool live, need_dx;
     float scale;                    // factor applied to the stashed pre-activation gradients (loss weight)
     void *h1T, *h2T, *d1T, *d2T, *d3T;
-    int64_t Bp, b0;
+    int64_t Bp, b0, spl;
 };
 
 template <typename P, int K1STEPS>
@@ -290,7 +316,7 @@ __device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideA
     __syncthreads();
     // layer 2 + output dot product
     zero_acc<P>(acc);
-    gemm_block<P, HD / KS>(acc, w2, wrs, a.W2, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.h1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h); });
+    gemm_block<P, HD / KS>(acc, w2, wrs, a.W2, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.h1T + (int64_t)wave * 32 * a.Bp, a.spl, a.b0, l31, h); });
     WPre<P, HD / KS, P::PRE128> w2t;
     wprefetch<P, HD / KS>(w2t, wrs, a.W2t, S4);
     bias16(a.b2, fb, h, bv);
@@ -309,10 +335,12 @@ __device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideA
     bce_frame = a.live ? -(a.y * lp + (1.f - a.y) * lq) : 0.f;                              // utils.py:55-56, this frame's term
     const float u = a.live ? -a.invB * (a.y / (p + a.eps) - (1.f - a.y) / (1.f - p + a.eps)) : 0.f;   // d BCE / d p
     const float dpre3 = u * p * (1.f - p);
-    stash_tile<P>(Hb, LDH, fb, (T*)a.h2T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h);
+    stash_tile<P>(Hb, LDH, fb, (T*)a.h2T + (int64_t)wave * 32 * a.Bp, a.spl, a.b0, l31, h);
     if (wave == 0 && h == 0) {       // output pre-activation gradient: feature row 0 of a 32-row stash tile
         T* d3 = (T*)a.d3T + (a.b0 / KS) * (64 * E) + (l31 / E) * 32 * E + (l31 % E);
-        *d3 = P::cvt(dpre3 * a.scale);
+        const T d3h = P::cvt(dpre3 * a.scale);
+        *d3 = d3h;
+        if constexpr (P::NP == 2) d3[a.spl] = P::cvt(dpre3 * a.scale - (float)d3h);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv[r] = c2r[r] > 0.f ? w3v[r] * dpre3 : 0.f;            // dpre2 (unit scale)
@@ -320,7 +348,7 @@ __device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideA
     __syncthreads();
     // backward through layer 2
     zero_acc<P>(acc);
-    gemm_block<P, HD / KS>(acc, w2t, wrs, a.W2t, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.d2T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h, a.scale); });
+    gemm_block<P, HD / KS>(acc, w2t, wrs, a.W2t, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (T*)a.d2T + (int64_t)wave * 32 * a.Bp, a.spl, a.b0, l31, h, a.scale); });
     WPre<P, HD / KS> w1t;
     if (a.need_dx && wave == 0) wprefetch<P, HD / KS>(w1t, wrs, a.W1t, a.s1t);
 #pragma unroll
@@ -329,9 +357,9 @@ __device__ __forceinline__ void side_mlp(__amdgpu_buffer_rsrc_t wrs, const SideA
     __syncthreads();
     zero_acc<P>(dx);
     if (a.need_dx && wave == 0) {
-        gemm_block<P, HD / KS>(dx, w1t, wrs, a.W1t, Hbr, a.s1t, [&]() { stash_tile<P>(Hb, LDH, fb, (T*)a.d1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h, a.scale); });
+        gemm_block<P, HD / KS>(dx, w1t, wrs, a.W1t, Hbr, a.s1t, [&]() { stash_tile<P>(Hb, LDH, fb, (T*)a.d1T + (int64_t)wave * 32 * a.Bp, a.spl, a.b0, l31, h, a.scale); });
     } else {
-        stash_tile<P>(Hb, LDH, fb, (T*)a.d1T + (int64_t)wave * 32 * a.Bp, a.b0, l31, h, a.scale);
+        stash_tile<P>(Hb, LDH, fb, (T*)a.d1T + (int64_t)wave * 32 * a.Bp, a.spl, a.b0, l31, h, a.scale);
     }
     __syncthreads();
 }
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     T* Ha = U + TB * LDU;
     T* Hb = Ha + TB * LDH;
     T* Zb = Hb + TB * LDH;
-    float* Xt = reinterpret_cast<float*>(Zb + TB * LDZ);     // XFULL: dense [32][513] fp32 x tile; else [32][129] slice
+    float* Xt = reinterpret_cast<float*>(U + P::NP * Ld<T>::act_elems);     // behind the operand plane(s).  XFULL: dense [32][513] fp32 x tile; else [32][129] slice
     float* Bias = Xt + (P::XFULL ? Ld<T>::xf_floats : Ld<T>::xt_floats);
     constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
     // M2_info tables behind the VAE biases: bc1 bc2 wc3 ba1 ba2 wa3 (128 each), then bc3, ba3
@@ -371,8 +399,8 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     constexpr unsigned SZ = sizeof(T);
     auto wbase = [&](const void* Wp, int tile, int ld) -> WRef {
         const unsigned m = (unsigned)((const char*)Wp - (const char*)g.wcopy);
-        if (WFRAG) return WRef{lane * 16, m + (unsigned)tile * (FB * SZ)};
-        return WRef{(int)((l31 * ld + h * E) * SZ), m + (unsigned)(32 * tile * ld) * SZ};
+        if (WFRAG) return WRef{lane * 16, m + (unsigned)tile * (FB * SZ), g.wpl_bytes};
+        return WRef{(int)((l31 * ld + h * E) * SZ), m + (unsigned)(32 * tile * ld) * SZ, g.wpl_bytes};
     };
     // byte strides between k-steps (4-tile, 1-tile and 17-tile matrices), between row tiles of W5s, and the
     // byte offsets of the y k-blocks inside W1 / W3
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
     const WRef W3ztr = wbase(g.W3zt, 0, HD);
     const WRef Wmvtr = wbase(g.Wmvt, wave_u, 32);
     const WRef W2tr = wbase(g.W2t, wave_u, HD);
-    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes}; };
+    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
     const T* const Ur = U + l31 * LDU + h * E;
     const T* const Har = Ha + l31 * LDH + h * E;
     const T* const Hbr = Hb + l31 * LDH + h * E;
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         f32x16 acc;
         zero_acc<P>(acc);
         gemm_block<P, XP / KS>(acc, w1x, wrs, W1r, Ur, S4, [&]() {
-            if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.Bp, b0, tl);
+            if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
         });
         DVAE_STAMP(2);
         if (INFO) {
@@ -515,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             sa.W1 = wbase(g.Wc1s, wave_u, XP); sa.W2 = wbase(g.Wc2s, wave_u, HD); sa.W2t = wbase(g.Wc2t, wave_u, HD); sa.W1t = sa.W2t;
             sa.s1 = S4; sa.s1t = S4; sa.b1 = Bias + OBC1; sa.b2 = Bias + OBC2; sa.w3 = Bias + OWC3; sa.b3 = Bias[OS3];
             sa.y = y_l; sa.invB = g.invB; sa.eps = g.elbo_eps; sa.live = live; sa.need_dx = false; sa.scale = g.alpha;
-            sa.h1T = g.c1T; sa.h2T = g.c2T; sa.d1T = g.dc1T; sa.d2T = g.dc2T; sa.d3T = g.dc3T; sa.Bp = g.Bp; sa.b0 = b0;
+            sa.h1T = g.c1T; sa.h2T = g.c2T; sa.d1T = g.dc1T; sa.d2T = g.dc2T; sa.d3T = g.dc3T; sa.Bp = g.Bp; sa.b0 = b0; sa.spl = g.spl;
             float pc; f32x16 dxc;
             side_mlp<P, XP / KS>(wrs, sa, Ur, Ha, Hb, red2, wave, l31, h, S4, bce_c, pc, dxc);
             acc = acc_keep;
@@ -535,11 +563,11 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             __syncthreads();
             if (YENC) {
                 gemm_block<P, (YENC ? YP : 0) / KS>(acc, w1y, wrs, woff(W1r, KB1), Ur, S4, [&]() {
-                    if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
+                    if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
                 });
                 wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
             } else {
-                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.Bp, b0, tl);
+                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
             }
         }
         float h1r[16], bv[16];
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(4);
         // ---------------- encoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4, [&]() { DVAE_FSTAMP(16); stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); DVAE_FSTAMP(17); });
+        gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4, [&]() { DVAE_FSTAMP(16); stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h1T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); DVAE_FSTAMP(17); });
         DVAE_FSTAMP(18);
         WPre<P, HD / KS, P::PRE128> wmv;
         WPre<P, ZD / KS> w3z;
@@ -577,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (YP > 0) wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, wmv, wrs, Wmvr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+            gemm_block<P, HD / KS>(acc, wmv, wrs, Wmvr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); });
             float zv[16];
             bias16(Bias + OBMV, 0, h, bv);                          // rows 0-15 bmu, 16-31 blv
 #pragma unroll
@@ -592,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             // z block of the decoder input: features 0..15 valid, 16..31 zero
             put_lds<P>(zv, Zb, LDZ, 0, l31, h);
         } else {
-            stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h);
+            stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.h2T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h);
         }
         __syncthreads();
 
@@ -602,14 +630,14 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             sa.W1 = wbase(g.Wa1s, wave_u, ZD); sa.W2 = wbase(g.Wa2s, wave_u, HD); sa.W2t = wbase(g.Wa2t, wave_u, HD); sa.W1t = wbase(g.Wa1t, 0, HD);
             sa.s1 = S4; sa.s1t = S1; sa.b1 = Bias + OBA1; sa.b2 = Bias + OBA2; sa.w3 = Bias + OWA3; sa.b3 = Bias[OS3 + 1];
             sa.y = y_l; sa.invB = g.invB; sa.eps = g.elbo_eps; sa.live = live; sa.need_dx = true; sa.scale = g.gamma - g.beta;
-            sa.h1T = g.a1T; sa.h2T = g.a2T; sa.d1T = g.da1T; sa.d2T = g.da2T; sa.d3T = g.da3T; sa.Bp = g.Bp; sa.b0 = b0;
+            sa.h1T = g.a1T; sa.h2T = g.a2T; sa.d1T = g.da1T; sa.d2T = g.da2T; sa.d3T = g.da3T; sa.Bp = g.Bp; sa.b0 = b0; sa.spl = g.spl;
             float pa;
-            if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h);
+            if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
             side_mlp<P, ZD / KS>(wrs, sa, Zbr, Ha, Hb, red2, wave, l31, h, S4, bce_a, pa, dzu);
         }
         // ---------------- decoder layer 1: [z | y] -> d1 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (!INFO && wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, b0, l31, h); });
+        gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4, [&]() { if (!INFO && wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h); });
         WPre<P, HD / KS, P::PRE128> w4;
         if (YP > 0) gemm_block<P, (YP > 0 ? YP : KS) / KS>(acc, w3y, wrs, woff(W3r, KB3), Ur, S4);
         wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
@@ -623,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(7);
         // ---------------- decoder layer 2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+        gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d1T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); });
         WPre<P, HD / KS, P::PRE128> w5;
         wprefetch<P, HD / KS>(w5, wrs, woff(W5s, wave_u * TSTEP), S17);
         float xr[16];
@@ -643,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             if (t == 4) DVAE_FSTAMP(21);
             zero_acc<P>(acc);
             const WRef wr = woff(W5s, (unsigned)t * TSTEP);
-            gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { if (t < 4) stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+            gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17, [&]() { if (t < 4) stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.d2T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); });
             if (t == 4) DVAE_FSTAMP(22);
             if (t + 4 < (P::XFULL ? NT_OUT - 1 : NT_OUT)) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
             else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
@@ -732,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- backward: d2 <- da ----------------
         zero_acc<P>(acc);
         gemm_block<P, NO / KS>(acc, w5t, wrs, W5tr, Ur, S4, [&]() {
-            for (int t = wave; t < NT_OUT; t += 4) stash_tile<P>(U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT + (int64_t)(t) * 32 * g.Bp, b0, l31, h);
+            for (int t = wave; t < NT_OUT; t += 4) stash_tile<P>(U, LDU, 32 * t, (g.ablate & 1) ? nullptr : (T*)g.daT + (int64_t)(t) * 32 * g.Bp, g.spl, b0, l31, h);
         });
         WPre<P, HD / KS, P::PRE128> w4t;
         wprefetch<P, HD / KS>(w4t, wrs, W4tr, S4);
@@ -745,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(10);
         // ---------------- backward: d1 <- dpre_d2 ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w4t, wrs, W4tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+        gemm_block<P, HD / KS>(acc, w4t, wrs, W4tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd2T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); });
         WPre<P, HD / KS, P::PRE128> w3zt;
         WPre<P, 32 / KS> wmvt;
         if (wave == 0) wprefetch<P, HD / KS>(w3zt, wrs, W3ztr, S1);
@@ -759,7 +787,7 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
         if (wave == 0) {
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w3zt, wrs, W3ztr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+            gemm_block<P, HD / KS>(acc, w3zt, wrs, W3ztr, Hbr, S1, [&]() { stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); });
             float dml[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -769,14 +797,14 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
             }
             put_lds<P>(dml, Zb, LDZ, 0, l31, h);
         } else {
-            stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h);
+            stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dd1T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h);
         }
         __syncthreads();
 
         DVAE_STAMP(12);
         // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
         zero_acc<P>(acc);
-        gemm_block<P, 32 / KS>(acc, wmvt, wrs, Wmvtr, Zbr, S4, [&]() { if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, b0, l31, h); });
+        gemm_block<P, 32 / KS>(acc, wmvt, wrs, Wmvtr, Zbr, S4, [&]() { if (wave == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h); });
         WPre<P, HD / KS, P::PRE128> w2t;
         wprefetch<P, HD / KS>(w2t, wrs, W2tr, S4);
 #pragma unroll
@@ -787,11 +815,11 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         DVAE_STAMP(13);
         // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
         zero_acc<P>(acc);
-        gemm_block<P, HD / KS>(acc, w2t, wrs, W2tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h); });
+        gemm_block<P, HD / KS>(acc, w2t, wrs, W2tr, Har, S4, [&]() { stash_tile<P>(Ha, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh2T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h); });
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
         put_lds<P>(dv, Hb, LDH, fb, l31, h);
-        stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T + (int64_t)(wave) * 32 * g.Bp, b0, l31, h);
+        stash_tile<P>(Hb, LDH, fb, (g.ablate & 1) ? nullptr : (T*)g.dh1T + (int64_t)(wave) * 32 * g.Bp, g.spl, b0, l31, h);
 
         DVAE_STAMP(14);
         // ---------------- per-tile loss sums ----------------
@@ -839,11 +867,11 @@ struct GroupDesc {
 };
 
 template <typename P, bool A1, bool B1>
-__device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int64_t kend, int64_t Bp, float* __restrict__ slab,
+__device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int64_t kend, int64_t Bp, int64_t spl, float* __restrict__ slab,
                                            int l31, int h) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
-    constexpr int E = P::E, KS = P::KSTEP;
+    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
     const int lane = h * 32 + l31;
     constexpr int FB = 64 * E;                              // elements per (feature tile, k-step) block
     const T* a0p = (const T*)d.A[0] + lane * E;
@@ -857,17 +885,21 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
     const Frag one = P::ones();
     const int64_t sbeg = kbeg / KS, send = kend / KS;       // k-steps of this frame slice
     // The stash was written once by the previous kernel: these are cold HBM/MALL reads (~2 us round trip).
-    // A ring of RD k-steps per operand keeps 4 * RD 1-KB loads in flight per wave; the slot an MFMA group has
+    // A ring of RD k-steps per operand keeps 4 * RD (x planes) 1-KB loads in flight per wave; the slot an MFMA group has
     // consumed is re-requested RD steps ahead (clamped on the last lap: a harmless reload, no branch).
     constexpr int RD = P::WRING;
-    Frag a0[RD], a1[RD], b0[RD], b1[RD];
+    Frag a0[RD][NP], a1[RD][NP], b0[RD][NP], b1[RD][NP];
+    auto ldp = [&](Frag (&f)[NP], const T* p, int64_t sk) {
+        f[0] = *reinterpret_cast<const Frag*>(p + sk * FB);
+        if constexpr (NP == 2) f[1] = *reinterpret_cast<const Frag*>(p + spl + sk * FB);
+    };
 #pragma unroll
     for (int i = 0; i < RD; ++i) {
         int64_t sk = sbeg + i; sk = sk < send ? sk : send - 1;
-        a0[i] = *reinterpret_cast<const Frag*>(a0p + sk * FB);
-        b0[i] = *reinterpret_cast<const Frag*>(b0p + sk * FB);
-        if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + sk * FB);
-        if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + sk * FB);
+        ldp(a0[i], a0p, sk);
+        ldp(b0[i], b0p, sk);
+        if (A1) ldp(a1[i], a1p, sk);
+        if (B1) ldp(b1[i], b1p, sk);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
@@ -875,18 +907,18 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
 #pragma unroll
         for (int i = 0; i < RD; ++i) {
             if (sk + i < send) {                            // wave-uniform: slices are multiples of RD steps except the tail
-                P::mma(c00, a0[i], b0[i]);
-                if (B1) P::mma(c01, a0[i], b1[i]);
-                if (A1) P::mma(c10, a1[i], b0[i]);
-                if (A1 && B1) P::mma(c11, a1[i], b1[i]);
-                if (bias0) P::mma(cb0, a0[i], one);
-                if (A1) { if (bias1) P::mma(cb1, a1[i], one); }
+                mmap<P>(c00, a0[i], b0[i]);
+                if (B1) mmap<P>(c01, a0[i], b1[i]);
+                if (A1) mmap<P>(c10, a1[i], b0[i]);
+                if (A1 && B1) mmap<P>(c11, a1[i], b1[i]);
+                if (bias0) { P::mma(cb0, a0[i][0], one); if constexpr (NP == 2) P::mma(cb0, a0[i][1], one); }
+                if (A1) { if (bias1) { P::mma(cb1, a1[i][0], one); if constexpr (NP == 2) P::mma(cb1, a1[i][1], one); } }
             }
             int64_t sn = sk + RD + i; sn = sn < send ? sn : send - 1;
-            a0[i] = *reinterpret_cast<const Frag*>(a0p + sn * FB);
-            b0[i] = *reinterpret_cast<const Frag*>(b0p + sn * FB);
-            if (A1) a1[i] = *reinterpret_cast<const Frag*>(a1p + sn * FB);
-            if (B1) b1[i] = *reinterpret_cast<const Frag*>(b1p + sn * FB);
+            ldp(a0[i], a0p, sn);
+            ldp(b0[i], b0p, sn);
+            if (A1) ldp(a1[i], a1p, sn);
+            if (B1) ldp(b1[i], b1p, sn);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -919,7 +951,7 @@ __device__ __forceinline__ void wgrad_body(const GroupDesc& d, int64_t kbeg, int
 #endif
 template <typename P>
 __global__ __launch_bounds__(256, DVAE_WGRAD_OCC) void wgrad_kernel(const GroupDesc* __restrict__ groups, int ngroups, int ksplit, int64_t Bp,
-                                                    int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
+                                                    int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int slice = blockIdx.x % ksplit, wg = blockIdx.x / ksplit;
@@ -931,10 +963,10 @@ __global__ __launch_bounds__(256, DVAE_WGRAD_OCC) void wgrad_kernel(const GroupD
     if (kend > Bp) kend = Bp;
     float* slab = slabs + (int64_t)slice * slab_stride;
     const bool a1 = d.A[1] != nullptr, b1 = d.Bm[1] != nullptr;
-    if (a1 && b1) wgrad_body<P, true, true>(d, kbeg, kend, Bp, slab, l31, h);
-    else if (a1) wgrad_body<P, true, false>(d, kbeg, kend, Bp, slab, l31, h);
-    else if (b1) wgrad_body<P, false, true>(d, kbeg, kend, Bp, slab, l31, h);
-    else wgrad_body<P, false, false>(d, kbeg, kend, Bp, slab, l31, h);
+    if (a1 && b1) wgrad_body<P, true, true>(d, kbeg, kend, Bp, spl, slab, l31, h);
+    else if (a1) wgrad_body<P, true, false>(d, kbeg, kend, Bp, spl, slab, l31, h);
+    else if (b1) wgrad_body<P, false, true>(d, kbeg, kend, Bp, spl, slab, l31, h);
+    else wgrad_body<P, false, false>(d, kbeg, kend, Bp, spl, slab, l31, h);
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride) {
@@ -963,7 +995,7 @@ struct ApplyArgs {
     const float* slabs; int64_t slab_stride; int nslabs;
     const TensorDesc* tensors; int ntensors;
     const unsigned char* chunk_tensor; int64_t n_params;
-    void* wcopy;
+    void* wcopy; int64_t wpl;      // kernel-layout weight copies; elements between the hi and lo planes (NP == 2)
     float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
     const double* partials; int npartials; int64_t B; float* losses3; double* accum;
     int info; float alpha, beta, gamma;
@@ -972,7 +1004,7 @@ struct ApplyArgs {
 // One thread per parameter over the flat buffer (every load independent); chunk_tensor maps each
 // 64-float chunk to its tensor (tensors start on 64-float boundaries), 255 = alignment padding.
 // The block after the last parameter block finalises the loss scalars.
-template <typename T, bool ADAM>
+template <typename T, bool ADAM, int NP = 1>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     if (blockIdx.x == gridDim.x - 1) {                    // loss finalisation block
         if (!ADAM || g.losses3 == nullptr) return;
@@ -1044,13 +1076,19 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
     if (d.sf_off >= 0) {
         const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
-        if (WFRAG) wc[d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E] = (T)pi;
-        else wc[d.sf_off + (int64_t)rr * d.sf_ld + cc] = (T)pi;
+        const int64_t o = WFRAG ? d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
+                                : d.sf_off + (int64_t)rr * d.sf_ld + cc;
+        const T ph = (T)pi;
+        wc[o] = ph;
+        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
     }
     if (d.st_off >= 0 && c < d.st_cmax) {
         const int rr = c, cc = r + d.st_roff;
-        if (WFRAG) wc[d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E] = (T)pi;
-        else wc[d.st_off + (int64_t)rr * d.st_ld + cc] = (T)pi;
+        const int64_t o = WFRAG ? d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
+                                : d.st_off + (int64_t)rr * d.st_ld + cc;
+        const T ph = (T)pi;
+        wc[o] = ph;
+        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
     }
 }
 
@@ -1072,8 +1110,12 @@ struct Layout {
 
 static inline int64_t al(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+static inline bool is_bf(int precision) { return precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3; }
+static inline int planes_of(int precision) { return precision == DVAE_PREC_BF16X3 ? 2 : 1; }
+
 static int make_layout(const dvae_train_plan_t& p, Layout& L) {
-    const int esz = p.precision == DVAE_PREC_BF16 ? 2 : 4;
+    const int esz = is_bf(p.precision) ? 2 : 4;
+    const int np = planes_of(p.precision);
     L.yp = p.y_dim == 0 ? 0 : (p.y_dim + 15) / 16 * 16;
     L.ye = p.model == DVAE_MODEL_M2 ? L.yp : 0;
     L.info = p.model == DVAE_MODEL_M2_INFO;
@@ -1111,8 +1153,8 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
-    L.o_wcopy = bytes(L.wcopy_elems * esz);
-    L.o_stash = bytes(L.stash_rows * p.Bp * esz);
+    L.o_wcopy = bytes(L.wcopy_elems * esz * np);              // PolX3: hi plane, then lo plane
+    L.o_stash = bytes(L.stash_rows * p.Bp * esz * np);
     L.o_grads = bytes((int64_t)p.ksplit * p.n_params * sizeof(float));
     L.total = b;
     return 0;
@@ -1151,7 +1193,7 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
         set_error("train_plan: fused kernels cover M1 (y 0), M2 (y 1 or 513) and M2_info (y 1) at x 513 / h [128,128] / z 16; got model %d y_dim %d", model, y_dim);
         return DVAE_E_UNSUPPORTED;
     }
-    DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16, "train_plan: unknown precision %d", precision);
+    DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3, "train_plan: unknown precision %d", precision);
     memset(plan, 0, sizeof(*plan));
     plan->model = model; plan->y_dim = y_dim; plan->precision = precision; plan->B = B;
     plan->Bp = al(B, 128);
@@ -1168,15 +1210,15 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     }
     plan->n_params = off;
     const int64_t ntiles = (B + TB - 1) / TB;
-    const int64_t maxg = 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
+    const int64_t maxg = 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);   // persistent tile loop beyond this many workgroups
     plan->rows_grid = ntiles < maxg ? ntiles : maxg;
     int ks = ksplit_hint;
     // bf16: 8 slices up to 8192 frames (more slices = more slabs for the apply pass to sum); 12 beyond: 80 groups x 12 = 960
     // single-wave jobs fill the 1024 wave slots in one round (wgrad 164 -> 124 us at 65 536 frames, 2.49 -> 1.80 ms at 2^20).
     // fp32: the MFMA-bound wgrad needs a wave on every SIMD (>= 1024 wave jobs): 16.
     if (ks <= 0) {
-        const int cap = precision == DVAE_PREC_BF16 ? (plan->Bp > 12288 ? 12 : 8) : 16;
-        ks = (int)(plan->Bp / (precision == DVAE_PREC_BF16 ? 1024 : 512)); if (ks < 1) ks = 1; if (ks > cap) ks = cap;
+        const int cap = is_bf(precision) ? (plan->Bp > 12288 ? 12 : 8) : 16;
+        ks = (int)(plan->Bp / (is_bf(precision) ? 1024 : 512)); if (ks < 1) ks = 1; if (ks > cap) ks = cap;
     }
     if (ks > 64) ks = 64;
     plan->ksplit = ks;
@@ -1198,7 +1240,7 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
 }
 
 static int64_t kper_of(const dvae_train_plan_t* p) {
-    const int ks = p->precision == DVAE_PREC_BF16 ? 16 : 8;
+    const int ks = is_bf(p->precision) ? 16 : 8;
     const int64_t unit = 4 * ks;
     return al((p->Bp + p->ksplit - 1) / p->ksplit, unit);
 }
@@ -1304,7 +1346,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
     a.slabs = (const float*)(ws + L.o_grads); a.slab_stride = plan->n_params; a.nslabs = n_slabs;
     a.tensors = (const TensorDesc*)(ws + L.o_tensors); a.ntensors = plan->n_tensors;
     a.chunk_tensor = (const unsigned char*)(ws + L.o_chunks); a.n_params = plan->n_params;
-    a.wcopy = ws + L.o_wcopy;
+    a.wcopy = ws + L.o_wcopy; a.wpl = L.wcopy_elems;
     if (adam) {
         const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
         a.one_minus_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2);
@@ -1313,7 +1355,10 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
     a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3; a.accum = (double*)(uintptr_t)plan->loss_accum;
     a.info = plan->model == DVAE_MODEL_M2_INFO; a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
     const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
-    if (plan->precision == DVAE_PREC_BF16) {
+    if (plan->precision == DVAE_PREC_BF16X3) {
+        if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((apply_kernel<__bf16, false, 2>), grid, dim3(256), 0, s, a);
+    } else if (plan->precision == DVAE_PREC_BF16) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((apply_kernel<__bf16, false>), grid, dim3(256), 0, s, a);
     } else {
@@ -1343,7 +1388,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
     TensorDesc td[DVAE_TRAIN_MAX_TENSORS];
     memset(td, 0, sizeof(td));
-    if (plan->precision == DVAE_PREC_BF16) fill_tables<__bf16>(plan, L, w, tiles, td);
+    if (is_bf(plan->precision)) fill_tables<__bf16>(plan, L, w, tiles, td);
     else fill_tables<float>(plan, L, w, tiles, td);
     hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(GroupDesc), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
@@ -1364,7 +1409,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
 
 template <typename P, int YP, bool YENC, bool INFO = false>
 static int launch_rows(const RowsArgs& a, int grid, hipStream_t s) {
-    const size_t lds = P::XFULL ? Ld<typename P::T>::bytes_full : Ld<typename P::T>::bytes_slices;
+    const size_t lds = Pl<P>::bytes;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)vae_rows_kernel<P, YP, YENC, INFO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1384,8 +1429,8 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     make_layout(*plan, L);
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)ws;
-    const bool bf = plan->precision == DVAE_PREC_BF16;
-    const int esz = bf ? 2 : 4;
+    const bool bf = plan->precision == DVAE_PREC_BF16, x3 = plan->precision == DVAE_PREC_BF16X3;
+    const int esz = (bf || x3) ? 2 : 4;
     RowsArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = (const int64_t*)(uintptr_t)plan->row_index;
@@ -1410,7 +1455,8 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
     }
     a.partials = (double*)(w + L.o_partials);
-    a.wcopy = wc; a.wcopy_bytes = L.wcopy_elems * esz;
+    a.wcopy = wc; a.wcopy_bytes = L.wcopy_elems * esz * planes_of(plan->precision);
+    a.spl = L.stash_rows * plan->Bp; a.wpl_bytes = (unsigned)(L.wcopy_elems * esz);
     a.dbg = g_dbg;
     { const char* ab = getenv("DVAE_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     char* st = w + L.o_stash;
@@ -1426,7 +1472,12 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     int rc;
     {
         ProfScope ps(s, 0);
-        if (bf) {
+        if (x3) {
+            if (L.info) rc = launch_rows<PolX3, 16, false, true>(a, grid, s);
+            else if (!m2) rc = launch_rows<PolX3, 0, false>(a, grid, s);
+            else if (plan->y_dim == 1) rc = launch_rows<PolX3, 16, true>(a, grid, s);
+            else rc = launch_rows<PolX3, 528, true>(a, grid, s);
+        } else if (bf) {
             if (L.info) rc = launch_rows<PolBF16, 16, false, true>(a, grid, s);
             else if (!m2) rc = launch_rows<PolBF16, 0, false>(a, grid, s);
             else if (plan->y_dim == 1) rc = launch_rows<PolBF16, 16, true>(a, grid, s);
@@ -1449,8 +1500,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     float* slabs = (float*)(w + L.o_grads);
     {
         ProfScope ps(s, 1);
-        if (bf) hipLaunchKernelGGL((wgrad_kernel<PolBF16>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, kper, slabs, plan->n_params);
-        else hipLaunchKernelGGL((wgrad_kernel<PolF32>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, kper, slabs, plan->n_params);
+        if (x3) hipLaunchKernelGGL((wgrad_kernel<PolX3>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        else if (bf) hipLaunchKernelGGL((wgrad_kernel<PolBF16>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        else hipLaunchKernelGGL((wgrad_kernel<PolF32>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
     }
     DVAE_LAUNCH_OK("wgrad_kernel");
     if (reduce_slabs && ks > 1) {

@@ -30,7 +30,9 @@ class TrainPlan(ctypes.Structure):
 
 
 MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3}
-PREC_CODE = {"fp32": 0, "bf16": 1}
+# matrix-core operand policies (include/dvae_train.h): fp32 = exact fp32 MFMA; bf16 = one bf16 per operand (fast, loose);
+# bf16x3 = split bf16 (hi + lo planes, three MFMAs per product): the parity-grade throughput mode
+PREC_CODE = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 TENSOR_NAMES = ["encoder.hidden.0.weight", "encoder.hidden.0.bias", "encoder.hidden.1.weight", "encoder.hidden.1.bias",
                 "encoder.sample.mu.weight", "encoder.sample.mu.bias", "encoder.sample.log_var.weight", "encoder.sample.log_var.bias",
                 "decoder.hidden.0.weight", "decoder.hidden.0.bias", "decoder.hidden.1.weight", "decoder.hidden.1.bias",
@@ -190,7 +192,7 @@ class Trainer:
         return out
 
     def _used_slabs(self):
-        unit = 4 * (16 if self.precision == "bf16" else 8)
+        unit = 4 * (16 if self.precision in ("bf16", "bf16x3") else 8)
         per = -(-self.plan.Bp // self.plan.ksplit)
         kper = -(-per // unit) * unit
         return -(-self.plan.Bp // kper)
@@ -304,7 +306,7 @@ class BenchImpl:
             pg = dist.group.WORLD
         self.tr = Trainer(model, dims, None, batch=B, device=device, precision=precision, process_group=pg, world=world, seed=0,
                           ksplit=ksplit)
-        self.dtype = "bf16" if precision == "bf16" else "f32"
+        self.dtype = {"bf16": "bf16", "bf16x3": "bf16x3", "fp32": "f32"}[precision]
         self.name = f"fused(rows+wgrad+apply HIP kernels, {precision} MFMA operands, fp32 accumulate/master)"
         self.model, self.dims, self.B, self.precision = model, dims, B, precision
 
@@ -331,11 +333,11 @@ class BenchImpl:
         flops = {"rows": 2.0 * (mac + dxm) * B, "wgrad": 2.0 * mac * B, "apply": 0.0, "reduce": 0.0}
         # algorithmic bytes: what an ideally fused step must move: x, y, eps once for the
         # rows kernel; the wgrad operands (activations + their gradients) for the split design
-        esz = 2 if self.precision == "bf16" else 4
+        esz = {"bf16": 2, "bf16x3": 4, "fp32": 4}[self.precision]
         stash_rows = 513 + y + 6 * 128 + 32 + 16 + 128 * 2 + 513
         byts = {"rows": 4.0 * (513 + y + 16) * B, "wgrad": float(esz * stash_rows * B), "apply": 16.0 * plan.n_params, "reduce": 0.0}
         dur = avg[dom] * 1e-6
-        peak_f = 2500.0 if self.precision == "bf16" else 157.3
+        peak_f = 2500.0 if self.precision in ("bf16", "bf16x3") else 157.3
         t_m = flops[dom] / (peak_f * 1e12)
         t_h = byts[dom] / 8.0e12
         if t_m >= t_h:

@@ -27,7 +27,12 @@ extern "C" {
 #endif
 
 enum { DVAE_MODEL_M1 = 1, DVAE_MODEL_M2 = 2, DVAE_MODEL_M2_INFO = 3 };
-enum { DVAE_PREC_F32 = 0, DVAE_PREC_BF16 = 1 };
+/* Matrix-core operand policies (accumulation and master weights are always fp32):
+ *   F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                       -- parity mode, 1/16 of the bf16 MFMA rate
+ *   BF16   one bf16 per operand                                            -- fastest; weight gradients within ~4e-2 of their maximum
+ *   BF16X3 split bf16: operand = hi + lo planes, product = hi*hi + lo*hi + hi*lo  -- parity-grade throughput mode
+ *          (losses ~1e-7, gradients ~1e-4 of their maximum vs float64; tools/exp_precision.py), 3/16 of the F32 cost */
+enum { DVAE_PREC_F32 = 0, DVAE_PREC_BF16 = 1, DVAE_PREC_BF16X3 = 2 };
 #define DVAE_TRAIN_MAX_TENSORS 32
 
 typedef struct {

@@ -55,13 +55,14 @@ def _relmax(a, b):
 
 # 20 000 frames = 625 tiles: more tiles than workgroups (256 fp32 / 512 bf16), i.e. the persistent tile loop
 @pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M1", 0, 8192), ("M2", 1, 1000), ("M2", 513, 33), ("M1", 0, 1), ("M2", 1, 20000)])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_fused_step_vs_oracle(model, y_dim, B, precision):
     """fp32 operand mode: <= 1e-4 relative (north_star bar) on losses and gradients.
-    bf16 operand mode (throughput mode): bf16 rounding of operands, fp32 accumulation.  The
-    synthetic power spectra span 1e-12 .. 1e4, so bf16 rounding of x and W1 moves encoder
-    pre-activations by O(1) on the loudest frames; measured deviation bound stated here: losses
-    2e-3 relative, every gradient tensor cosine >= 0.99 with the fp64 oracle and within 0.3 of its max."""
+    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-4 relative (measured ~1e-6),
+    every gradient tensor within 1e-3 of its maximum (measured <= 2e-4; tools/exp_precision.py predicts 1e-4).
+    bf16 (one bf16 per operand, opt-in fast mode): the synthetic power spectra span 1e-12 .. 1e4, so bf16
+    rounding of x and W1 moves encoder pre-activations by O(1) on the loudest frames; measured deviation bound
+    stated here: losses 2e-3 relative, every gradient tensor cosine >= 0.99 with the fp64 oracle and within 0.3 of its max."""
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     params = gu.make_params(model, dims, 11)
     x, y, e = gu.make_batch(dims, B, 12)
@@ -71,9 +72,11 @@ def test_fused_step_vs_oracle(model, y_dim, B, precision):
     t = lambda a: None if a is None else torch.from_numpy(a).cuda()
     losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
     ref = np.array([out["loss"], out["recon"], out["kl"]])
-    ltol, gtol = (1e-4, 1e-4) if precision == "fp32" else (2e-3, 0.3)
+    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-3), "bf16": (2e-3, 0.3)}[precision]
     np.testing.assert_allclose(losses, ref, rtol=ltol)
     g = tr.grads_numpy()
+    worst = max(_relmax(g[k], np.asarray(grads[k], np.float64).reshape(g[k].shape)) for k in grads)
+    print(f"fused[{model},y{y_dim},B{B},{precision}]: loss rel err {np.max(np.abs(losses - ref) / np.abs(ref)):.2e}, worst grad relmax {worst:.2e}")
     for k in grads:
         gr = np.asarray(grads[k], np.float64).reshape(g[k].shape)
         assert _relmax(g[k], gr) < gtol, k
@@ -214,7 +217,7 @@ def test_fused_m2info_matches_reference_vectors(vae_golden, name):
     check_case(FusedInfoImpl("fp32"), vae_golden, case)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_fused_m2info_vs_oracle_full_batch(precision):
     dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
     B = 8192
@@ -228,12 +231,30 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
     t = lambda a: torch.from_numpy(a).cuda()
     losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
     ref = np.array([out["ELBO"], out["recon"], out["kl"], out["enc_loss"], out["classif_loss"], out["aux_loss"], out["aux_enc_loss"]])
-    np.testing.assert_allclose(losses[:7], ref, rtol=1e-4 if precision == "fp32" else 5e-3, atol=1e-5)
+    np.testing.assert_allclose(losses[:7], ref, rtol=5e-3 if precision == "bf16" else 1e-4, atol=1e-5)
     g = tr.grads_numpy()
-    tol = 1e-4 if precision == "fp32" else 0.3
+    tol = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16": 0.3}[precision]
+    # The classifier / auxiliary nets are ReLU MLPs: the reference's own gradient is discontinuous where a hidden
+    # pre-activation is within rounding of zero, and a mask that flips in ONE frame moves ONE row of that layer's weight
+    # gradient (and one bias element) by about one frame's contribution, ~1e-3 of the tensor's maximum at 8192 frames.
+    # tools/diag/info_rows.py: under bf16x3 every other row agrees to ~2e-6; the fp32 policy shows the same isolated rows
+    # at other seeds (and the float32 and float64 oracles differ by up to 0.75 on the saturated classifier).  So: every
+    # tensor within `tol` of its maximum except at most 2 rows per ReLU-net tensor, and those within 1e-2.
+    worst_clean = 0.0
     for k in params:
-        gr = np.asarray(g1[k], np.float64) + (np.asarray(g2[k], np.float64) if k in g2 else 0.0)   # aux: (gamma - beta) dBCE
-        assert _relmax(g[k], gr.reshape(g[k].shape)) < tol, k
+        gr = (np.asarray(g1[k], np.float64) + (np.asarray(g2[k], np.float64) if k in g2 else 0.0)).reshape(g[k].shape)   # aux: (gamma - beta) dBCE
+        err = np.abs(g[k].astype(np.float64) - gr) / (np.abs(gr).max() + 1e-30)
+        relu_net = k.startswith("auxiliary.") or ".classifier." in k
+        if relu_net and precision != "bf16":
+            rows = np.sort(err.reshape(err.shape[0], -1).max(axis=1))[::-1]
+            assert rows[0] < 1e-2, (k, rows[:3])
+            assert (rows >= tol).sum() <= 2, (k, rows[:4])
+            worst_clean = max(worst_clean, float(rows[rows < tol].max()) if (rows < tol).any() else 0.0)
+        else:
+            assert err.max() < tol, k
+            worst_clean = max(worst_clean, float(err.max()))
+    print(f"fused[M2_info,B{B},{precision}]: loss rel err {np.max(np.abs(losses[:7] - ref) / (np.abs(ref) + 1e-5)):.2e}, worst gradient error "
+          f"(outside <= 2 ReLU-tie rows per tensor) {worst_clean:.2e}")
 
 
 def test_evaluate_is_forward_only_and_matches_step_losses():
@@ -271,7 +292,7 @@ def test_in_kernel_noise_is_standard_normal_and_reproducible():
     assert not np.array_equal(n1, other)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_step_without_noise_tensor_equals_step_on_the_drawn_noise(precision):
     dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
     params = gu.make_params("M2", dims, 3)
@@ -306,7 +327,8 @@ def test_device_side_loss_accumulation():
     np.testing.assert_allclose(acc.cpu().numpy()[:3], want, rtol=1e-12)     # detached: no more additions
 
 
-@pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "fp32"), ("M2", 513, "bf16"), ("M1", 0, "bf16"), ("M2_info", 1, "fp32")])
+@pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "fp32"), ("M2", 513, "bf16"), ("M1", 0, "bf16"), ("M2_info", 1, "fp32"),
+                                                   ("M2", 513, "bf16x3"), ("M2_info", 1, "bf16x3")])
 def test_in_kernel_row_gather_equals_gathered_batch(model, y_dim, precision):
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     params = gu.make_params(model, dims, 5)
@@ -326,7 +348,8 @@ def test_in_kernel_row_gather_equals_gathered_batch(model, y_dim, precision):
         a.step(X, Y, E, rows=rows[:10])
 
 
-@pytest.mark.parametrize("model,y_dim,precision,tol", [("M2", 513, "fp32", 2e-4), ("M2", 1, "bf16", 2e-2), ("M2_info", 1, "fp32", 5e-4)])
+@pytest.mark.parametrize("model,y_dim,precision,tol", [("M2", 513, "fp32", 2e-4), ("M2", 1, "bf16", 2e-2), ("M2_info", 1, "fp32", 5e-4),
+                                                       ("M2", 513, "bf16x3", 2e-4), ("M2_info", 1, "bf16x3", 5e-4)])
 def test_long_trajectory_tracks_the_cpu_reference_loop(model, y_dim, precision, tol):
     """120 consecutive steps (lr 1e-3: the parameters move by ~0.1) against the torch-CPU restatement of the reference
     loop on the same batches and noise: Adam moments, bias correction and the weight-copy refresh over many steps."""
@@ -359,9 +382,10 @@ def test_long_trajectory_tracks_the_cpu_reference_loop(model, y_dim, precision, 
     assert rms_moved > 0.01, rms_moved
     assert rms_drift < (0.08 if precision == "bf16" else 0.02) * rms_moved, (rms_moved, rms_drift)
     assert (np.abs(dr) > 10 * lr).mean() < (0.02 if precision == "bf16" else 2e-3), float((np.abs(dr) > 10 * lr).mean())
+    print(f"trajectory[{model},{precision}]: rms drift / rms moved = {rms_drift / rms_moved:.4f}")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_persistent_tile_loop_equals_the_sum_of_its_halves(precision):
     """20 000 frames run more than one tile per workgroup; two 10 000-frame steps do not: same gradient."""
     dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
@@ -383,7 +407,8 @@ def test_persistent_tile_loop_equals_the_sum_of_its_halves(precision):
 
 
 @pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 1000, "bf16"), ("M2", 513, 33, "fp32"), ("M2_info", 1, 257, "bf16"),
-                                                       ("M1", 0, 8192, "bf16"), ("M2", 1, 20000, "fp32")])
+                                                       ("M1", 0, 8192, "bf16"), ("M2", 1, 20000, "fp32"), ("M2", 513, 1000, "bf16x3"),
+                                                       ("M2_info", 1, 257, "bf16x3"), ("M2", 1, 20000, "bf16x3")])
 def test_kernels_stay_inside_their_buffers(model, y_dim, B, precision):
     """Guard bands around the workspace, the parameter / moment buffers and the loss scalars survive train steps
     (stash tiles, gradient slabs, weight copies and partial sums are all addressed by hand in the kernels)."""
