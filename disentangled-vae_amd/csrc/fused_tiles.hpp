@@ -163,9 +163,10 @@ __device__ __forceinline__ void bloadp(typename P::Frag (&b)[P::NP], const typen
     if constexpr (P::NP == 2) b[1] = *reinterpret_cast<const typename P::Frag*>(p + Pl<P>::lds);
 }
 // acc += a * b over all plane pairs that matter: hi*hi, lo*hi, hi*lo
+// `blo` (wave-uniform): the B operand has a non-zero lo plane (false for label tiles that one bf16 plane holds exactly)
 template <typename P>
-__device__ __forceinline__ void mmap(f32x16& acc, const typename P::Frag (&a)[P::NP], const typename P::Frag (&b)[P::NP]) {
-    if constexpr (P::NP == 2) { P::mma(acc, a[1], b[0]); P::mma(acc, a[0], b[1]); }
+__device__ __forceinline__ void mmap(f32x16& acc, const typename P::Frag (&a)[P::NP], const typename P::Frag (&b)[P::NP], bool blo = true) {
+    if constexpr (P::NP == 2) { P::mma(acc, a[1], b[0]); if (blo) P::mma(acc, a[0], b[1]); }
     P::mma(acc, a[0], b[0]);
 }
 
@@ -189,7 +190,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // here, the store acks overlap the D k-steps the ring already covers.
 template <typename P, int NSTEPS, typename Hook = NoHook, int PREN = P::PRE>
 __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PREN>& w, __amdgpu_buffer_rsrc_t rs, WRef wr,
-                                           const typename P::T* brow, unsigned WSTR, Hook after_fill = Hook()) {
+                                           const typename P::T* brow, unsigned WSTR, Hook after_fill = Hook(), bool blo = true) {
     typedef typename P::Frag Frag;
     constexpr int STR = 2 * P::E;        // LDS activations: k-step = 2E consecutive features of a frame row
     constexpr int D = NSTEPS < P::PD ? NSTEPS : P::PD;
@@ -221,7 +222,7 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PR
         for (int c = 0; c < NIT - 1; ++c) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                mmap<P>(acc, a[i], bq[i % BD]);
+                mmap<P>(acc, a[i], bq[i % BD], blo);
                 // D is a multiple of BD whenever NIT > 1, so slot i % BD is static across laps
                 bloadp<P>(bq[i % BD], brow + (c * D + i + BD) * STR);
                 wloadp<P>(a[i], rs, wr, ((c + 1) * D + i) * WSTR);
@@ -233,7 +234,7 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PR
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             constexpr int base = (NIT - 1) * D;
-            mmap<P>(acc, a[i], bq[(base + i) % BD]);
+            mmap<P>(acc, a[i], bq[(base + i) % BD], blo);
             if (base + i + BD < NSTEPS) bloadp<P>(bq[(base + i) % BD], brow + (base + i + BD) * STR);
             if (i < REM) wloadp<P>(a[i], rs, wr, (NIT * D + i) * WSTR);
             __builtin_amdgcn_sched_barrier(0);
@@ -242,7 +243,7 @@ __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PR
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
         constexpr int base = NIT * D;
-        mmap<P>(acc, a[i], bq[(base + i) % BD]);
+        mmap<P>(acc, a[i], bq[(base + i) % BD], blo);
         if (base + i + BD < NSTEPS) bloadp<P>(bq[(base + i) % BD], brow + (base + i + BD) * STR);
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -1,0 +1,241 @@
+// Device helpers shared by the rows kernels of the fused train step (train_fused.hip: 4-wave kernel; train_rows2.hip:
+// 8-wave chain + helper kernel): reparametrisation noise, kernel arguments, tile loaders, LDS -> stash transposition.
+#pragma once
+#include "fused_tiles.hpp"
+
+namespace dvae {
+namespace fused {
+
+// Philox4x32-10 (Salmon et al., SC'11) -> four standard normals by Box-Muller.  Counter = (frame lo, frame hi, step lo,
+// step hi << 8 | draw), key = seed: every frame of every step has its own stream, independent of tiling and grid.
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long frame, unsigned long long step, unsigned draw,
+                                               float (&out)[4]) {
+    unsigned c0 = (unsigned)frame, c1 = (unsigned)(frame >> 32), c2 = (unsigned)step, c3 = ((unsigned)(step >> 32) << 8) | draw;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float ra = sqrtf(-2.f * __logf(u0)), rb = sqrtf(-2.f * __logf(u2));
+    float sa, ca, sb, cb;
+    __sincosf(6.283185307179586f * u1, &sa, &ca);
+    __sincosf(6.283185307179586f * u3, &sb, &cb);
+    out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
+}
+// noise of latent features 4h .. 4h+3 (draw 2h) and 8+4h .. 8+4h+3 (draw 2h+1) of one frame: the C-tile ownership of wave 0
+__device__ __forceinline__ void frame_noise8(unsigned long long seed, unsigned long long frame, unsigned long long step, int h, float (&e)[8]) {
+    float a[4], b[4];
+    philox_normal4(seed, frame, step, 2u * h, a);
+    philox_normal4(seed, frame, step, 2u * h + 1u, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { e[j] = a[j]; e[4 + j] = b[j]; }
+}
+
+struct RowsArgs {
+    const float* x; const float* y; const float* eps;
+    int ldx, ldy, ydim;
+    int fastx, fasty;      // rows are dense (ld == 513) and 16-byte aligned: whole-tile vector loads
+    int64_t B, Bp;
+    unsigned long long rng_seed, rng_step;   // in-kernel reparametrisation noise (eps == nullptr)
+    const int64_t* rows;                      // optional gather: frame b of the step is row rows[b] of x / y (epoch shuffle without a copy)
+    int64_t n_rows;                           // rows of the frame store behind x / y when `rows` is set: indices outside [0, n_rows) are
+    int* bad_rows;                            // clamped to row 0 and counted here (never dereferenced out of range)
+    int ntiles;
+    float invB, elbo_eps;
+    const void *W1s, *W2s, *Wmvs, *W3s, *W4s, *W5s, *W5t, *W4t, *W3zt, *Wmvt, *W2t;
+    const float *b1, *b2, *bmu, *blv, *b3, *b4, *b5;
+    const float* w5last;   // fp32 row 512 of the output layer (the one real feature of the 17th 32-row tile)
+    void *xT, *yT, *h1T, *h2T, *dh1T, *dh2T, *dmlvT, *zT, *d1T, *d2T, *dd1T, *dd2T, *daT;
+    const void* wcopy; int64_t wcopy_bytes;   // whole weight-copy buffer (one buffer descriptor)
+    int64_t spl;                              // stash: elements between the hi and lo operand planes (PolX3)
+    unsigned wpl_bytes;                       // weight copies: bytes between the planes
+    // M2_info (DeepGenerativeModel_v5): classifier on x, auxiliary classifier on z (both 128-128-1, relu/relu/sigmoid)
+    const void *Wc1s, *Wc2s, *Wc2t, *Wa1s, *Wa1t, *Wa2s, *Wa2t;
+    const float *bc1, *bc2, *wc3, *bc3, *ba1, *ba2, *wa3, *ba3;
+    void *c1T, *c2T, *dc1T, *dc2T, *dc3T, *a1T, *a2T, *da1T, *da2T, *da3T;
+    float alpha, beta, gamma;
+    double* partials;
+    unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
+    int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
+};
+
+#ifdef DVAE_FINE_STAMPS
+#define DVAE_FSTAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define DVAE_FSTAMP(i) do { } while (0)
+#endif
+#define DVAE_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+
+
+// LDS tile [32 frames][features fbase .. fbase+31] -> fragment-major stash tile (E consecutive frames of
+// one feature = one 16-byte fragment).  Called by the wave that wrote those LDS columns, with EXEC all ones.
+// bf16: the transposition is done by the LDS itself: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of
+// a 4-row x 16-column block (gfx950), so a fragment costs 2 reads instead of 8 two-byte ones.  The lane with index
+// 4q + p in its group supplies the address of row q, columns 4p .. 4p+3 of the block.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <typename P>
+__device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr, int64_t spl,
+                                           int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30) {
+    typedef typename P::T T;
+    typedef typename P::Frag Frag;
+    constexpr int E = P::E;
+    if (stash_tile_ptr == nullptr) return;
+    T* dst = stash_tile_ptr + (b0 / P::KSTEP) * (64 * E) + l31 * E;
+    if constexpr (sizeof(T) == 2) {
+        const int i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
+        const T* blk = lds + q * ldl + fbase + 16 * cg + 4 * pp;
+        const bool keep = fbase + l31 < col_limit;
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int i = 0; i < TB / (2 * E); ++i) {
+            const int gq = h + 2 * i;                      // frame group: frames gq*8 .. gq*8+7
+            Frag f[P::NP];
+#pragma unroll
+            for (int pl = 0; pl < P::NP; ++pl) {
+                const T* bp = blk + pl * Pl<P>::lds;
+                const s16x4 r0 = lds_tr16(bp + (8 * gq) * ldl), r1 = lds_tr16(bp + (8 * gq + 4) * ldl);
+                s16x8 raw = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                f[pl] = __builtin_bit_cast(Frag, raw);
+            }
+            if (scale != 1.f) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    if constexpr (P::NP == 2) {
+                        const float v = ((float)f[0][j] + (float)f[1][j]) * scale;
+                        f[0][j] = P::cvt(v); f[1][j] = P::cvt(v - (float)f[0][j]);
+                    } else f[0][j] = P::cvt((float)f[0][j] * scale);
+                }
+            }
+            if (!keep) {
+#pragma unroll
+                for (int pl = 0; pl < P::NP; ++pl)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) f[pl][j] = P::cvt(0.f);
+            }
+#pragma unroll
+            for (int pl = 0; pl < P::NP; ++pl) *reinterpret_cast<Frag*>(dst + pl * spl + gq * 32 * E) = f[pl];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TB / (2 * E); ++i) {
+            const int gq = h + 2 * i;                      // frame group: frames gq*E .. gq*E+E-1
+            Frag f;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const T v = lds[(gq * E + j) * ldl + fbase + l31];
+                f[j] = scale == 1.f ? v : P::cvt((float)v * scale);
+                if (fbase + l31 >= col_limit) f[j] = P::cvt(0.f);
+            }
+            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
+        }
+    }
+}
+
+// generic (edge tile / strided / unaligned input): global [32 frames][ncols] fp32 -> LDS as T, zero padded
+template <typename P, typename RowOf>
+__device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, int ld, int ncols, int pcols, int64_t b0, int64_t B,
+                                                 typename P::T* U, int ldu, int tid, RowOf rowof, float* xf = nullptr) {
+    const int total = TB * pcols;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int row = idx / pcols, col = idx - row * pcols;
+        float v = 0.f;
+        if (col < ncols && b0 + row < B) v = src[rowof(row) * ld + col];
+        const typename P::T vh = P::cvt(v);
+        U[row * ldu + col] = vh;
+        if constexpr (P::NP == 2) U[Pl<P>::lds + row * ldu + col] = P::cvt(v - (float)vh);
+        if (xf && col < ncols) xf[row * ncols + col] = v;
+    }
+}
+
+// dense 513-column tile (32 rows back to back in memory).  Thread t takes the 4-column chunks c = t + 256 i
+// (i < 16): row c >> 7, columns 4 (c & 127) .. +3 -- shifts only, and the LDS image row U[row][col .. col+3] is
+// one aligned 8-byte store.  The global address (row * 513 + col floats) is only 4-byte aligned: gfx950 takes
+// dwordx4 loads at dword alignment.  Column 512 of row (t & 31) rides in slot 16.
+constexpr int NQ513 = 17;
+struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
+template <typename RowOf>
+__device__ __forceinline__ void tile513_issue(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = reinterpret_cast<const F4U*>(base + rowof(c >> 7) * XD + 4 * (c & 127))->v;
+    }
+    v[16][0] = base[rowof(tid & 31) * XD + XD - 1];
+    __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
+}
+template <typename P, int PCOLS>
+__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr) {
+    typedef typename P::Pack4 Pack4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 7, col = 4 * (c & 127);
+        if (xf) {                                              // dense [frame][513] fp32 copy (rows 4-byte aligned)
+            float* d = xf + row * XD + col;
+            d[0] = v[i][0]; d[1] = v[i][1]; d[2] = v[i][2]; d[3] = v[i][3];
+        }
+        Pack4 pk;
+        pk[0] = P::cvt(v[i][0]); pk[1] = P::cvt(v[i][1]); pk[2] = P::cvt(v[i][2]); pk[3] = P::cvt(v[i][3]);
+        *reinterpret_cast<Pack4*>(U + row * ldu + col) = pk;
+        if constexpr (P::NP == 2) {
+            Pack4 pl;
+            pl[0] = P::cvt(v[i][0] - (float)pk[0]); pl[1] = P::cvt(v[i][1] - (float)pk[1]);
+            pl[2] = P::cvt(v[i][2] - (float)pk[2]); pl[3] = P::cvt(v[i][3] - (float)pk[3]);
+            *reinterpret_cast<Pack4*>(U + Pl<P>::lds + row * ldu + col) = pl;
+        }
+    }
+    constexpr int PADC = PCOLS - XD;                            // column 512, then PADC zero columns
+    if (tid < TB) {
+        if (xf) xf[tid * XD + XD - 1] = v[16][0];
+        const typename P::T vh = P::cvt(v[16][0]);
+        U[tid * ldu + XD - 1] = vh;
+        if constexpr (P::NP == 2) U[Pl<P>::lds + tid * ldu + XD - 1] = P::cvt(v[16][0] - (float)vh);
+    }
+    for (int idx = tid; idx < TB * PADC; idx += 256) {
+        const int r = idx / PADC, c = XD + idx - r * PADC;
+        U[r * ldu + c] = P::cvt(0.f);
+        if constexpr (P::NP == 2) U[Pl<P>::lds + r * ldu + c] = P::cvt(0.f);
+    }
+}
+
+// LDS U[frame][col] -> fragment-major stash (see put_tile), 16 bytes (E frames of one feature) per
+// store; feature rows up to `srows` (multiple of 32) are written, columns >= pcols as zeros
+template <typename P>
+__device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, int pcols, int srows, typename P::T* stash, int64_t spl,
+                                               int64_t Bp, int64_t b0, int tid) {
+    typedef typename P::Frag Frag;
+    constexpr int E = P::E;
+    if constexpr (sizeof(typename P::T) == 2) {
+        // one wave per 32-feature tile (wave-uniform loop: EXEC stays all ones for the transposing reads)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        for (int ft = wave; ft < srows / 32; ft += 4)
+            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, spl, b0, lane & 31, lane >> 5, 1.f, pcols);
+        return;
+    }
+    constexpr int groups = TB / E;
+    const int total = srows * groups;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int gi = idx / srows, f = idx - gi * srows;     // consecutive threads -> consecutive features
+        Frag p;
+#pragma unroll
+        for (int j = 0; j < E; ++j) p[j] = (f < pcols) ? U[(gi * E + j) * ldu + f] : P::cvt(0.f);
+        *reinterpret_cast<Frag*>(stash + (int64_t)(f >> 5) * 32 * Bp + (b0 / P::KSTEP) * (64 * E) + (gi * 32 + (f & 31)) * E) = p;
+    }
+}
+
+
+// train_rows2.hip: the 8-wave chain + helper rows kernel (M1 / M2, bf16 and bf16x3 operand policies)
+int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s);
+bool rows2_supported(int precision, int model);
+
+}  // namespace fused
+}  // namespace dvae

@@ -1,0 +1,559 @@
+// rows kernel, second generation: one 512-thread workgroup (8 waves, two per SIMD) per 32-frame tile.
+//
+//   chain waves 0-3  : the serial layer chain of the train step -- per layer one MFMA GEMM on 32x32 tiles
+//                      (out^T[features x frames] = W * in^T, weights streamed from L2 into a register ring, activations
+//                      from LDS), the bias / tanh / loss epilogue in registers, the next layer's operand into LDS.
+//                      Nothing else: a chain wave never touches the inputs' HBM stream or the stash.
+//   helper waves 4-7 : everything beside the chain, on the SAME SIMDs (VALU / LDS / memory instructions issue beside
+//                      the partner wave's MFMAs): the x / y tiles HBM -> registers -> (hi, lo) bf16 planes in LDS, the
+//                      LDS -> stash transposition (ds_read_b64_tr_b16) and every stash store, the bias table, the
+//                      gather table, and -- in the persistent tile loop -- the NEXT tile's x load, issued during the
+//                      backward phases and committed once the output-gradient tile has been consumed.
+// Both roles run the same sequence of workgroup barriers (the phase list below); a helper always transposes the
+// buffer the chain is reading in that phase (both only read it), while the chain's epilogue fills the other one.
+// Compared with the 4-wave kernel of train_fused.hip (one wave per SIMD, 512 registers, 136 of them staging
+// registers, stash stores and tile loads on the chain's critical path): <= 256 registers per wave, a second
+// instruction stream per SIMD, the loss epilogue reads x straight from global memory into registers (no LDS slices,
+// no barriers inside the output layer), and the label part of decoder layer 1 is computed while the label tile is
+// in LDS for the encoder (it does not depend on z).
+//
+// phase list (barrier after each; [C] chain, [H] helpers).  U = [frame][544] tile buffer, Ha/Hb = [frame][128], Zb = [frame][32]
+//   (first tile only)  [H] gather table            | BROW (only with a gather table)
+//   (first tile only)  [H] x -> U, bias table      | BX
+//   [C] L1 x GEMM (U)              [H] y loads in flight, stash x          | BL1X      (y: only models with labels)
+//   [C] weight prefetch            [H] y -> U                              | BY
+//   [C] L1 y GEMM, dec-L1 y GEMM (U), h1 -> Ha     [H] stash y             | BH1
+//   [C] L2 (Ha), h2 -> Hb          [H] stash h1 (Ha)                       | BH2
+//   [C] heads (Hb), z -> Zb        [H] stash h2 (Hb)                       | BZ
+//   [C] dec L1 z (Zb), d1 -> Ha    [H] stash z (Zb)                        | BD1
+//   [C] dec L2 (Ha), d2 -> Hb      [H] stash d1 (Ha)                       | BD2
+//   [C] output layer (Hb), loss, da -> U          [H] stash d2 (Hb)        | BDA
+//   [C] bwd out (U), dpre_d2 -> Ha [H] stash da (U), next gather table     | BDD2
+//   [C] bwd d2 (Ha), dpre_d1 -> Hb [H] stash dpre_d2 (Ha), next x loads issued | BDD1
+//   [C] bwd z (Hb), dmu|dlv -> Zb  [H] stash dpre_d1 (Hb)                  | BDML
+//   [C] bwd heads (Zb), dpre_h2 -> Ha  [H] stash dmu|dlv (Zb)              | BDH2
+//   [C] bwd h2 (Ha), dpre_h1 -> Hb [H] stash dpre_h2 (Ha)                  | BDH1
+//   [C] loss sums -> red           [H] stash dpre_h1 (Hb), next x -> U     | BRED   (= BX of the next tile)
+#include <math.h>
+#include <stdlib.h>
+#include "fused_tiles.hpp"
+#include "rows_common.hpp"
+#include "../../include/dvae_train.h"
+
+namespace dvae {
+namespace fused {
+
+template <typename P> struct Lds2 {
+    typedef typename P::T T;
+    static constexpr int nbias = Ld<T>::nbias;
+    static constexpr size_t o_bias = (size_t)Ld<T>::act_elems * P::NP * sizeof(T);
+    static constexpr size_t o_red = o_bias + (size_t)nbias * sizeof(float);
+    static constexpr size_t o_flags = o_red + 16 * sizeof(float);
+    static constexpr size_t o_rows = o_flags + 16 * sizeof(int);
+    static constexpr size_t bytes = o_rows + 2 * TB * sizeof(int64_t);
+    static_assert(o_bias % 16 == 0 && o_rows % 8 == 0, "LDS carve alignment");
+};
+
+#define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+
+template <typename P, int YP, bool YENC>
+__global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
+    typedef typename P::T T;
+    typedef typename P::Frag Frag;
+    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
+    constexpr int LDU = Ld<T>::u, LDH = Ld<T>::hh, LDZ = Ld<T>::z;
+    constexpr int LD1 = XP + (YENC ? YP : 0), LD3 = ZD + YP;
+    constexpr bool Y513 = (YP == XP);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const U = reinterpret_cast<T*>(smem);
+    T* const Ha = U + TB * LDU;
+    T* const Hb = Ha + TB * LDH;
+    T* const Zb = Hb + TB * LDH;
+    float* const Bias = reinterpret_cast<float*>(smem + Lds2<P>::o_bias);
+    float* const red = reinterpret_cast<float*>(smem + Lds2<P>::o_red);
+    int* const flags = reinterpret_cast<int*>(smem + Lds2<P>::o_flags);          // [0]: the label tile has a non-zero lo plane
+    int64_t* const rowsrc = reinterpret_cast<int64_t*>(smem + Lds2<P>::o_rows);  // [2][TB] gather table, double buffered
+    constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool gather = g.rows != nullptr;
+    const int ntl = (g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1: grid <= ntiles)
+
+    if (wave_u < 4) {
+        // =========================================================== chain waves ===========================================================
+        const int cw = wave_u, fb = 32 * cw;
+        constexpr int FB = 64 * E;
+        constexpr unsigned SZ = sizeof(T);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
+        auto wbase = [&](const void* Wp, int tile) -> WRef {
+            const unsigned m = (unsigned)((const char*)Wp - (const char*)g.wcopy);
+            return WRef{lane * 16, m + (unsigned)tile * (FB * SZ), g.wpl_bytes};
+        };
+        auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
+        constexpr unsigned S4 = 4 * FB * SZ, S1 = FB * SZ, S17 = NT_OUT * FB * SZ, TSTEP = FB * SZ;
+        constexpr unsigned KB1 = (XP / KS) * 4 * FB * SZ, KB3 = (ZD / KS) * 4 * FB * SZ;
+        (void)LD1; (void)LD3;
+        const WRef W1r = wbase(g.W1s, cw), W2r = wbase(g.W2s, cw), Wmvr = wbase(g.Wmvs, 0), W3r = wbase(g.W3s, cw), W4r = wbase(g.W4s, cw);
+        const WRef W5s = wbase(g.W5s, 0), W5tr = wbase(g.W5t, cw), W4tr = wbase(g.W4t, cw), W3ztr = wbase(g.W3zt, 0);
+        const WRef Wmvtr = wbase(g.Wmvt, cw), W2tr = wbase(g.W2t, cw);
+        const T* const Ur = U + l31 * LDU + h * E;
+        const T* const Har = Ha + l31 * LDH + h * E;
+        const T* const Hbr = Hb + l31 * LDH + h * E;
+        const T* const Zbr = Zb + l31 * LDZ + h * E;
+        double tot_rec = 0.0, tot_kl = 0.0;
+
+        for (int it = 0; it < ntl; ++it) {
+            const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+            const int64_t b0 = (int64_t)tile * TB;
+            const bool live = (b0 + l31) < g.B;
+            const int64_t* const rsrc = rowsrc + (it & 1) * TB;
+            float rec_lane = 0.f, kl_lane = 0.f;
+            R2_STAMP(0);
+            if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 30] = clock64();
+            // reparametrisation noise of this lane's frame (wave 0 owns the latent tile)
+            float ep_r[8];
+            if (cw == 0) {
+                int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1;
+                if (g.eps != nullptr) {
+                    const f32x4 e0 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 4 * h);
+                    const f32x4 e1 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 8 + 4 * h);
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) { ep_r[jq] = live ? e0[jq] : 0.f; ep_r[4 + jq] = live ? e1[jq] : 0.f; }
+                } else {
+                    frame_noise8(g.rng_seed, (unsigned long long)br, g.rng_step, h, ep_r);
+#pragma unroll
+                    for (int jq = 0; jq < 8; ++jq) ep_r[jq] = live ? ep_r[jq] : 0.f;
+                }
+            }
+            WPre<P, XP / KS> w1x;
+            wprefetch<P, XP / KS>(w1x, wrs, W1r, S4);
+            if (it == 0) {
+                if (gather) __syncthreads();                               // BROW
+                __syncthreads();                                           // BX
+            }
+            R2_STAMP(1);
+            // ---------------- encoder layer 1: [x | y] -> h1 ----------------
+            f32x16 acc, accy;
+            zero_acc<P>(acc);
+            gemm_block<P, XP / KS>(acc, w1x, wrs, W1r, Ur, S4);
+            R2_STAMP(2);
+            WPre<P, HD / KS, P::PRE128> w2;
+            if (YP > 0) {
+                WPre<P, (YENC ? YP : KS) / KS> w1y;
+                if (YENC) wprefetch<P, (YENC ? YP : KS) / KS>(w1y, wrs, woff(W1r, KB1), S4);
+                __syncthreads();                                           // BL1X: the x image of U has been consumed
+                WPre<P, (YP > 0 ? YP : KS) / KS, P::PRE> w3y;
+                wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
+                __syncthreads();                                           // BY: the y image is in U
+                const bool ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
+                if (YENC) gemm_block<P, (YENC ? YP : KS) / KS>(acc, w1y, wrs, woff(W1r, KB1), Ur, S4, NoHook(), ylo);
+                // label block of decoder layer 1: independent of z, computed while the label tile is in LDS
+                zero_acc<P>(accy);
+                gemm_block<P, (YP > 0 ? YP : KS) / KS>(accy, w3y, wrs, woff(W3r, KB3), Ur, S4, NoHook(), ylo);
+            }
+            wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
+            float h1r[16], bv[16];
+            R2_STAMP(3);
+            bias16(Bias + OB1, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1r[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(h1r, Ha, LDH, fb, l31, h);
+            __syncthreads();                                               // BH1
+            R2_STAMP(4);
+            // ---------------- encoder layer 2 ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4);
+            WPre<P, HD / KS, P::PRE128> wmv;
+            WPre<P, ZD / KS> w3z;
+            if (cw == 0) wprefetch<P, HD / KS>(wmv, wrs, Wmvr, S1);
+            wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
+            float h2r[16];
+            bias16(Bias + OB2, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(h2r, Hb, LDH, fb, l31, h);
+            __syncthreads();                                               // BH2
+            R2_STAMP(5);
+            // ---------------- heads + reparametrisation (wave 0): rows 0-15 mu, 16-31 log_var ----------------
+            float mu_r[8], lv_r[8], sd_r[8];
+            if (cw == 0) {
+                zero_acc<P>(acc);
+                gemm_block<P, HD / KS>(acc, wmv, wrs, Wmvr, Hbr, S1);
+                float zv[16];
+                bias16(Bias + OBMV, 0, h, bv);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    mu_r[r] = acc[r] + bv[r];
+                    lv_r[r] = acc[r + 8] + bv[r + 8];
+                    sd_r[r] = P::exp_(0.5f * lv_r[r]);                 // models.py:17
+                    zv[r] = fmaf(sd_r[r], ep_r[r], mu_r[r]);           // models.py:20
+                    zv[r + 8] = 0.f;
+                    if (live) kl_lane += lv_r[r] - mu_r[r] * mu_r[r] - P::exp_(lv_r[r]);   // utils.py:75
+                }
+                put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+            }
+            __syncthreads();                                               // BZ
+            R2_STAMP(6);
+            // ---------------- decoder layer 1: [z | y] -> d1 ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4);
+            WPre<P, HD / KS, P::PRE128> w4;
+            wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
+            float d1r[16];
+            bias16(Bias + OB3, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + (YP > 0 ? accy[r] : 0.f) + bv[r]);
+            put_lds<P>(d1r, Ha, LDH, fb, l31, h);
+            __syncthreads();                                               // BD1
+            R2_STAMP(7);
+            // ---------------- decoder layer 2 ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4);
+            WPre<P, HD / KS, P::PRE128> w5;
+            wprefetch<P, HD / KS>(w5, wrs, woff(W5s, cw * TSTEP), S17);
+            // loss epilogue input: x[frame][32 t + 8 gq + 4 h .. + 3] of this lane's frame straight from global memory
+            // (the tile was read a few microseconds ago: L2 / MALL), one output tile ahead
+            int64_t rowx;
+            if (gather) rowx = rsrc[l31];
+            else { rowx = b0 + l31; rowx = rowx < g.B ? rowx : g.B - 1; }
+            const float* const xrow = g.x + rowx * g.ldx + 4 * h;
+            f32x4 xq[4], xn[4];
+            auto xload = [&](int t, f32x4 (&q)[4]) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
+            };
+            xload(cw, xq);
+            float d2r[16];
+            bias16(Bias + OB4, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(d2r, Hb, LDH, fb, l31, h);
+            __syncthreads();                                               // BD2
+            R2_STAMP(8);
+            // ---------------- output layer a = W5 d2 + b5, Itakura-Saito terms, da -> U ----------------
+            WPre<P, NO / KS> w5t;
+            const float invB_l = live ? g.invB : 0.f;                      // frames past B contribute nothing
+            // 16 full tiles = 4 per wave; the 17th tile holds ONE real feature (bin 512): wave 3 does it as a 128-term dot product
+#pragma unroll 1
+            for (int t = cw; t < NT_OUT - 1; t += 4) {
+                zero_acc<P>(acc);
+                const WRef wr = woff(W5s, (unsigned)t * TSTEP);
+                if (t + 4 < NT_OUT - 1) xload(t + 4, xn);
+                gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17);
+                if (t + 4 < NT_OUT - 1) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
+                else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
+                float da[16], b5v[16];
+                bias16(Bias + OB5, 32 * t, h, b5v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float xs = xq[r >> 2][r & 3];
+                    const float a = acc[r] + b5v[r];
+                    const float xe = xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
+                    rec_lane += xe - P::log_(xs + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
+                    da[r] = (1.f - xe) * invB_l;                         // d recon / d a
+                }
+                put_lds<P>(da, U, LDU, 32 * t, l31, h);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) xq[gq] = xn[gq];
+            }
+            if (cw == 3) {
+                const float* wl = Bias + OB5 + NO + 64 * h;                 // this half's 64 weights (LDS broadcast reads)
+                const T* drow = Hb + l31 * LDH + 64 * h;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 64 / E; ++c) {
+                    Frag dv[NP];
+                    bloadp<P>(dv, drow + c * E);
+#pragma unroll
+                    for (int j = 0; j < E; j += 4) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + c * E + j);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            float dd = (float)dv[0][j + jj];
+                            if constexpr (NP == 2) dd += (float)dv[1][j + jj];
+                            s = fmaf(dd, wv[jj], s);
+                        }
+                    }
+                }
+                s += __shfl_xor(s, 32, 64);
+                const float a = s + Bias[OB5 + XD - 1];
+                const float xv512 = g.x[rowx * g.ldx + XD - 1];
+                const float xe = xv512 * P::exp_(-a);
+                if (h == 0) rec_lane += xe - P::log_(xv512 + g.elbo_eps) + a - 1.f;
+                const float da512 = (1.f - xe) * invB_l;
+                // columns 512 .. 543 of this frame's da row: the value, then 31 zeros (16 per lane half)
+                float dz16[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz16[r] = 0.f;
+                if (h == 0) dz16[0] = da512;
+                T* const urow = U + l31 * LDU + (XD - 1) + 16 * h;
+#pragma unroll
+                for (int c = 0; c < 16 / E; ++c) {
+                    Frag fh, fl;
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        fh[j] = P::cvt(dz16[c * E + j]);
+                        fl[j] = P::cvt(dz16[c * E + j] - (float)fh[j]);
+                    }
+                    *reinterpret_cast<Frag*>(urow + c * E) = fh;
+                    if constexpr (NP == 2) *reinterpret_cast<Frag*>(urow + Pl<P>::lds + c * E) = fl;
+                }
+            }
+            __syncthreads();                                               // BDA
+            R2_STAMP(9);
+            // ---------------- backward: d2 <- da ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, NO / KS>(acc, w5t, wrs, W5tr, Ur, S4);
+            WPre<P, HD / KS, P::PRE128> w4t;
+            wprefetch<P, HD / KS>(w4t, wrs, W4tr, S4);
+            float dv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d2r[r] * d2r[r]);
+            put_lds<P>(dv, Ha, LDH, fb, l31, h);
+            __syncthreads();                                               // BDD2
+            R2_STAMP(10);
+            // ---------------- backward: d1 <- dpre_d2 ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, HD / KS>(acc, w4t, wrs, W4tr, Har, S4);
+            WPre<P, HD / KS, P::PRE128> w3zt;
+            WPre<P, 32 / KS> wmvt;
+            if (cw == 0) wprefetch<P, HD / KS>(w3zt, wrs, W3ztr, S1);
+            wprefetch<P, 32 / KS>(wmvt, wrs, Wmvtr, S4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d1r[r] * d1r[r]);
+            put_lds<P>(dv, Hb, LDH, fb, l31, h);
+            __syncthreads();                                               // BDD1
+            R2_STAMP(11);
+            // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
+            if (cw == 0) {
+                zero_acc<P>(acc);
+                gemm_block<P, HD / KS>(acc, w3zt, wrs, W3ztr, Hbr, S1);
+                float dml[16];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float dz = acc[r];
+                    dml[r] = live ? dz + mu_r[r] * g.invB : 0.f;                                                    // dmu
+                    dml[r + 8] = live ? dz * ep_r[r] * (0.5f * sd_r[r]) - 0.5f * g.invB * (1.f - P::exp_(lv_r[r])) : 0.f;   // dlogvar
+                }
+                put_lds<P>(dml, Zb, LDZ, 0, l31, h);
+            }
+            __syncthreads();                                               // BDML
+            R2_STAMP(12);
+            // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, 32 / KS>(acc, wmvt, wrs, Wmvtr, Zbr, S4);
+            WPre<P, HD / KS, P::PRE128> w2t;
+            wprefetch<P, HD / KS>(w2t, wrs, W2tr, S4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);
+            put_lds<P>(dv, Ha, LDH, fb, l31, h);
+            __syncthreads();                                               // BDH2
+            R2_STAMP(13);
+            // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
+            zero_acc<P>(acc);
+            gemm_block<P, HD / KS>(acc, w2t, wrs, W2tr, Har, S4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
+            put_lds<P>(dv, Hb, LDH, fb, l31, h);
+            __syncthreads();                                               // BDH1
+            R2_STAMP(14);
+            // ---------------- per-tile loss sums ----------------
+            if (!live) rec_lane = 0.f;
+            const float rs = wave_sum(rec_lane), ks = wave_sum(kl_lane);
+            if (lane == 0) { red[cw] = rs; red[4 + cw] = ks; }
+            __syncthreads();                                               // BRED (the next tile's x image is in U)
+            if (tid == 0) {
+                tot_rec += (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+                tot_kl += -0.5 * (double)red[4];
+            }
+        }
+        R2_STAMP(15);
+        if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 31] = clock64();
+        if (tid == 0) {
+            g.partials[4 * blockIdx.x] = tot_rec;
+            g.partials[4 * blockIdx.x + 1] = tot_kl;
+            g.partials[4 * blockIdx.x + 2] = 0.0;
+            g.partials[4 * blockIdx.x + 3] = 0.0;
+        }
+    } else {
+        // =========================================================== helper waves ===========================================================
+        const int hw = wave_u - 4, ht = tid - 256;
+        // fp32 bias table -> LDS once; the loads are issued here (clamped addresses instead of branches)
+        constexpr int NBT = Ld<T>::nbias;
+        constexpr int NB = (NBT + 255) / 256;
+        float bvv[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            int i = ht + 256 * q;
+            i = i < NBT ? i : NBT - 1;
+            const float* src;
+            int k;
+            if (i < OB2) { src = g.b1; k = i; }
+            else if (i < OBMV) { src = g.b2; k = i - OB2; }
+            else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
+            else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
+            else if (i < OB4) { src = g.b3; k = i - OB3; }
+            else if (i < OB5) { src = g.b4; k = i - OB4; }
+            else if (i < OB5 + NO) { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
+            else { src = g.w5last; k = i - OB5 - NO; }
+            bvv[q] = src[k];
+        }
+        // gather table of tile `tl_` into half `half` (threads 0..31 of the helper group); bad indices are clamped and counted
+        auto fill_rows = [&](int tl_, int half) {
+            if (ht < TB) {
+                int64_t br = (int64_t)tl_ * TB + ht; br = br < g.B ? br : g.B - 1;
+                int64_t r = g.rows[br];
+                if (r < 0 || r >= g.n_rows) { r = 0; if (g.bad_rows) atomicAdd(g.bad_rows, 1); }
+                rowsrc[half * TB + ht] = r;
+            }
+        };
+        f32x4 xv[NQ513];
+        bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
+        for (int it = 0; it < ntl; ++it) {
+            const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+            const int64_t b0 = (int64_t)tile * TB;
+            const bool full = (b0 + TB) <= g.B;
+            const int64_t* const rsrc = rowsrc + (it & 1) * TB;
+            auto rowof = [&](int r) -> int64_t {
+                if (gather) return rsrc[r];
+                const int64_t br = b0 + r;
+                return br < g.B ? br : g.B - 1;
+            };
+            // per-iteration opaque copy of the thread id: keeps the per-thread staging addresses out of loop-invariant hoisting
+            int tl = ht;
+            asm volatile("" : "+v"(tl));
+            if (it == 0) {
+                if (gather) { fill_rows(tile, 0); __syncthreads(); }       // BROW
+                if (g.fastx && full) {
+                    tile513_issue(g.x, rowof, xv, tl);
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        const int i = ht + 256 * q;
+                        if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
+                    }
+                    tile513_commit<P, XP>(xv, U, LDU, tl);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        const int i = ht + 256 * q;
+                        if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
+                    }
+                    load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof);
+                }
+                if (ht == 0) flags[0] = 0;
+                __syncthreads();                                           // BX
+            }
+            // ---- chain: L1 x GEMM.  y loads in flight, x -> stash
+            const bool yfast = Y513 && g.fasty && full;
+            f32x4 yv[NQ513];
+            if (YP > 0) {
+                if (Y513 && yfast) tile513_issue(g.y, rowof, yv, tl);
+                stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                __syncthreads();                                           // BL1X
+                if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl);
+                else load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl, rowof);
+                if constexpr (NP == 2) {                                   // does the label tile need its lo plane?
+                    bool any = false;
+                    if (Y513 && yfast) {
+#pragma unroll
+                        for (int i = 0; i < NQ513; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) any |= (yv[i][j] - (float)P::cvt(yv[i][j])) != 0.f;
+                    } else {
+                        for (int idx = tl; idx < TB * YP; idx += 256) any |= (float)U[Pl<P>::lds + (idx / YP) * LDU + idx % YP] != 0.f;
+                    }
+                    if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
+                }
+                __syncthreads();                                           // BY
+                stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+            } else {
+                stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+            }
+            __syncthreads();                                               // BH1
+            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            __syncthreads();                                               // BH2
+            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            __syncthreads();                                               // BZ
+            if (hw == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
+            if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
+            __syncthreads();                                               // BD1
+            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            __syncthreads();                                               // BD2
+            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            __syncthreads();                                               // BDA
+            for (int t = hw; t < NT_OUT; t += 4) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
+            const bool more = it + 1 < ntl;
+            const int ntile = tile + (int)gridDim.x;
+            if (more && gather) fill_rows(ntile, (it + 1) & 1);
+            __syncthreads();                                               // BDD2: da consumed, U is free
+            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            // next tile's x: requested now, committed three phases later
+            const int64_t nb0 = (int64_t)ntile * TB;
+            const bool nfull = more && (nb0 + TB) <= g.B;
+            const int64_t* const nsrc = rowsrc + ((it + 1) & 1) * TB;
+            auto nrowof = [&](int r) -> int64_t {
+                if (gather) return nsrc[r];
+                const int64_t br = nb0 + r;
+                return br < g.B ? br : g.B - 1;
+            };
+            x_in_regs = more && g.fastx && nfull;
+            if (x_in_regs) tile513_issue(g.x, nrowof, xv, tl);
+            __syncthreads();                                               // BDD1
+            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            __syncthreads();                                               // BDML
+            if (hw == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
+            __syncthreads();                                               // BDH2
+            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            __syncthreads();                                               // BDH1
+            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (more) {
+                if (x_in_regs) tile513_commit<P, XP>(xv, U, LDU, tl);
+                else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof);
+            }
+            __syncthreads();                                               // BRED
+        }
+    }
+}
+
+template <typename P, int YP, bool YENC>
+static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
+    const size_t lds = Lds2<P>::bytes;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(rows2 kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC>), dim3(grid), dim3(512), lds, s, a);
+    DVAE_LAUNCH_OK("vae_rows2_kernel");
+    return 0;
+}
+
+// model: DVAE_MODEL_M1 / DVAE_MODEL_M2 (M2_info stays on the 4-wave kernel); precision: DVAE_PREC_BF16 / DVAE_PREC_BF16X3
+int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s) {
+    const bool m2 = model == DVAE_MODEL_M2;
+    if (precision == DVAE_PREC_BF16X3) {
+        if (!m2) return launch_rows2_t<PolX3, 0, false>(a, grid, s);
+        if (y_dim == 1) return launch_rows2_t<PolX3, 16, true>(a, grid, s);
+        return launch_rows2_t<PolX3, 528, true>(a, grid, s);
+    }
+    if (precision == DVAE_PREC_BF16) {
+        if (!m2) return launch_rows2_t<PolBF16, 0, false>(a, grid, s);
+        if (y_dim == 1) return launch_rows2_t<PolBF16, 16, true>(a, grid, s);
+        return launch_rows2_t<PolBF16, 528, true>(a, grid, s);
+    }
+    set_error("rows2 kernel: unsupported precision %d", precision);
+    return DVAE_E_UNSUPPORTED;
+}
+
+bool rows2_supported(int precision, int model) {
+    return (precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3) && (model == DVAE_MODEL_M1 || model == DVAE_MODEL_M2);
+}
+
+}  // namespace fused
+}  // namespace dvae

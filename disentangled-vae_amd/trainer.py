@@ -26,7 +26,8 @@ class TrainPlan(ctypes.Structure):
                 ("rows_grid", ctypes.c_int64), ("flops_per_step", ctypes.c_double), ("min_hbm_bytes_per_step", ctypes.c_double),
                 ("info_alpha", ctypes.c_double), ("info_beta", ctypes.c_double), ("info_gamma", ctypes.c_double),
                 ("rng_seed", ctypes.c_uint64), ("rng_step", ctypes.c_uint64), ("loss_accum", ctypes.c_uint64),
-                ("row_index", ctypes.c_uint64)]
+                ("row_index", ctypes.c_uint64), ("row_count", ctypes.c_int64), ("bad_row_counter", ctypes.c_uint64),
+                ("rows_kernel", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
 MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3}
@@ -73,6 +74,8 @@ class Trainer:
         self.lib = _lib()
         self.model, self.dims, self.B = model, dict(dims), int(batch)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.precision = precision
         self.lr, self.betas, self.adam_eps, self.elbo_eps = lr, betas, adam_eps, elbo_eps
         self.pg, self.world = process_group, int(world)
@@ -94,6 +97,8 @@ class Trainer:
                 self.params, self.m, self.v, self._shared = share.params, share.m, share.v, share._shared
             self.ws = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
             self.losses = torch.zeros(8 if model == "M2_info" else 3, dtype=torch.float32, device=self.device)
+            self.bad_rows = torch.zeros(1, dtype=torch.int32, device=self.device)      # gather indices the kernels refused (see bad_row_count)
+        self.plan.bad_row_counter = self.bad_rows.data_ptr()
         go = self.plan.grad_offset_bytes
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
         self._copy_version = self._shared["version"]
@@ -200,23 +205,35 @@ class Trainer:
     _reduced = False
 
     # ---- one train step ----
-    def _check_inputs(self, x, y, rows):
+    def _check_inputs(self, x, y, rows, eps_noise=None):
         """rows=None: x [B,513], y [B,y_dim] are the batch.  rows = int64 CUDA tensor [B]: x / y are a whole frame store
         ([N,513], [N,y_dim]) and frame b of the step is row rows[b] (gathered inside the kernel: no copy)."""
         B = self.B
         n = B if rows is None else x.shape[0]
-        if x.ndim != 2 or x.shape != (n, 513) or x.dtype != torch.float32 or not x.is_cuda:
-            raise ValueError(f"x must be a float32 CUDA tensor [{n if rows is not None else B}, 513]")
+        if x.ndim != 2 or x.shape != (n, 513) or x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError(f"x must be a float32 tensor [{n if rows is not None else B}, 513] on {self.device}")
         if self.y_dim:
-            if y is None or y.shape != (n, self.y_dim) or y.dtype != torch.float32:
-                raise ValueError(f"y must be a float32 CUDA tensor [{n}, {self.y_dim}]")
+            if y is None or y.shape != (n, self.y_dim) or y.dtype != torch.float32 or y.device != self.device:
+                raise ValueError(f"y must be a float32 tensor [{n}, {self.y_dim}] on {self.device}")
+        if eps_noise is not None and (eps_noise.shape != (B, 16) or eps_noise.dtype != torch.float32 or eps_noise.device != self.device):
+            raise ValueError(f"eps_noise must be a float32 tensor [{B}, 16] on {self.device}")
         if rows is not None:
-            if not (rows.is_cuda and rows.dtype == torch.int64 and rows.shape == (B,) and rows.is_contiguous()):
-                raise ValueError(f"rows must be a contiguous int64 CUDA tensor [{B}]")
+            if not (rows.device == self.device and rows.dtype == torch.int64 and rows.shape == (B,) and rows.is_contiguous()):
+                raise ValueError(f"rows must be a contiguous int64 tensor [{B}] on {self.device}")
+        # the kernels clamp an index outside [0, n) to row 0 and count it in self.bad_rows (no out-of-range read)
         self.plan.row_index = 0 if rows is None else rows.data_ptr()
+        self.plan.row_count = 0 if rows is None else n
+
+    def bad_row_count(self):
+        """Gather indices outside the frame store seen since the last call (synchronises); the affected frames were
+        trained on row 0 instead.  step() never reads memory through such an index."""
+        n = int(self.bad_rows.item())
+        if n:
+            self.bad_rows.zero_()
+        return n
 
     def step(self, x, y=None, eps_noise=None, rows=None):
-        self._check_inputs(x, y, rows)
+        self._check_inputs(x, y, rows, eps_noise)
         x = x if x.stride(1) == 1 else x.contiguous()
         if eps_noise is not None:           # None: the rows kernel draws the noise itself (Philox, see noise())
             eps_noise = eps_noise.contiguous()
@@ -230,6 +247,10 @@ class Trainer:
         self._shared["version"] += 1
         self._copy_version = self._shared["version"]
         plan = ctypes.byref(self.plan)
+        with torch.cuda.device(self.device):
+            return self._launch_step(plan, x, yp, ldy, eps_noise)
+
+    def _launch_step(self, plan, x, yp, ldy, eps_noise):
         s = N.stream()
         if self.world == 1:
             N.check(self.lib.dvae_train_step(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), N.ptr(x), N.ld(x),
@@ -249,16 +270,20 @@ class Trainer:
     def evaluate(self, x, y=None, eps_noise=None, rows=None):
         """Validation pass (scripts/training_M2.py:176-193): forward + elbo on a batch of the trainer's size, no
         backward, no update.  Returns a NEW device tensor [ELBO, recon, KL] (M2_info: 8 entries)."""
-        self._check_inputs(x, y, rows)
+        self._check_inputs(x, y, rows, eps_noise)
+        x = x if x.stride(1) == 1 else x.contiguous()
+        if self.y_dim:
+            y = y if y.stride(1) == 1 else y.contiguous()
         self._sync_copies()
         if eps_noise is None:               # drawn in the kernel, from a counter range the training steps never reach
             self._shared["eval_count"] = self._shared.get("eval_count", 0) + 1
             self.plan.rng_step = (1 << 40) + self._shared["eval_count"]
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         out = torch.zeros_like(self.losses)
-        N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
-                                         N.ptr(None if eps_noise is None else eps_noise.contiguous()), self.elbo_eps, N.ptr(out), N.stream()),
-                "dvae_train_eval")
+        with torch.cuda.device(self.device):
+            N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
+                                             N.ptr(None if eps_noise is None else eps_noise.contiguous()), self.elbo_eps, N.ptr(out), N.stream()),
+                    "dvae_train_eval")
         return out
 
     def accumulate_losses(self, buf):
@@ -278,6 +303,7 @@ class Trainer:
 
     def grads_only(self, x, y, eps_noise, reduce=False):
         """rows + wgrad kernels without the optimiser (tests / gradient inspection)."""
+        self._check_inputs(x, y, None, eps_noise)
         self._sync_copies()
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,

@@ -73,8 +73,17 @@ typedef struct {
     uint64_t loss_accum;
     /* Optional gather (epoch shuffle without copying the data set): device pointer to B int64 row numbers, or 0.
        When set, x and y are the whole frame store (rows of ldx / ldy floats) and frame b of the step is row
-       row_index[b]; the caller guarantees every index is in range. */
+       row_index[b].  row_count = rows of that store: an index outside [0, row_count) is never dereferenced -- the tile
+       loader reads row 0 instead and adds one to the int32 device counter bad_row_counter (0 = none), which the
+       caller inspects when it next synchronises. */
     uint64_t row_index;
+    int64_t  row_count;
+    uint64_t bad_row_counter;
+    /* rows kernel generation chosen by dvae_train_plan: 2 = 8-wave chain + helper kernel (csrc/train_rows2.hip; M1 / M2 with
+       bf16 or bf16x3 operands), 1 = 4-wave kernel (csrc/train_fused.hip; every model and policy).  Environment override
+       DVAE_ROWS=1 at plan time. */
+    int32_t  rows_kernel;
+    int32_t  reserved1;
 } dvae_train_plan_t;
 
 /* Fill `plan` for (model, y_dim, precision, B).  ksplit_hint 0 = choose.  Returns DVAE_E_UNSUPPORTED
