@@ -27,6 +27,7 @@ struct PolF32 {
     typedef f32x4 Pack4;
     static constexpr int E = 4;        // elements per 16-byte fragment
     static constexpr int NP = 1;       // operand planes (2 = bf16 hi + lo, see PolX3)
+    static constexpr int BDMAX = 4;    // LDS activation fragments read ahead of their MFMA (k-steps)
     static constexpr int KSTEP = 8;    // reduction depth per fragment pair
     static constexpr int PD = 6;       // weight fragments in flight per wave (k-steps ahead of the MFMAs)
     static constexpr int PRE = 2;      // of those, requested before the previous layer's epilogue
@@ -55,6 +56,7 @@ struct PolBF16 {
     typedef bf16x4 Pack4;
     static constexpr int E = 8;
     static constexpr int NP = 1;
+    static constexpr int BDMAX = 4;
     static constexpr int KSTEP = 16;
     static constexpr int PD = 16;
     static constexpr int PRE = 6;
@@ -106,6 +108,51 @@ struct PolX3 : PolBF16 {
     static constexpr int WRING = 4;
     static constexpr bool EARLY_Y = false;
     static constexpr bool XFULL = false;   // two operand planes fill the LDS: the fp32 x tile streams in 128-column slices
+};
+
+// Ring depths for the 8-wave rows kernel (train_rows2.hip): two waves per SIMD leave 256 registers per wave
+#ifndef R2_PD_X3
+#define R2_PD_X3 4
+#endif
+#ifndef R2_PRE_X3
+#define R2_PRE_X3 2
+#endif
+#ifndef R2_PD_BF
+#define R2_PD_BF 8
+#endif
+#ifndef R2_PRE_BF
+#define R2_PRE_BF 4
+#endif
+#ifndef R2_BD_X3
+#define R2_BD_X3 2
+#endif
+#ifndef R2_DBIG_X3
+#define R2_DBIG_X3 8
+#endif
+#ifndef R2_PBIG_X3
+#define R2_PBIG_X3 2
+#endif
+#ifndef R2_D128_X3
+#define R2_D128_X3 8
+#endif
+#ifndef R2_P128_X3
+#define R2_P128_X3 2
+#endif
+#ifndef R2_DBIG_BF
+#define R2_DBIG_BF 16
+#endif
+#ifndef R2_PBIG_BF
+#define R2_PBIG_BF 4
+#endif
+struct PolX3v2 : PolX3 {
+    static constexpr int PD = R2_PD_X3, PRE = R2_PRE_X3, PRE128 = R2_P128_X3, PREBIG = R2_PBIG_X3;   // PD / PRE: the output-layer loop (the register peak)
+    static constexpr int DBIG = R2_DBIG_X3, D128 = R2_D128_X3;   // ring depths of the long GEMMs / the 128-deep layers
+    static constexpr int BDMAX = R2_BD_X3;
+};
+struct PolBF16v2 : PolBF16 {
+    static constexpr int PD = R2_PD_BF, PRE = R2_PRE_BF, PRE128 = 8, PREBIG = R2_PBIG_BF;
+    static constexpr int DBIG = R2_DBIG_BF, D128 = 8;
+    static constexpr bool XFULL = false, EARLY_Y = false;
 };
 
 // LDS row strides (elements): an odd number of 16-byte slots per row
@@ -188,15 +235,17 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // (the previous layer's stash tile).  vmcnt retires loads and stores in issue order, so a store issued
 // right before a load that the next MFMA needs exposes a full write-acknowledge round trip; issued
 // here, the store acks overlap the D k-steps the ring already covers.
-template <typename P, int NSTEPS, typename Hook = NoHook, int PREN = P::PRE>
+// DMAX: weight-ring depth at this call site (k-steps in flight); call sites with few live registers ask for more
+template <typename P, int NSTEPS, typename Hook = NoHook, int PREN = P::PRE, int DMAX = P::PD>
 __device__ __forceinline__ void gemm_block(f32x16& acc, const WPre<P, NSTEPS, PREN>& w, __amdgpu_buffer_rsrc_t rs, WRef wr,
                                            const typename P::T* brow, unsigned WSTR, Hook after_fill = Hook(), bool blo = true) {
     typedef typename P::Frag Frag;
     constexpr int STR = 2 * P::E;        // LDS activations: k-step = 2E consecutive features of a frame row
-    constexpr int D = NSTEPS < P::PD ? NSTEPS : P::PD;
+    constexpr int D = NSTEPS < DMAX ? NSTEPS : DMAX;
     constexpr int NIT = D > 0 ? NSTEPS / D : 0, REM = D > 0 ? NSTEPS % D : 0;
     // activation fragments are read from LDS BD k-steps ahead; BD divides D so ring slots are static across laps
-    constexpr int BD = D % 4 == 0 ? 4 : (D % 3 == 0 ? 3 : (D % 2 == 0 ? 2 : 1));
+    constexpr int BDM = P::BDMAX;
+    constexpr int BD = (D % 4 == 0 && BDM >= 4) ? 4 : ((D % 3 == 0 && BDM >= 3) ? 3 : ((D % 2 == 0 && BDM >= 2) ? 2 : 1));
     static_assert(NIT <= 1 || D % BD == 0, "B ring must divide the weight ring");
     Frag a[D > 0 ? D : 1][P::NP];
 #pragma unroll
@@ -302,6 +351,23 @@ __device__ __forceinline__ void put_lds(const float (&v)[16], typename P::T* lds
             q[0] = P::cvt(v[4 * gq] - (float)p[0]); q[1] = P::cvt(v[4 * gq + 1] - (float)p[1]);
             q[2] = P::cvt(v[4 * gq + 2] - (float)p[2]); q[3] = P::cvt(v[4 * gq + 3] - (float)p[3]);
             *reinterpret_cast<Pack4*>(lds + Pl<P>::lds + l31 * ldl + fbase + 8 * gq + 4 * h) = q;
+        }
+    }
+}
+
+// inverse of put_lds: the 16 C-tile values of this lane back from the operand plane(s) (hi + lo for PolX3)
+template <typename P>
+__device__ __forceinline__ void get_lds(float (&v)[16], const typename P::T* lds, int ldl, int fbase, int l31, int h) {
+    typedef typename P::Pack4 Pack4;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const Pack4 p = *reinterpret_cast<const Pack4*>(lds + l31 * ldl + fbase + 8 * gq + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * gq + j] = (float)p[j];
+        if constexpr (P::NP == 2) {
+            const Pack4 q = *reinterpret_cast<const Pack4*>(lds + Pl<P>::lds + l31 * ldl + fbase + 8 * gq + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * gq + j] += (float)q[j];
         }
     }
 }

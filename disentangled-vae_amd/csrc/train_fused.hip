@@ -992,8 +992,12 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     }
     plan->n_params = off;
     const int64_t ntiles = (B + TB - 1) / TB;
+    // rows kernel generation: the 8-wave kernel wins for the split policy (48 vs 55 us per 8192 frames), the 4-wave kernel for plain
+    // bf16 (33 vs 35 us); DVAE_ROWS=1 / 2 forces one where both exist
     const char* rk = getenv("DVAE_ROWS");
-    plan->rows_kernel = (rows2_supported(precision, model) && !(rk && atoi(rk) == 1)) ? 2 : 1;
+    int want = precision == DVAE_PREC_BF16X3 ? 2 : 1;
+    if (rk && (atoi(rk) == 1 || atoi(rk) == 2)) want = atoi(rk);
+    plan->rows_kernel = (want == 2 && rows2_supported(precision, model)) ? 2 : 1;
     // workgroups resident at once: the 8-wave kernel holds one per CU; the 4-wave bf16 kernel two.  Beyond that: persistent tile loop
     const int64_t maxg = plan->rows_kernel == 2 ? 256 : 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
     plan->rows_grid = ntiles < maxg ? ntiles : maxg;

@@ -22,18 +22,18 @@
 //   (first tile only)  [H] x -> U, bias table      | BX
 //   [C] L1 x GEMM (U)              [H] y loads in flight, stash x          | BL1X      (y: only models with labels)
 //   [C] weight prefetch            [H] y -> U                              | BY
-//   [C] L1 y GEMM, dec-L1 y GEMM (U), h1 -> Ha     [H] stash y             | BH1
+//   [C] L1 y GEMM (U), h1 -> Ha    [H] stash y                             | BH1
 //   [C] L2 (Ha), h2 -> Hb          [H] stash h1 (Ha)                       | BH2
-//   [C] heads (Hb), z -> Zb        [H] stash h2 (Hb)                       | BZ
+//   [C] heads (Hb; wave 0), z -> Zb; dec-L1 label GEMM (U; all waves)   [H] stash h2 (Hb)   | BZ
 //   [C] dec L1 z (Zb), d1 -> Ha    [H] stash z (Zb)                        | BD1
 //   [C] dec L2 (Ha), d2 -> Hb      [H] stash d1 (Ha)                       | BD2
 //   [C] output layer (Hb), loss, da -> U          [H] stash d2 (Hb)        | BDA
-//   [C] bwd out (U), dpre_d2 -> Ha [H] stash da (U), next gather table     | BDD2
-//   [C] bwd d2 (Ha), dpre_d1 -> Hb [H] stash dpre_d2 (Ha), next x loads issued | BDD1
-//   [C] bwd z (Hb), dmu|dlv -> Zb  [H] stash dpre_d1 (Hb)                  | BDML
-//   [C] bwd heads (Zb), dpre_h2 -> Ha  [H] stash dmu|dlv (Zb)              | BDH2
-//   [C] bwd h2 (Ha), dpre_h1 -> Hb [H] stash dpre_h2 (Ha)                  | BDH1
-//   [C] loss sums -> red           [H] stash dpre_h1 (Hb), next x -> U     | BRED   (= BX of the next tile)
+//   [C] bwd out (U), dpre_d2 -> Hb (over d2)      [H] stash da (U), next gather table     | BDD2
+//   [C] bwd d2 (Hb), dpre_d1 -> Ha (over d1)      [H] stash dpre_d2 (Hb), next x loads issued | BDD1
+//   [C] bwd z (Ha), dmu|dlv -> Zb  [H] stash dpre_d1 (Ha)                  | BDML
+//   [C] bwd heads (Zb), dpre_h2 -> Hb  [H] stash dmu|dlv (Zb)              | BDH2
+//   [C] bwd h2 (Hb), dpre_h1 -> Ha [H] stash dpre_h2 (Hb)                  | BDH1
+//   [C] loss sums -> red           [H] stash dpre_h1 (Ha), next x -> U     | BRED   (= BX of the next tile)
 #include <math.h>
 #include <stdlib.h>
 #include "fused_tiles.hpp"
@@ -50,11 +50,68 @@ template <typename P> struct Lds2 {
     static constexpr size_t o_red = o_bias + (size_t)nbias * sizeof(float);
     static constexpr size_t o_flags = o_red + 16 * sizeof(float);
     static constexpr size_t o_rows = o_flags + 16 * sizeof(int);
-    static constexpr size_t bytes = o_rows + 2 * TB * sizeof(int64_t);
+    static constexpr size_t o_keep = o_rows + 2 * TB * sizeof(int64_t);                  // fp32 h1 | h2 of the chain waves: [2][16][256]
+    static constexpr size_t o_keepz = o_keep + 2 * 16 * 256 * sizeof(float);             // fp32 mu | log_var of wave 0: [16][64]
+    static constexpr size_t bytes = o_keepz + 16 * 64 * sizeof(float);
     static_assert(o_bias % 16 == 0 && o_rows % 8 == 0, "LDS carve alignment");
 };
 
+// Workgroup barrier that orders LDS only: waits for this wave's LDS operations, not for its global stores (the helpers'
+// stash stores stay in flight across phases; __syncthreads() carries a fence that drains vmcnt at every barrier, which made
+// the chain wait for the write acknowledgements of every stash tile: measured 60 -> 3x us per tile).  Global data handed
+// between the roles does not exist: the stash is consumed by the NEXT kernel, inputs are read-only.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+
+// Output layer for tiles t0, t0 + 4, ... of one chain wave (sharing the 16 tiles with the helper waves was tried: the
+// larger helper spilled and the phase did not get shorter -- it is not bound by per-wave work):
+// a = W5 d2 + b5 on a 32-feature tile, Itakura-Saito terms against x read straight from global memory, da -> U.
+// `wnext` (chain waves): weight fragments to request after the last tile's GEMM (the backward product's first k-steps).
+template <typename P, typename WNext>
+__device__ __forceinline__ void out_tiles(const RowsArgs& g, __amdgpu_buffer_rsrc_t wrs, WRef W5s, int t0, const typename P::T* Hbr, typename P::T* U,
+                                          const float* Bias5, const float* xrow, float invB_l, int l31, int h, float& rec_lane, WNext wnext) {
+    typedef typename P::T T;
+    constexpr int E = P::E, KS = P::KSTEP, LDU = Ld<T>::u;
+    constexpr unsigned SZ = sizeof(T), FB = 64 * E, S17 = NT_OUT * FB * SZ, TSTEP = FB * SZ;
+    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
+    auto xload = [&](int t, f32x4 (&q)[4]) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            if (g.ablate & 8) q[gq] = f32x4{1.f, 2.f, 3.f, 4.f};
+            else q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
+        }
+    };
+    f32x4 xq[4], xn[4];
+    WPre<P, HD / KS, P::PRE> w5;
+    wprefetch<P, HD / KS>(w5, wrs, woff(W5s, (unsigned)t0 * TSTEP), S17);
+    xload(t0, xq);
+    f32x16 acc;
+#pragma unroll 1
+    for (int t = t0; t < NT_OUT - 1; t += 4) {
+        zero_acc<P>(acc);
+        const WRef wr = woff(W5s, (unsigned)t * TSTEP);
+        const bool more = t + 4 < NT_OUT - 1;
+        if (more) xload(t + 4, xn);
+        if (!(g.ablate & 128)) gemm_block<P, HD / KS, NoHook, P::PRE, P::PD>(acc, w5, wrs, wr, Hbr, S17);
+        if (more) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
+        else wnext();
+        float da[16], b5v[16];
+        bias16(Bias5, 32 * t, h, b5v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float xs = xq[r >> 2][r & 3];
+            const float a = acc[r] + b5v[r];
+            const float xe = (g.ablate & 16) ? xs * a : xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
+            rec_lane += xe - ((g.ablate & 16) ? xs : P::log_(xs + g.elbo_eps)) + a - 1.f;   // utils.py:74 (log r = a)
+            da[r] = (1.f - xe) * invB_l;                         // d recon / d a
+        }
+        if (!(g.ablate & 32)) put_lds<P>(da, U, LDU, 32 * t, l31, h);
+        if (g.ablate & 64) continue;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) xq[gq] = xn[gq];
+    }
+}
 
 template <typename P, int YP, bool YENC>
 __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
@@ -73,6 +130,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     float* const red = reinterpret_cast<float*>(smem + Lds2<P>::o_red);
     int* const flags = reinterpret_cast<int*>(smem + Lds2<P>::o_flags);          // [0]: the label tile has a non-zero lo plane
     int64_t* const rowsrc = reinterpret_cast<int64_t*>(smem + Lds2<P>::o_rows);  // [2][TB] gather table, double buffered
+    // Two waves per SIMD leave 256 registers per wave: the tanh outputs the backward pass needs again do not stay in
+    // registers.  h1 / h2 (needed ten phases later) wait in private fp32 LDS slots; d1 / d2 are re-read from their own
+    // operand planes (hi + lo), which the backward tiles then overwrite in place (same lane, same elements).
+    float* const keep = reinterpret_cast<float*>(smem + Lds2<P>::o_keep);
+    float* const keepz = reinterpret_cast<float*>(smem + Lds2<P>::o_keepz);
     constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +154,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             return WRef{lane * 16, m + (unsigned)tile * (FB * SZ), g.wpl_bytes};
         };
         auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
-        constexpr unsigned S4 = 4 * FB * SZ, S1 = FB * SZ, S17 = NT_OUT * FB * SZ, TSTEP = FB * SZ;
+        constexpr unsigned S4 = 4 * FB * SZ, S1 = FB * SZ;
         constexpr unsigned KB1 = (XP / KS) * 4 * FB * SZ, KB3 = (ZD / KS) * 4 * FB * SZ;
         (void)LD1; (void)LD3;
         const WRef W1r = wbase(g.W1s, cw), W2r = wbase(g.W2s, cw), Wmvr = wbase(g.Wmvs, 0), W3r = wbase(g.W3s, cw), W4r = wbase(g.W4s, cw);
@@ -127,137 +189,109 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     for (int jq = 0; jq < 8; ++jq) ep_r[jq] = live ? ep_r[jq] : 0.f;
                 }
             }
-            WPre<P, XP / KS> w1x;
+            WPre<P, XP / KS, P::PREBIG> w1x;
             wprefetch<P, XP / KS>(w1x, wrs, W1r, S4);
             if (it == 0) {
-                if (gather) __syncthreads();                               // BROW
-                __syncthreads();                                           // BX
+                if (gather) wg_barrier();                               // BROW
+                wg_barrier();                                           // BX
             }
             R2_STAMP(1);
             // ---------------- encoder layer 1: [x | y] -> h1 ----------------
-            f32x16 acc, accy;
+            f32x16 acc;
             zero_acc<P>(acc);
-            gemm_block<P, XP / KS>(acc, w1x, wrs, W1r, Ur, S4);
+            gemm_block<P, XP / KS, NoHook, P::PREBIG, P::DBIG>(acc, w1x, wrs, W1r, Ur, S4);
             R2_STAMP(2);
             WPre<P, HD / KS, P::PRE128> w2;
+            bool ylo = false;
             if (YP > 0) {
-                WPre<P, (YENC ? YP : KS) / KS> w1y;
+                WPre<P, (YENC ? YP : KS) / KS, P::PREBIG> w1y;
                 if (YENC) wprefetch<P, (YENC ? YP : KS) / KS>(w1y, wrs, woff(W1r, KB1), S4);
-                __syncthreads();                                           // BL1X: the x image of U has been consumed
-                WPre<P, (YP > 0 ? YP : KS) / KS, P::PRE> w3y;
-                wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
-                __syncthreads();                                           // BY: the y image is in U
-                const bool ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
-                if (YENC) gemm_block<P, (YENC ? YP : KS) / KS>(acc, w1y, wrs, woff(W1r, KB1), Ur, S4, NoHook(), ylo);
-                // label block of decoder layer 1: independent of z, computed while the label tile is in LDS
-                zero_acc<P>(accy);
-                gemm_block<P, (YP > 0 ? YP : KS) / KS>(accy, w3y, wrs, woff(W3r, KB3), Ur, S4, NoHook(), ylo);
+                wg_barrier();                                           // BL1X: the x image of U has been consumed
+                wg_barrier();                                           // BY: the y image is in U (it stays there until the loss epilogue writes da)
+                ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
+                if (YENC) gemm_block<P, (YENC ? YP : KS) / KS, NoHook, P::PREBIG, P::DBIG>(acc, w1y, wrs, woff(W1r, KB1), Ur, S4, NoHook(), ylo);
             }
             wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
-            float h1r[16], bv[16];
+            float hv[16], bv[16];
             R2_STAMP(3);
             bias16(Bias + OB1, fb, h, bv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h1r[r] = P::tanh_(acc[r] + bv[r]);
-            put_lds<P>(h1r, Ha, LDH, fb, l31, h);
-            __syncthreads();                                               // BH1
+            for (int r = 0; r < 16; ++r) { hv[r] = P::tanh_(acc[r] + bv[r]); keep[r * 256 + tid] = hv[r]; }
+            put_lds<P>(hv, Ha, LDH, fb, l31, h);
+            wg_barrier();                                               // BH1
             R2_STAMP(4);
             // ---------------- encoder layer 2 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w2, wrs, W2r, Har, S4);
+            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w2, wrs, W2r, Har, S4);
             WPre<P, HD / KS, P::PRE128> wmv;
-            WPre<P, ZD / KS> w3z;
+            WPre<P, (YP > 0 ? YP : KS) / KS, P::PREBIG> w3y;
             if (cw == 0) wprefetch<P, HD / KS>(wmv, wrs, Wmvr, S1);
-            wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
-            float h2r[16];
+            else if (YP > 0) wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
             bias16(Bias + OB2, fb, h, bv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h2r[r] = P::tanh_(acc[r] + bv[r]);
-            put_lds<P>(h2r, Hb, LDH, fb, l31, h);
-            __syncthreads();                                               // BH2
+            for (int r = 0; r < 16; ++r) { hv[r] = P::tanh_(acc[r] + bv[r]); keep[(16 + r) * 256 + tid] = hv[r]; }
+            put_lds<P>(hv, Hb, LDH, fb, l31, h);
+            wg_barrier();                                               // BH2
             R2_STAMP(5);
             // ---------------- heads + reparametrisation (wave 0): rows 0-15 mu, 16-31 log_var ----------------
-            float mu_r[8], lv_r[8], sd_r[8];
+            f32x16 accy;
             if (cw == 0) {
                 zero_acc<P>(acc);
-                gemm_block<P, HD / KS>(acc, wmv, wrs, Wmvr, Hbr, S1);
+                gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, wmv, wrs, Wmvr, Hbr, S1);
+                if (YP > 0) wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
                 float zv[16];
                 bias16(Bias + OBMV, 0, h, bv);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    mu_r[r] = acc[r] + bv[r];
-                    lv_r[r] = acc[r + 8] + bv[r + 8];
-                    sd_r[r] = P::exp_(0.5f * lv_r[r]);                 // models.py:17
-                    zv[r] = fmaf(sd_r[r], ep_r[r], mu_r[r]);           // models.py:20
+                    const float mu = acc[r] + bv[r], lv = acc[r + 8] + bv[r + 8];
+                    keepz[r * 64 + lane] = mu; keepz[(8 + r) * 64 + lane] = lv;
+                    zv[r] = fmaf(P::exp_(0.5f * lv), ep_r[r], mu);     // models.py:17, 20
                     zv[r + 8] = 0.f;
-                    if (live) kl_lane += lv_r[r] - mu_r[r] * mu_r[r] - P::exp_(lv_r[r]);   // utils.py:75
+                    if (live) kl_lane += lv - mu * mu - P::exp_(lv);   // utils.py:75
                 }
                 put_lds<P>(zv, Zb, LDZ, 0, l31, h);
             }
-            __syncthreads();                                               // BZ
+            // label block of decoder layer 1: independent of z (three of the four waves have nothing else to do in this phase)
+            if (YP > 0) {
+                zero_acc<P>(accy);
+                gemm_block<P, (YP > 0 ? YP : KS) / KS, NoHook, P::PREBIG, P::DBIG>(accy, w3y, wrs, woff(W3r, KB3), Ur, S4, NoHook(), ylo);
+            }
+            WPre<P, ZD / KS> w3z;
+            wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
+            wg_barrier();                                               // BZ
             R2_STAMP(6);
             // ---------------- decoder layer 1: [z | y] -> d1 ----------------
             zero_acc<P>(acc);
             gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4);
             WPre<P, HD / KS, P::PRE128> w4;
             wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
-            float d1r[16];
             bias16(Bias + OB3, fb, h, bv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1r[r] = P::tanh_(acc[r] + (YP > 0 ? accy[r] : 0.f) + bv[r]);
-            put_lds<P>(d1r, Ha, LDH, fb, l31, h);
-            __syncthreads();                                               // BD1
+            for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + (YP > 0 ? accy[r] : 0.f) + bv[r]);
+            put_lds<P>(hv, Ha, LDH, fb, l31, h);
+            wg_barrier();                                               // BD1
             R2_STAMP(7);
             // ---------------- decoder layer 2 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w4, wrs, W4r, Har, S4);
-            WPre<P, HD / KS, P::PRE128> w5;
-            wprefetch<P, HD / KS>(w5, wrs, woff(W5s, cw * TSTEP), S17);
+            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w4, wrs, W4r, Har, S4);
             // loss epilogue input: x[frame][32 t + 8 gq + 4 h .. + 3] of this lane's frame straight from global memory
-            // (the tile was read a few microseconds ago: L2 / MALL), one output tile ahead
+            // (the tile was read a few microseconds ago: L2 / MALL)
             int64_t rowx;
             if (gather) rowx = rsrc[l31];
             else { rowx = b0 + l31; rowx = rowx < g.B ? rowx : g.B - 1; }
             const float* const xrow = g.x + rowx * g.ldx + 4 * h;
-            f32x4 xq[4], xn[4];
-            auto xload = [&](int t, f32x4 (&q)[4]) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
-            };
-            xload(cw, xq);
-            float d2r[16];
             bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2r[r] = P::tanh_(acc[r] + bv[r]);
-            put_lds<P>(d2r, Hb, LDH, fb, l31, h);
-            __syncthreads();                                               // BD2
+            for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(hv, Hb, LDH, fb, l31, h);
+            wg_barrier();                                               // BD2
             R2_STAMP(8);
             // ---------------- output layer a = W5 d2 + b5, Itakura-Saito terms, da -> U ----------------
-            WPre<P, NO / KS> w5t;
+            WPre<P, NO / KS, P::PRE> w5t;
             const float invB_l = live ? g.invB : 0.f;                      // frames past B contribute nothing
-            // 16 full tiles = 4 per wave; the 17th tile holds ONE real feature (bin 512): wave 3 does it as a 128-term dot product
-#pragma unroll 1
-            for (int t = cw; t < NT_OUT - 1; t += 4) {
-                zero_acc<P>(acc);
-                const WRef wr = woff(W5s, (unsigned)t * TSTEP);
-                if (t + 4 < NT_OUT - 1) xload(t + 4, xn);
-                gemm_block<P, HD / KS>(acc, w5, wrs, wr, Hbr, S17);
-                if (t + 4 < NT_OUT - 1) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
-                else wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4);
-                float da[16], b5v[16];
-                bias16(Bias + OB5, 32 * t, h, b5v);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float xs = xq[r >> 2][r & 3];
-                    const float a = acc[r] + b5v[r];
-                    const float xe = xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
-                    rec_lane += xe - P::log_(xs + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
-                    da[r] = (1.f - xe) * invB_l;                         // d recon / d a
-                }
-                put_lds<P>(da, U, LDU, 32 * t, l31, h);
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) xq[gq] = xn[gq];
-            }
+            // 16 full tiles, 4 per chain wave; the 17th tile holds ONE real feature (bin 512): chain wave 3 does it as a 128-term dot product
+            out_tiles<P>(g, wrs, W5s, cw, Hbr, U, Bias + OB5, xrow, invB_l, l31, h, rec_lane,
+                         [&]() { wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4); });
             if (cw == 3) {
                 const float* wl = Bias + OB5 + NO + 64 * h;                 // this half's 64 weights (LDS broadcast reads)
                 const T* drow = Hb + l31 * LDH + 64 * h;
@@ -301,45 +335,47 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if constexpr (NP == 2) *reinterpret_cast<Frag*>(urow + Pl<P>::lds + c * E) = fl;
                 }
             }
-            __syncthreads();                                               // BDA
+            wg_barrier();                                               // BDA
             R2_STAMP(9);
             // ---------------- backward: d2 <- da ----------------
             zero_acc<P>(acc);
-            gemm_block<P, NO / KS>(acc, w5t, wrs, W5tr, Ur, S4);
+            gemm_block<P, NO / KS, NoHook, P::PRE, P::DBIG>(acc, w5t, wrs, W5tr, Ur, S4);
             WPre<P, HD / KS, P::PRE128> w4t;
             wprefetch<P, HD / KS>(w4t, wrs, W4tr, S4);
             float dv[16];
+            get_lds<P>(hv, Hb, LDH, fb, l31, h);                          // d2 of this lane's elements (every reader of Hb has passed BDA)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d2r[r] * d2r[r]);
-            put_lds<P>(dv, Ha, LDH, fb, l31, h);
-            __syncthreads();                                               // BDD2
+            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - hv[r] * hv[r]);
+            put_lds<P>(dv, Hb, LDH, fb, l31, h);                          // in place
+            wg_barrier();                                               // BDD2
             R2_STAMP(10);
             // ---------------- backward: d1 <- dpre_d2 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w4t, wrs, W4tr, Har, S4);
+            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w4t, wrs, W4tr, Hbr, S4);
             WPre<P, HD / KS, P::PRE128> w3zt;
             WPre<P, 32 / KS> wmvt;
             if (cw == 0) wprefetch<P, HD / KS>(w3zt, wrs, W3ztr, S1);
             wprefetch<P, 32 / KS>(wmvt, wrs, Wmvtr, S4);
+            get_lds<P>(hv, Ha, LDH, fb, l31, h);                          // d1: Ha has not been written since decoder layer 1
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - d1r[r] * d1r[r]);
-            put_lds<P>(dv, Hb, LDH, fb, l31, h);
-            __syncthreads();                                               // BDD1
+            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - hv[r] * hv[r]);
+            put_lds<P>(dv, Ha, LDH, fb, l31, h);                          // in place
+            wg_barrier();                                               // BDD1
             R2_STAMP(11);
             // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
             if (cw == 0) {
                 zero_acc<P>(acc);
-                gemm_block<P, HD / KS>(acc, w3zt, wrs, W3ztr, Hbr, S1);
+                gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w3zt, wrs, W3ztr, Har, S1);
                 float dml[16];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float dz = acc[r];
-                    dml[r] = live ? dz + mu_r[r] * g.invB : 0.f;                                                    // dmu
-                    dml[r + 8] = live ? dz * ep_r[r] * (0.5f * sd_r[r]) - 0.5f * g.invB * (1.f - P::exp_(lv_r[r])) : 0.f;   // dlogvar
+                    const float dz = acc[r], mu = keepz[r * 64 + lane], lv = keepz[(8 + r) * 64 + lane];
+                    dml[r] = live ? dz + mu * g.invB : 0.f;                                                         // dmu
+                    dml[r + 8] = live ? dz * ep_r[r] * (0.5f * P::exp_(0.5f * lv)) - 0.5f * g.invB * (1.f - P::exp_(lv)) : 0.f;   // dlogvar
                 }
                 put_lds<P>(dml, Zb, LDZ, 0, l31, h);
             }
-            __syncthreads();                                               // BDML
+            wg_barrier();                                               // BDML
             R2_STAMP(12);
             // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
             zero_acc<P>(acc);
@@ -347,23 +383,23 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             WPre<P, HD / KS, P::PRE128> w2t;
             wprefetch<P, HD / KS>(w2t, wrs, W2tr, S4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h2r[r] * h2r[r]);
-            put_lds<P>(dv, Ha, LDH, fb, l31, h);
-            __syncthreads();                                               // BDH2
+            for (int r = 0; r < 16; ++r) { const float hk = keep[(16 + r) * 256 + tid]; dv[r] = acc[r] * (1.f - hk * hk); }
+            put_lds<P>(dv, Hb, LDH, fb, l31, h);
+            wg_barrier();                                               // BDH2
             R2_STAMP(13);
             // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS>(acc, w2t, wrs, W2tr, Har, S4);
+            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w2t, wrs, W2tr, Hbr, S4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - h1r[r] * h1r[r]);
-            put_lds<P>(dv, Hb, LDH, fb, l31, h);
-            __syncthreads();                                               // BDH1
+            for (int r = 0; r < 16; ++r) { const float hk = keep[r * 256 + tid]; dv[r] = acc[r] * (1.f - hk * hk); }
+            put_lds<P>(dv, Ha, LDH, fb, l31, h);
+            wg_barrier();                                               // BDH1
             R2_STAMP(14);
             // ---------------- per-tile loss sums ----------------
             if (!live) rec_lane = 0.f;
             const float rs = wave_sum(rec_lane), ks = wave_sum(kl_lane);
             if (lane == 0) { red[cw] = rs; red[4 + cw] = ks; }
-            __syncthreads();                                               // BRED (the next tile's x image is in U)
+            wg_barrier();                                               // BRED (the next tile's x image is in U)
             if (tid == 0) {
                 tot_rec += (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
                 tot_kl += -0.5 * (double)red[4];
@@ -380,6 +416,8 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     } else {
         // =========================================================== helper waves ===========================================================
         const int hw = wave_u - 4, ht = tid - 256;
+        // (An L2 warm-up of the weight copies by the helpers -- one dword per 128-byte line, 1/32 of the buffer per workgroup of an
+        // XCD -- changed nothing: the weight stream runs at the ~34 B/clk/CU of an L2-resident table shared by every CU, not at miss latency.)
         // fp32 bias table -> LDS once; the loads are issued here (clamped addresses instead of branches)
         constexpr int NBT = Ld<T>::nbias;
         constexpr int NB = (NBT + 255) / 256;
@@ -425,7 +463,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             int tl = ht;
             asm volatile("" : "+v"(tl));
             if (it == 0) {
-                if (gather) { fill_rows(tile, 0); __syncthreads(); }       // BROW
+                if (gather) { fill_rows(tile, 0); wg_barrier(); }       // BROW
                 if (g.fastx && full) {
                     tile513_issue(g.x, rowof, xv, tl);
 #pragma unroll
@@ -443,15 +481,15 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof);
                 }
                 if (ht == 0) flags[0] = 0;
-                __syncthreads();                                           // BX
+                wg_barrier();                                           // BX
             }
             // ---- chain: L1 x GEMM.  y loads in flight, x -> stash
             const bool yfast = Y513 && g.fasty && full;
             f32x4 yv[NQ513];
             if (YP > 0) {
                 if (Y513 && yfast) tile513_issue(g.y, rowof, yv, tl);
-                stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
-                __syncthreads();                                           // BL1X
+                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                wg_barrier();                                           // BL1X
                 if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl);
                 else load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl, rowof);
                 if constexpr (NP == 2) {                                   // does the label tile need its lo plane?
@@ -466,29 +504,29 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     }
                     if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
                 }
-                __syncthreads();                                           // BY
-                stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+                wg_barrier();                                           // BY
+                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
             } else {
-                stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
             }
-            __syncthreads();                                               // BH1
-            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            __syncthreads();                                               // BH2
-            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            __syncthreads();                                               // BZ
-            if (hw == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
+            wg_barrier();                                               // BH1
+            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BH2
+            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BZ
+            if (hw == 0 && !(g.ablate & 1)) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
             if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
-            __syncthreads();                                               // BD1
-            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            __syncthreads();                                               // BD2
-            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            __syncthreads();                                               // BDA
-            for (int t = hw; t < NT_OUT; t += 4) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BD1
+            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BD2
+            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BDA
+            for (int t = hw; t < NT_OUT; t += 4) if (!(g.ablate & 1)) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
             const bool more = it + 1 < ntl;
             const int ntile = tile + (int)gridDim.x;
             if (more && gather) fill_rows(ntile, (it + 1) & 1);
-            __syncthreads();                                               // BDD2: da consumed, U is free
-            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BDD2: da consumed, U is free
+            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dd2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             // next tile's x: requested now, committed three phases later
             const int64_t nb0 = (int64_t)ntile * TB;
             const bool nfull = more && (nb0 + TB) <= g.B;
@@ -500,19 +538,19 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             };
             x_in_regs = more && g.fastx && nfull;
             if (x_in_regs) tile513_issue(g.x, nrowof, xv, tl);
-            __syncthreads();                                               // BDD1
-            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            __syncthreads();                                               // BDML
-            if (hw == 0) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
-            __syncthreads();                                               // BDH2
-            stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            __syncthreads();                                               // BDH1
-            stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BDD1
+            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BDML
+            if (hw == 0 && !(g.ablate & 1)) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
+            wg_barrier();                                               // BDH2
+            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            wg_barrier();                                               // BDH1
+            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             if (more) {
                 if (x_in_regs) tile513_commit<P, XP>(xv, U, LDU, tl);
                 else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof);
             }
-            __syncthreads();                                               // BRED
+            wg_barrier();                                               // BRED
         }
     }
 }
@@ -538,14 +576,14 @@ static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
 int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s) {
     const bool m2 = model == DVAE_MODEL_M2;
     if (precision == DVAE_PREC_BF16X3) {
-        if (!m2) return launch_rows2_t<PolX3, 0, false>(a, grid, s);
-        if (y_dim == 1) return launch_rows2_t<PolX3, 16, true>(a, grid, s);
-        return launch_rows2_t<PolX3, 528, true>(a, grid, s);
+        if (!m2) return launch_rows2_t<PolX3v2, 0, false>(a, grid, s);
+        if (y_dim == 1) return launch_rows2_t<PolX3v2, 16, true>(a, grid, s);
+        return launch_rows2_t<PolX3v2, 528, true>(a, grid, s);
     }
     if (precision == DVAE_PREC_BF16) {
-        if (!m2) return launch_rows2_t<PolBF16, 0, false>(a, grid, s);
-        if (y_dim == 1) return launch_rows2_t<PolBF16, 16, true>(a, grid, s);
-        return launch_rows2_t<PolBF16, 528, true>(a, grid, s);
+        if (!m2) return launch_rows2_t<PolBF16v2, 0, false>(a, grid, s);
+        if (y_dim == 1) return launch_rows2_t<PolBF16v2, 16, true>(a, grid, s);
+        return launch_rows2_t<PolBF16v2, 528, true>(a, grid, s);
     }
     set_error("rows2 kernel: unsupported precision %d", precision);
     return DVAE_E_UNSUPPORTED;

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvae_hip.so")
+LIB_PATH = os.environ.get("DVAE_LIB") or os.path.join(_HERE, "libdvae_hip.so")      # DVAE_LIB: diagnostic builds (tools/exp_rows2.sh)
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID, ACT_EXP = 0, 1, 2, 3, 4
 ABI_VERSION = 1
