@@ -9,17 +9,23 @@ Adam; + gradient all-reduce when N > 1) of the M2 VAE, 513 bins, on N MI355X.
 A "step" is one pass of the hot path over one batch of B synthetic frames per GPU
 (weak scaling: B per GPU is fixed).  Inputs are resident in HBM before the timed region
 (cycled from a >= 1 GB device pool so they are not cache resident).  Rank 0 prints ONE JSON line.
+
+Default = the parity-grade throughput mode: bf16x3 (split-bf16 MFMA operands, three MFMAs per product, fp32 accumulate and
+master weights; losses ~1e-7 and gradients ~1e-4 of their maximum against float64, tests/test_gpu_fused.py).  The same line
+carries, measured in the same process (N = 1): `parity_mode` (the exact-fp32-MFMA policy and the one-bf16-per-operand fast
+mode), `spread` (5 more repeats of the timed region), `b128` (the reference scripts' batch size, GPU and CPU) and
+`cpu_baseline` (oracle/torch_ref.py on the host cores: all granted cores, and one thread).
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch
 
@@ -27,7 +33,6 @@ import torch
 TRAIN_FLOPS = {("M1", 0): 890112, ("M2", 1): 891136, ("M2", 513): 1415424, ("M2_info", 1): 1475072}
 # mandatory HBM bytes per frame for a fused step (x, y, eps read once, fp32)
 MIN_BYTES = {("M1", 0): 2116, ("M2", 1): 2120, ("M2", 513): 4168, ("M2_info", 1): 2120}
-PEAK = {"hbm": (8000.0, "GB/s"), "mfma_f32": (157.3, "TFLOP/s"), "mfma_bf16": (2500.0, "TFLOP/s")}
 
 
 def parse():
@@ -39,45 +44,28 @@ def parse():
     ap.add_argument("--y-dim", type=int, default=None, help="label width (M2 default 513 = IBM labels, the script default)")
     ap.add_argument("--batch", type=int, default=8192, help="frames per step per GPU")
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "modules"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"],
+                    help="MFMA operand policy of the fused path: bf16x3 = split bf16 (parity grade), bf16 = one bf16 per operand (fast, loose), fp32 = exact fp32 MFMA")
     ap.add_argument("--pool-gb", type=float, default=1.0)
     ap.add_argument("--ksplit", type=int, default=0, help="frame-axis slices of the weight-gradient kernel (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip parity_mode / spread / b128 (they run outside the timed region)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
-
-
-def synth_batches(dims, B, nb, seed, device):
-    """SURVEY.md 8d synthetic frames generated on the device (plumbing, outside the timed region)."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    xd, yd, zd = dims["x_dim"], dims["y_dim"], dims["z_dim"]
-    out = []
-    for _ in range(nb):
-        n1 = torch.randn((B, xd), generator=g, device=device)
-        n2 = torch.randn((B, xd), generator=g, device=device)
-        n3 = torch.randn((B, xd), generator=g, device=device)
-        x = (torch.exp(4 * n1 - 8) * (n2 * n2 + n3 * n3) / 2).clamp_(1e-12, 1e4)
-        y = None
-        if yd:
-            y = (torch.rand((B, yd), generator=g, device=device) < (0.6 if yd == 1 else 0.3)).float()
-        e = torch.randn((B, zd), generator=g, device=device)
-        out.append((x, y, e))
-    return out
 
 
 class ModulesImpl:
     """The drop-in path: packages.models modules + autograd Functions + stock torch.optim.Adam."""
-    name = "modules(layer-level HIP kernels + torch.optim.Adam)"
+    name = "modules(packages.models drop-in modules + autograd + torch.optim.Adam)"
 
     def __init__(self, model, dims, device, world):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from impl_modules import build_model
+        synth = importlib.import_module("disentangled-vae_amd.synth")
         from packages.models import models as M
         from packages.models.utils import elbo, binary_cross_entropy
         self.M, self.elbo, self.bce = M, elbo, binary_cross_entropy
         torch.manual_seed(0)
         self.model = model
-        self.m = build_model(model, dims).to(device)
+        self.m = synth.build_model(model, dims).to(device)
         self.world = world
         if model == "M2_info":
             self.opt = torch.optim.Adam(self.m.enc_dec_clf.parameters(), lr=1e-4, betas=(0.9, 0.999))
@@ -139,18 +127,17 @@ def host_cores():
     return n
 
 
-def cpu_baseline(model, dims, B, seconds):
-    """The reference's CPU loop body (oracle/torch_ref.py, kind "port") on this node's host cores."""
+def cpu_steps_per_s(model, dims, B, seconds, threads, max_steps=400):
+    """The reference's CPU loop body (oracle/torch_ref.py, kind "port") for `seconds` on `threads` host threads."""
     from oracle import torch_ref as tr
-    import golden_util as gu
-    ncores = host_cores()
-    torch.set_num_threads(ncores)
+    synth = importlib.import_module("disentangled-vae_amd.synth")
+    torch.set_num_threads(threads)
     d = dict(x_dim=dims["x_dim"], y_dim=max(dims["y_dim"], 1) if model != "M1" else 1, z_dim=dims["z_dim"], h_dim=dims["h_dim"])
     p = tr.init_params(model, seed=0, **d)
     st = tr.Stepper(model, p)
     xs = []
     for i in range(2):
-        x, y, e = gu.make_batch(dims, B, 4321 + i)
+        x, y, e = synth.make_batch(dims, B, 4321 + i)
         xs.append((torch.from_numpy(x), None if y is None else torch.from_numpy(y), torch.from_numpy(e)))
     for i in range(2):
         st.step(*xs[i % 2])
@@ -158,10 +145,43 @@ def cpu_baseline(model, dims, B, seconds):
     while True:
         st.step(*xs[n % 2]); n += 1
         dt = time.perf_counter() - t0
-        if dt > seconds or n >= 400:
+        if dt > seconds or n >= max_steps:
             break
-    return {"value": B * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steps of {B} frames ({model}, fp32, torch {torch.__version__} CPU ops + torch.optim.Adam), {dt:.1f} s"}
+    return B * n / dt, n, dt, torch.get_num_threads()
+
+
+def cpu_baseline(model, dims, B, seconds):
+    ncores = host_cores()
+    v, n, dt, thr = cpu_steps_per_s(model, dims, B, seconds, ncores)
+    v1, n1, dt1, _ = cpu_steps_per_s(model, dims, B, max(4.0, 0.6 * seconds), 1, max_steps=60)
+    torch.set_num_threads(ncores)
+    what = f"({model}, fp32, torch {torch.__version__} CPU ops + torch.optim.Adam)"
+    return {"value": v, "unit": "frames/s", "cores": thr, "kind": "port",
+            "sample": f"{n} steps of {B} frames {what}, {dt:.1f} s",
+            "single_thread": {"value": v1, "unit": "frames/s", "cores": 1, "sample": f"{n1} steps of {B} frames {what}, {dt1:.1f} s"}}
+
+
+def timed_steps(impl, batches, first, steps, dist, device):
+    """K steps bracketed by barrier + synchronize on both sides; max over ranks.  Returns (seconds, last loss tensor)."""
+    nb = len(batches)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = impl.step(*batches[(first + i) % nb])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, last
 
 
 def main():
@@ -177,7 +197,7 @@ def main():
     dev_index = local_rank % max(ndev, 1)          # one rank per GPU on the node; wraps only on test rigs with fewer GPUs
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    dist = None
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -186,26 +206,23 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    synth = importlib.import_module("disentangled-vae_amd.synth")
     y_dim = a.y_dim if a.y_dim is not None else {"M1": 0, "M2": 513, "M2_info": 1}[a.model]
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     B = a.batch
     bytes_per_batch = B * (513 + y_dim + 16) * 4
     nb = max(2, min(64, int(a.pool_gb * 2 ** 30 / bytes_per_batch) + 1))
-    batches = synth_batches(dims, B, nb, 1234 + rank, device)
+    batches = synth.device_batches(dims, B, nb, 1234 + rank, device)
 
     impl_name = a.impl
     trainer_mod = None
     if impl_name in ("auto", "fused"):
-        try:
-            trainer_mod = importlib.import_module("disentangled-vae_amd.trainer")
-        except ModuleNotFoundError:
-            if impl_name == "fused":
-                raise
-        impl_name = "fused" if trainer_mod is not None else "modules"
-        if trainer_mod is not None and not trainer_mod.supported(a.model, dims):
+        trainer_mod = importlib.import_module("disentangled-vae_amd.trainer")
+        impl_name = "fused"
+        if not trainer_mod.supported(a.model, dims):
             if a.impl == "fused":
                 raise SystemExit(f"fused train step does not cover {a.model} {dims}")
-            impl_name = "modules"        # e.g. M2_info: layer-level HIP kernels + autograd + torch.optim.Adam
+            impl_name = "modules"
     if impl_name == "fused":
         impl = trainer_mod.BenchImpl(a.model, dims, B, device, world, a.precision, ksplit=a.ksplit)
     else:
@@ -213,29 +230,18 @@ def main():
 
     for i in range(a.warmup):
         impl.step(*batches[i % nb])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        last = impl.step(*batches[(a.warmup + i) % nb])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, last = timed_steps(impl, batches, a.warmup, a.steps, dist, device)          # THE timed region: exactly K steps
     final_loss = float(last.reshape(-1)[0].item()) if last is not None else float("nan")
+
+    extras = not a.no_extras
+    spread = None
+    if extras:                                                                      # run-to-run spread inside the process
+        reps = [1e3 * timed_steps(impl, batches, a.warmup + (r + 1) * a.steps, a.steps, dist, device)[0] / a.steps for r in range(5)]
+        spread = {"repeats": 5, "steps_each": a.steps, "ms_per_step_min": min(reps), "ms_per_step_median": statistics.median(reps),
+                  "ms_per_step_max": max(reps), "note": "five more repeats of the timed region, after it"}
 
     prof = impl.kernel_profile(batches, min(a.steps, 50))
     key = (a.model, y_dim)
-    roofline = None
-    if prof is not None:
-        roofline = prof
     out = {
         "metric": "spectrogram frames/sec (train step), M2 VAE 513-bin" if a.model == "M2" else f"spectrogram frames/sec (train step), {a.model} VAE 513-bin",
         "value": world * B * a.steps / dt,
@@ -254,11 +260,39 @@ def main():
                    "frames_per_step_per_gpu": B, "global_frames_per_step": B * world, "impl": impl.name,
                    "parallelism": f"dp{world}", "final_elbo": final_loss,
                    "train_flops_per_frame": TRAIN_FLOPS.get(key), "min_hbm_bytes_per_frame": MIN_BYTES.get(key)},
-        "roofline": roofline,
+        "roofline": prof,
+        "spread": spread,
     }
+    if world > 1:
+        out["multi_gpu"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(),
+                            "allreduce_us": None if prof is None else prof.get("allreduce_us"),
+                            "allreduce_bytes": None if impl_name != "fused" else 4 * int(impl.tr.plan.n_params),
+                            "note": "allreduce_us = mean device time of the flat-gradient all-reduce per step (events on the launch stream, rank 0)"}
     if rank == 0:
+        if world == 1 and extras and impl_name == "fused":
+            def other(precision, Bx, steps):
+                bs = synth.device_batches(dims, Bx, 4, 99, device)
+                o = trainer_mod.BenchImpl(a.model, dims, Bx, device, 1, precision)
+                for i in range(20):
+                    o.step(*bs[i % 4])
+                t, _ = timed_steps(o, bs, 0, steps, None, device)
+                return 1e3 * t / steps
+            pm = {}
+            for prec in ("fp32", "bf16", "bf16x3"):
+                if prec != a.precision:
+                    pm[prec + "_ms_per_step"] = other(prec, B, min(a.steps, 100))
+            pm["note"] = ("same workload, other MFMA operand policies, measured in this process: fp32 = exact fp32 MFMA (<= 1e-4 on everything); "
+                          "bf16 = one bf16 per operand (gradients within ~4e-2 of their maximum); the headline policy is " + a.precision)
+            out["parity_mode"] = pm
+            g128 = other(a.precision, 128, 200)
+            out["b128"] = {"frames_per_step": 128, "gpu_ms_per_step": g128, "gpu_frames_per_s": 128 / (g128 * 1e-3),
+                           "note": "the batch size of scripts/training_M2.py:60"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model, dims, B, a.cpu_seconds)
+            if "b128" in out:
+                v, n, dtc, thr = cpu_steps_per_s(a.model, dims, 128, 3.0, host_cores())
+                out["b128"]["cpu_frames_per_s"] = v
+                out["b128"]["cpu_cores"] = thr
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -260,7 +260,14 @@ class Trainer:
         else:
             N.check(self.lib.dvae_train_grads(plan, N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
                                               self.elbo_eps, 1, s), "dvae_train_grads")
+            ev = None
+            if self._ar_events is not None:                           # profiling: device time of the exchange, on the launch stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dp.allreduce_flat_(self.flat_grad, self.pg)              # RCCL over xGMI: one flat fp32 buffer per step
+            if ev is not None:
+                ev[1].record()
+                self._ar_events.append(ev)
             N.check(self.lib.dvae_train_apply(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), 1, self.step_count,
                                               self.lr, self.betas[0], self.betas[1], self.adam_eps, 1.0 / self.world,
                                               N.ptr(self.losses), s), "dvae_train_apply")
@@ -311,8 +318,18 @@ class Trainer:
         self._reduced = bool(reduce)
 
     # ---- per-kernel device time (hipEvents on the launch stream) ----
+    _ar_events = None
+
     def profile(self, enable):
         self.lib.dvae_train_profile(1 if enable else 0)
+        self._ar_events = [] if (enable and self.world > 1) else None
+
+    def allreduce_us(self):
+        """Mean device time (us) of the gradient all-reduce over the steps made since profile(True); None at world 1."""
+        if not self._ar_events:
+            return None
+        torch.cuda.synchronize()
+        return 1e3 * sum(a.elapsed_time(b) for a, b in self._ar_events) / len(self._ar_events)
 
     def profile_read(self):
         ms = (ctypes.c_double * 4)()
@@ -347,6 +364,7 @@ class BenchImpl:
         for i in range(steps):
             tr.step(*batches[i % len(batches)])
         prof = tr.profile_read()
+        ar_us = tr.allreduce_us()
         tr.profile(False)
         avg = {k: (ms / c * 1e3 if c else 0.0) for k, (ms, c) in prof.items()}      # us per launch
         dom = max(avg, key=lambda k: avg[k])
@@ -370,17 +388,24 @@ class BenchImpl:
             bound, ach, peak, unit = "mfma", flops[dom] / dur / 1e12, peak_f, "TFLOP/s"
         else:
             bound, ach, peak, unit = "hbm", byts[dom] / dur / 1e9, 8000.0, "GB/s"
-        traffic = None
-        try:        # PMC-derived HBM bytes per launch (separate rocprofv3 --pmc passes, summarised by tools/pmc_traffic.py)
+        # HBM bytes per launch of the dominant kernel: NOT measured in this run -- an offline PMC figure (separate rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note; tools/pmc_traffic.py) committed under profiles/, used only
+        # when it was taken on this exact configuration
+        rows_name = "vae_rows2_kernel" if tr.plan.rows_kernel == 2 else "vae_rows_kernel"
+        knames = {"rows": rows_name, "wgrad": "wgrad_kernel", "apply": "apply_kernel", "reduce": "slab_reduce_kernel"}
+        traffic, traffic_source = None, None
+        try:
             import json, os
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_r01.json")))
-            kname = {"rows": "vae_rows_kernel", "wgrad": "wgrad_kernel", "apply": "apply_kernel", "reduce": "slab_reduce_kernel"}[dom]
-            if self.model == "M2" and y == 513 and B == 8192 and self.precision == "bf16" and kname in tj:
-                traffic = tj[kname]["hbm_bytes_per_launch"]
+            rel = os.path.join("profiles", "traffic_r02.json")
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), rel)))
+            cfg = tj.get("config", {})
+            if (cfg.get("model"), cfg.get("y_dim"), cfg.get("batch"), cfg.get("precision")) == (self.model, y, B, self.precision) and knames[dom] in tj["kernels"]:
+                traffic = tj["kernels"][knames[dom]]["hbm_bytes_per_launch"]
+                traffic_source = rel + " (offline rocprofv3 PMC passes, not this run)"
         except Exception:
-            traffic = None
-        return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
-                "kernel": {"rows": "vae_rows_kernel", "wgrad": "wgrad_kernel", "apply": "apply_kernel", "reduce": "slab_reduce_kernel"}[dom],
+            traffic, traffic_source = None, None
+        return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": knames[dom], "allreduce_us": ar_us,
                 "avg_us": avg, "algorithmic_flops_per_launch": flops[dom], "algorithmic_bytes_per_launch": byts[dom],
                 "mfma_frac": flops[dom] / dur / 1e12 / peak_f, "hbm_frac": byts[dom] / dur / 8.0e12,
                 "timing": "hipEventElapsedTime around each launch on the launch stream, mean over %d steps" % steps}

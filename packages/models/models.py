@@ -183,20 +183,14 @@ class VariationalAutoencoder(nn.Module):
         _xavier_reset(self)
 
     def _kld(self, z, q_param, p_param=None):
-        # dead in every script (reference models.py:143-163); kept for import compatibility
-        (mu, log_var) = q_param
+        """log q(z|x) - log p(z) for one sample z (optionally through a normalising flow).  No script calls it
+        (reference models.py:143-163 is equally unreachable); kept so the attribute exists."""
+        log_q = log_gaussian(z, *q_param)
         if self.flow is not None:
-            f_z, log_det_z = self.flow(z)
-            qz = log_gaussian(z, mu, log_var) - sum(log_det_z)
-            z = f_z
-        else:
-            qz = log_gaussian(z, mu, log_var)
-        if p_param is None:
-            pz = log_standard_gaussian(z)
-        else:
-            (mu, log_var) = p_param
-            pz = log_gaussian(z, mu, log_var)
-        return qz - pz
+            z, log_dets = self.flow(z)
+            log_q = log_q - sum(log_dets)
+        log_p = log_standard_gaussian(z) if p_param is None else log_gaussian(z, *p_param)
+        return log_q - log_p
 
     def _kld_v2(self, z, q_param):
         # per-frame KL without the "+1" (quirk Q2); side-effect value only, plain tensor ops

@@ -22,19 +22,22 @@ def enumerate_discrete(x, y_dim):
 
 
 def onehot(k):
-    """label -> one-hot vector of length k (all zeros when label >= k) (reference :30-42)."""
+    """-> function(label) = the length-k indicator vector of `label` (all zeros for label >= k; negative labels count from the end,
+    like the index assignment of reference :30-42)."""
+    slots = torch.arange(k)
+
     def encode(label):
-        y = torch.zeros(k)
-        if label < k:
-            y[label] = 1
-        return y
+        label = int(label)
+        if label < -k:
+            raise IndexError(f"index {label} is out of bounds for dimension 0 with size {k}")
+        return (slots == (label if label >= 0 else label + k)).to(torch.get_default_dtype())
     return encode
 
 
 def log_sum_exp(tensor, dim=-1, sum_op=torch.sum):
-    """max-shifted log(sum_op(exp(.)) + 1e-8) (reference :44-53)."""
-    max, _ = torch.max(tensor, dim=dim, keepdim=True)
-    return torch.log(sum_op(torch.exp(tensor - max), dim=dim, keepdim=True) + 1e-8) + max
+    """log(sum_op(exp(tensor)) + 1e-8 * exp(peak)) evaluated around the peak of `tensor` along `dim` (reference :44-53)."""
+    peak = tensor.amax(dim=dim, keepdim=True)
+    return peak + (sum_op((tensor - peak).exp(), dim=dim, keepdim=True) + 1e-8).log()
 
 
 def _on_gpu(*ts):
@@ -118,17 +121,19 @@ def magnitude_spectrum_approxiamation_loss(x, s, y_hat):
 
 
 def f1_loss(y_hat_hard: torch.Tensor, y: torch.Tensor, epsilon=1e-8) -> torch.Tensor:
-    """-> (accuracy, precision, recall, f1) from hard 0/1 predictions (reference :120-159)."""
-    y_pred = y_hat_hard.detach()
-    y_true = y.detach()
-    assert y_true.ndim == 1
-    assert y_pred.ndim == 1 or y_pred.ndim == 2
-    if y_pred.ndim == 2:
-        y_pred = y_pred.argmax(dim=1)
-    tp = (y_true * y_pred).sum().to(torch.float32)
-    tn = ((1 - y_true) * (1 - y_pred)).sum().to(torch.float32)
-    fp = ((1 - y_true) * y_pred).sum().to(torch.float32)
-    fn = (y_true * (1 - y_pred)).sum().to(torch.float32)
+    """-> (accuracy, precision, recall, f1) of hard 0/1 predictions against 0/1 truth (reference :120-159).  [N, C] predictions
+    are reduced to their argmax class first.  The confusion counts come from three sums (hits, predicted positives, true positives)."""
+    pred, truth = y_hat_hard.detach(), y.detach()
+    if truth.ndim != 1 or pred.ndim not in (1, 2):
+        raise AssertionError("f1_loss: y must be 1-D and y_hat_hard 1-D or 2-D")
+    if pred.ndim == 2:
+        pred = pred.argmax(dim=1)
+    n = truth.numel()
+    hits, n_pred, n_true = (truth * pred).sum(), pred.sum(), truth.sum()
+    tp = hits.to(torch.float32)
+    fp = (n_pred - hits).to(torch.float32)
+    fn = (n_true - hits).to(torch.float32)
+    tn = (n - n_pred - n_true + hits).to(torch.float32)
     accuracy = (tp + tn) / (tp + tn + fp + fn + epsilon)
     precision = tp / (tp + fp + epsilon)
     recall = tp / (tp + fn + epsilon)

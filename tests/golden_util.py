@@ -81,21 +81,11 @@ def make_params(model, dims, seed, wscale=1.0):
     return p
 
 
-def make_batch(dims, B, seed):
-    """Synthetic frames per SURVEY.md 8d: heavy-tailed positive power spectra,
-    Bernoulli labels, N(0,1) reparametrisation noise."""
-    rng = np.random.default_rng(seed)
-    xd, yd, zd = dims["x_dim"], dims["y_dim"], dims["z_dim"]
-    n1, n2, n3 = (rng.standard_normal((B, xd)) for _ in range(3))
-    x = np.exp(4 * n1 - 8) * (n2 ** 2 + n3 ** 2) / 2
-    x = np.clip(x, 1e-12, 1e4).astype(np.float32)
-    if yd == 0:
-        y = None
-    else:
-        prob = 0.6 if yd == 1 else 0.3
-        y = (rng.random((B, yd)) < prob).astype(np.float32)
-    eps = rng.standard_normal((B, zd)).astype(np.float32)
-    return x, y, eps
+import importlib as _importlib
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+make_batch = _importlib.import_module("disentangled-vae_amd.synth").make_batch    # the benchmark's generator: one definition
 
 
 def checksum(arrs):

@@ -15,35 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF + "/scripts"), reason="reference scripts not present (GPU box)")
 
 
-class _FakeH5Dataset:
-    def __init__(self, arr):
-        self.arr = arr
-        self.shape = arr.shape
-
-    def __getitem__(self, idx):
-        return self.arr[idx]
-
-
-class _FakeH5File:
-    data = {}
-
-    def __init__(self, path, mode="r", **kw):
-        self.path = path
-
-    def __getitem__(self, k):
-        return _FakeH5Dataset(_FakeH5File.data[k])
-
-    def __contains__(self, k):
-        return k in _FakeH5File.data
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-    def close(self):
-        pass
+import fake_h5
 
 
 class _Done(Exception):
@@ -53,13 +25,12 @@ class _Done(Exception):
 def _run(script, y_dim, tmp_path, monkeypatch):
     rng = np.random.default_rng(0)
     n = 64
-    _FakeH5File.data = {}
+    arrays = {}
     for split in ("train", "validation"):
-        _FakeH5File.data["X_" + split] = (rng.random((513, n)) ** 2).astype(np.float32)
-        _FakeH5File.data["Y_" + split] = (rng.random((y_dim, n)) < 0.5).astype(np.float32)
-    fake_h5 = types.ModuleType("h5py")
-    fake_h5.File = _FakeH5File
-    for name, mod in (("h5py", fake_h5), ("torchaudio", types.ModuleType("torchaudio")), ("librosa", types.ModuleType("librosa"))):
+        arrays["X_" + split] = (rng.random((513, n)) ** 2).astype(np.float32)
+        arrays["Y_" + split] = (rng.random((y_dim, n)) < 0.5).astype(np.float32)
+    fake_h5.install(monkeypatch, arrays)
+    for name, mod in (("torchaudio", types.ModuleType("torchaudio")), ("librosa", types.ModuleType("librosa"))):
         monkeypatch.setitem(sys.modules, name, mod)
     # the script does sys.path.append('.') and imports packages.* : cwd must hold THIS repo's packages
     os.symlink(os.path.join(ROOT, "packages"), tmp_path / "packages")

@@ -146,7 +146,7 @@ def test_state_dict_round_trip_and_repack():
         trainer.Trainer("M2", dict(x_dim=513, y_dim=7, z_dim=16, h_dim=(128, 128)), None, batch=8)
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32"):
     import os, sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
@@ -156,10 +156,10 @@ def _dp_worker(rank, world, port, q):
     dp = importlib.import_module("disentangled-vae_amd.dp")
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     Bg = 512
     lo, hi = dp.shard_rows(Bg, rank, world)
-    tr = tr_mod.Trainer("M2", dims, gu.make_params("M2", dims, 21), batch=hi - lo, precision="fp32",
+    tr = tr_mod.Trainer(model, dims, gu.make_params(model, dims, 21), batch=hi - lo, precision=precision,
                         process_group=dist.group.WORLD, world=world)
     for step in range(2):
         x, y, e = gu.make_batch(dims, Bg, 30 + step)
@@ -169,31 +169,37 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equals_single_process():
-    """2 ranks (sharing the one GPU, gloo in place of RCCL) == 1 rank on the concatenated batch."""
+@pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "fp32"), ("M2", 513, "bf16x3"), ("M2_info", 1, "fp32")])
+def test_two_rank_data_parallel_equals_single_process(model, y_dim, precision):
+    """2 ranks (sharing the one GPU, gloo in place of RCCL) == 1 rank on the concatenated batch; M2_info: both Adam
+    groups travel in the one flat buffer."""
     import torch.multiprocessing as mp
     import os
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() + 7 * len(model) + y_dim + len(precision)) % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, model, y_dim, precision)) for r in range(2)]
     for pr in procs:
         pr.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
-    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
-    tr = trainer.Trainer("M2", dims, gu.make_params("M2", dims, 21), batch=512, precision="fp32")
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    tr = trainer.Trainer(model, dims, gu.make_params(model, dims, 21), batch=512, precision=precision)
     for step in range(2):
         x, y, e = gu.make_batch(dims, 512, 30 + step)
         t = lambda a: torch.from_numpy(a).cuda()
         losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
     ref = tr.state_dict_numpy()
+    # the two halves sum their gradients in a different order than one 512-frame pass; Adam's first steps are sign-like, so a
+    # gradient that is rounding noise moves its parameter by up to 2 lr either way: bound the bulk tightly, every element by 2 steps
     for k in ref:
         assert np.array_equal(res[0][1][k], res[1][1][k]), k                      # replicas identical
-        assert np.max(np.abs(res[0][1][k] - ref[k])) <= 2e-6, k                   # == single process (fp32 sum order)
-    np.testing.assert_allclose(0.5 * (res[0][2] + res[1][2]), losses, rtol=1e-5)
+        d = np.abs(res[0][1][k] - ref[k])
+        assert d.max() <= (2e-6 if (model, precision) == ("M2", "fp32") else 4.1e-4), (k, d.max())
+        assert np.mean(d > 2e-6) < (0.0 if (model, precision) == ("M2", "fp32") else 0.02) + 1e-12, (k, float(np.mean(d > 2e-6)))
+    np.testing.assert_allclose(0.5 * (res[0][2] + res[1][2]), losses, rtol=1e-5, atol=1e-6)
 
 
 class FusedInfoImpl(FusedImpl):
