@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256, 1) void vae_rows_kernel(const RowsArgs g) {
         if (g.rows != nullptr) {
             __syncthreads();                                 // previous tile's readers are done with rowsrc
             if (tid < TB) {
-                int64_t br = b0 + tid; br = br < g.B ? br : g.B - 1;
+                const int64_t bf = b0 + tid;
+                const int64_t br = bf < g.B ? bf : g.B - 1;
                 int64_t rr = g.rows[br];
-                if (rr < 0 || rr >= g.n_rows) { rr = 0; if (g.bad_rows) atomicAdd(g.bad_rows, 1); }   // never dereference an out-of-range index
+                if (rr < 0 || rr >= g.n_rows) { rr = 0; if (g.bad_rows && bf < g.B) atomicAdd(g.bad_rows, 1); }   // never dereference an out-of-range index
                 rowsrc[tid] = rr;
             }
             __syncthreads();

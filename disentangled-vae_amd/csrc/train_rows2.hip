@@ -441,9 +441,10 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         // gather table of tile `tl_` into half `half` (threads 0..31 of the helper group); bad indices are clamped and counted
         auto fill_rows = [&](int tl_, int half) {
             if (ht < TB) {
-                int64_t br = (int64_t)tl_ * TB + ht; br = br < g.B ? br : g.B - 1;
+                const int64_t bf = (int64_t)tl_ * TB + ht;
+                const int64_t br = bf < g.B ? bf : g.B - 1;                 // frames past the batch repeat its last row (masked out later)
                 int64_t r = g.rows[br];
-                if (r < 0 || r >= g.n_rows) { r = 0; if (g.bad_rows) atomicAdd(g.bad_rows, 1); }
+                if (r < 0 || r >= g.n_rows) { r = 0; if (g.bad_rows && bf < g.B) atomicAdd(g.bad_rows, 1); }
                 rowsrc[half * TB + ht] = r;
             }
         };
