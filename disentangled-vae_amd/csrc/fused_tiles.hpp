@@ -118,7 +118,7 @@ struct PolX3 : PolBF16 {
 #define R2_PRE_X3 2
 #endif
 #ifndef R2_PD_BF
-#define R2_PD_BF 8
+#define R2_PD_BF 10
 #endif
 #ifndef R2_PRE_BF
 #define R2_PRE_BF 4

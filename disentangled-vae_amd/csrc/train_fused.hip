@@ -993,10 +993,10 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     }
     plan->n_params = off;
     const int64_t ntiles = (B + TB - 1) / TB;
-    // rows kernel generation: the 8-wave kernel wins for the split policy (48 vs 55 us per 8192 frames), the 4-wave kernel for plain
-    // bf16 (33 vs 35 us); DVAE_ROWS=1 / 2 forces one where both exist
+    // rows kernel generation: the 8-wave chain + helper kernel wherever it exists (M1 / M2 with bf16 or bf16x3 operands: 48 vs 55 us
+    // per 8192 frames under bf16x3, 31 vs 33 us under bf16); DVAE_ROWS=1 forces the 4-wave kernel
     const char* rk = getenv("DVAE_ROWS");
-    int want = precision == DVAE_PREC_BF16X3 ? 2 : 1;
+    int want = 2;
     if (rk && (atoi(rk) == 1 || atoi(rk) == 2)) want = atoi(rk);
     plan->rows_kernel = (want == 2 && rows2_supported(precision, model)) ? 2 : 1;
     // workgroups resident at once: the 8-wave kernel holds one per CU; the 4-wave bf16 kernel two.  Beyond that: persistent tile loop

@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include "fused_tiles.hpp"
 #include "rows_common.hpp"
+#include "wstream.hpp"
 #include "../../include/dvae_train.h"
 
 namespace dvae {
@@ -64,62 +65,12 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 #define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
-// Output layer for tiles t0, t0 + 4, ... of one chain wave (sharing the 16 tiles with the helper waves was tried: the
-// larger helper spilled and the phase did not get shorter -- it is not bound by per-wave work):
-// a = W5 d2 + b5 on a 32-feature tile, Itakura-Saito terms against x read straight from global memory, da -> U.
-// `wnext` (chain waves): weight fragments to request after the last tile's GEMM (the backward product's first k-steps).
-template <typename P, typename WNext>
-__device__ __forceinline__ void out_tiles(const RowsArgs& g, __amdgpu_buffer_rsrc_t wrs, WRef W5s, int t0, const typename P::T* Hbr, typename P::T* U,
-                                          const float* Bias5, const float* xrow, float invB_l, int l31, int h, float& rec_lane, WNext wnext) {
-    typedef typename P::T T;
-    constexpr int E = P::E, KS = P::KSTEP, LDU = Ld<T>::u;
-    constexpr unsigned SZ = sizeof(T), FB = 64 * E, S17 = NT_OUT * FB * SZ, TSTEP = FB * SZ;
-    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
-    auto xload = [&](int t, f32x4 (&q)[4]) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            if (g.ablate & 8) q[gq] = f32x4{1.f, 2.f, 3.f, 4.f};
-            else q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
-        }
-    };
-    f32x4 xq[4], xn[4];
-    WPre<P, HD / KS, P::PRE> w5;
-    wprefetch<P, HD / KS>(w5, wrs, woff(W5s, (unsigned)t0 * TSTEP), S17);
-    xload(t0, xq);
-    f32x16 acc;
-#pragma unroll 1
-    for (int t = t0; t < NT_OUT - 1; t += 4) {
-        zero_acc<P>(acc);
-        const WRef wr = woff(W5s, (unsigned)t * TSTEP);
-        const bool more = t + 4 < NT_OUT - 1;
-        if (more) xload(t + 4, xn);
-        if (!(g.ablate & 128)) gemm_block<P, HD / KS, NoHook, P::PRE, P::PD>(acc, w5, wrs, wr, Hbr, S17);
-        if (more) wprefetch<P, HD / KS>(w5, wrs, woff(wr, 4 * TSTEP), S17);
-        else wnext();
-        float da[16], b5v[16];
-        bias16(Bias5, 32 * t, h, b5v);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float xs = xq[r >> 2][r & 3];
-            const float a = acc[r] + b5v[r];
-            const float xe = (g.ablate & 16) ? xs * a : xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
-            rec_lane += xe - ((g.ablate & 16) ? xs : P::log_(xs + g.elbo_eps)) + a - 1.f;   // utils.py:74 (log r = a)
-            da[r] = (1.f - xe) * invB_l;                         // d recon / d a
-        }
-        if (!(g.ablate & 32)) put_lds<P>(da, U, LDU, 32 * t, l31, h);
-        if (g.ablate & 64) continue;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) xq[gq] = xn[gq];
-    }
-}
-
 template <typename P, int YP, bool YENC>
 __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
     constexpr int LDU = Ld<T>::u, LDH = Ld<T>::hh, LDZ = Ld<T>::z;
-    constexpr int LD1 = XP + (YENC ? YP : 0), LD3 = ZD + YP;
     constexpr bool Y513 = (YP == XP);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const U = reinterpret_cast<T*>(smem);
@@ -146,24 +97,33 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     if (wave_u < 4) {
         // =========================================================== chain waves ===========================================================
         const int cw = wave_u, fb = 32 * cw;
-        constexpr int FB = 64 * E;
-        constexpr unsigned SZ = sizeof(T);
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
-        auto wbase = [&](const void* Wp, int tile) -> WRef {
-            const unsigned m = (unsigned)((const char*)Wp - (const char*)g.wcopy);
-            return WRef{lane * 16, m + (unsigned)tile * (FB * SZ), g.wpl_bytes};
-        };
-        auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
-        constexpr unsigned S4 = 4 * FB * SZ, S1 = FB * SZ;
-        constexpr unsigned KB1 = (XP / KS) * 4 * FB * SZ, KB3 = (ZD / KS) * 4 * FB * SZ;
-        (void)LD1; (void)LD3;
-        const WRef W1r = wbase(g.W1s, cw), W2r = wbase(g.W2s, cw), Wmvr = wbase(g.Wmvs, 0), W3r = wbase(g.W3s, cw), W4r = wbase(g.W4s, cw);
-        const WRef W5s = wbase(g.W5s, 0), W5tr = wbase(g.W5t, cw), W4tr = wbase(g.W4t, cw), W3ztr = wbase(g.W3zt, 0);
-        const WRef Wmvtr = wbase(g.Wmvt, cw), W2tr = wbase(g.W2t, cw);
+        constexpr int D = P::PD;
+        typedef Sched<P, YP, YENC, D> SC;
+        typedef WStream<P, SC, D> WS;
+        constexpr unsigned FBB = SC::FBB;
+        WS ws;
+        ws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
+        ws.voff = lane * 16;
+        ws.pl = g.wpl_bytes;
+        {
+            auto mo = [&](const void* Wp) { return (unsigned)((const char*)Wp - (const char*)g.wcopy); };
+            const unsigned tw = (unsigned)cw * FBB;                          // this wave's row tile in the 4-tile matrices
+            constexpr unsigned KB1 = (XP / KS) * 4 * FBB, KB3 = (ZD / KS) * 4 * FBB;   // label k-blocks behind the x / z blocks of W1 / W3
+            ws.sb[G_W1X] = mo(g.W1s) + tw;  ws.sb[G_W1Y] = mo(g.W1s) + tw + KB1;
+            ws.sb[G_W2] = mo(g.W2s) + tw;   ws.sb[G_WMV] = mo(g.Wmvs);
+            ws.sb[G_W3Y] = mo(g.W3s) + tw + KB3;  ws.sb[G_W3Z] = mo(g.W3s) + tw;
+            ws.sb[G_W4] = mo(g.W4s) + tw;
+            ws.sb[G_W5A] = mo(g.W5s) + (unsigned)cw * FBB;        ws.sb[G_W5B] = mo(g.W5s) + (unsigned)(cw + 4) * FBB;
+            ws.sb[G_W5C] = mo(g.W5s) + (unsigned)(cw + 8) * FBB;  ws.sb[G_W5D] = mo(g.W5s) + (unsigned)(cw + 12) * FBB;
+            ws.sb[G_W5T] = mo(g.W5t) + tw;  ws.sb[G_W4T] = mo(g.W4t) + tw;  ws.sb[G_W3ZT] = mo(g.W3zt);
+            ws.sb[G_WMVT] = mo(g.Wmvt) + tw;  ws.sb[G_W2T] = mo(g.W2t) + tw;  ws.sb[G_PAD] = mo(g.W1s);
+        }
+        ws.fill();                                                         // the first D k-steps of the stream, in flight under the x tile load
         const T* const Ur = U + l31 * LDU + h * E;
         const T* const Har = Ha + l31 * LDH + h * E;
         const T* const Hbr = Hb + l31 * LDH + h * E;
         const T* const Zbr = Zb + l31 * LDZ + h * E;
+        const bool w0 = cw == 0;
         double tot_rec = 0.0, tot_kl = 0.0;
 
         for (int it = 0; it < ntl; ++it) {
@@ -176,7 +136,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 30] = clock64();
             // reparametrisation noise of this lane's frame (wave 0 owns the latent tile)
             float ep_r[8];
-            if (cw == 0) {
+            if (w0) {
                 int64_t br = b0 + l31; br = br < g.B ? br : g.B - 1;
                 if (g.eps != nullptr) {
                     const f32x4 e0 = *reinterpret_cast<const f32x4*>(g.eps + br * ZD + 4 * h);
@@ -189,8 +149,6 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     for (int jq = 0; jq < 8; ++jq) ep_r[jq] = live ? ep_r[jq] : 0.f;
                 }
             }
-            WPre<P, XP / KS, P::PREBIG> w1x;
-            wprefetch<P, XP / KS>(w1x, wrs, W1r, S4);
             if (it == 0) {
                 if (gather) wg_barrier();                               // BROW
                 wg_barrier();                                           // BX
@@ -199,19 +157,15 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             // ---------------- encoder layer 1: [x | y] -> h1 ----------------
             f32x16 acc;
             zero_acc<P>(acc);
-            gemm_block<P, XP / KS, NoHook, P::PREBIG, P::DBIG>(acc, w1x, wrs, W1r, Ur, S4);
+            gemm_seg<P, SC, D, G_W1X>(acc, ws, Ur);
             R2_STAMP(2);
-            WPre<P, HD / KS, P::PRE128> w2;
             bool ylo = false;
             if (YP > 0) {
-                WPre<P, (YENC ? YP : KS) / KS, P::PREBIG> w1y;
-                if (YENC) wprefetch<P, (YENC ? YP : KS) / KS>(w1y, wrs, woff(W1r, KB1), S4);
                 wg_barrier();                                           // BL1X: the x image of U has been consumed
                 wg_barrier();                                           // BY: the y image is in U (it stays there until the loss epilogue writes da)
                 ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
-                if (YENC) gemm_block<P, (YENC ? YP : KS) / KS, NoHook, P::PREBIG, P::DBIG>(acc, w1y, wrs, woff(W1r, KB1), Ur, S4, NoHook(), ylo);
+                gemm_seg<P, SC, D, G_W1Y>(acc, ws, Ur, ylo);
             }
-            wprefetch<P, HD / KS>(w2, wrs, W2r, S4);
             float hv[16], bv[16];
             R2_STAMP(3);
             bias16(Bias + OB1, fb, h, bv);
@@ -222,11 +176,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(4);
             // ---------------- encoder layer 2 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w2, wrs, W2r, Har, S4);
-            WPre<P, HD / KS, P::PRE128> wmv;
-            WPre<P, (YP > 0 ? YP : KS) / KS, P::PREBIG> w3y;
-            if (cw == 0) wprefetch<P, HD / KS>(wmv, wrs, Wmvr, S1);
-            else if (YP > 0) wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
+            gemm_seg<P, SC, D, G_W2>(acc, ws, Har);
             bias16(Bias + OB2, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { hv[r] = P::tanh_(acc[r] + bv[r]); keep[(16 + r) * 256 + tid] = hv[r]; }
@@ -234,11 +184,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             wg_barrier();                                               // BH2
             R2_STAMP(5);
             // ---------------- heads + reparametrisation (wave 0): rows 0-15 mu, 16-31 log_var ----------------
-            f32x16 accy;
-            if (cw == 0) {
-                zero_acc<P>(acc);
-                gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, wmv, wrs, Wmvr, Hbr, S1);
-                if (YP > 0) wprefetch<P, (YP > 0 ? YP : KS) / KS>(w3y, wrs, woff(W3r, KB3), S4);
+            zero_acc<P>(acc);
+            gemm_seg<P, SC, D, G_WMV>(acc, ws, Hbr, true, w0);
+            if (w0) {
                 float zv[16];
                 bias16(Bias + OBMV, 0, h, bv);
 #pragma unroll
@@ -252,19 +200,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 put_lds<P>(zv, Zb, LDZ, 0, l31, h);
             }
             // label block of decoder layer 1: independent of z (three of the four waves have nothing else to do in this phase)
+            f32x16 accy;
             if (YP > 0) {
                 zero_acc<P>(accy);
-                gemm_block<P, (YP > 0 ? YP : KS) / KS, NoHook, P::PREBIG, P::DBIG>(accy, w3y, wrs, woff(W3r, KB3), Ur, S4, NoHook(), ylo);
+                gemm_seg<P, SC, D, G_W3Y>(accy, ws, Ur, ylo);
             }
-            WPre<P, ZD / KS> w3z;
-            wprefetch<P, ZD / KS>(w3z, wrs, W3r, S4);
             wg_barrier();                                               // BZ
             R2_STAMP(6);
             // ---------------- decoder layer 1: [z | y] -> d1 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, ZD / KS>(acc, w3z, wrs, W3r, Zbr, S4);
-            WPre<P, HD / KS, P::PRE128> w4;
-            wprefetch<P, HD / KS>(w4, wrs, W4r, S4);
+            gemm_seg<P, SC, D, G_W3Z>(acc, ws, Zbr);
             bias16(Bias + OB3, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + (YP > 0 ? accy[r] : 0.f) + bv[r]);
@@ -273,13 +218,23 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(7);
             // ---------------- decoder layer 2 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w4, wrs, W4r, Har, S4);
+            gemm_seg<P, SC, D, G_W4>(acc, ws, Har);
             // loss epilogue input: x[frame][32 t + 8 gq + 4 h .. + 3] of this lane's frame straight from global memory
-            // (the tile was read a few microseconds ago: L2 / MALL)
+            // (the tile was read a few microseconds ago: L2 / MALL), one output tile ahead
             int64_t rowx;
             if (gather) rowx = rsrc[l31];
             else { rowx = b0 + l31; rowx = rowx < g.B ? rowx : g.B - 1; }
             const float* const xrow = g.x + rowx * g.ldx + 4 * h;
+            f32x4 xq[4], xn[4];
+            auto xload = [&](int t, f32x4 (&q)[4]) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    if (g.ablate & 8) q[gq] = f32x4{1.f, 2.f, 3.f, 4.f};
+                    else q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
+                }
+            };
+            xload(cw, xq);
+            const float xv512 = cw == 3 ? g.x[rowx * g.ldx + XD - 1] : 0.f;      // bin 512 (wave 3's dot-product tile), requested a phase early
             bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + bv[r]);
@@ -287,11 +242,29 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             wg_barrier();                                               // BD2
             R2_STAMP(8);
             // ---------------- output layer a = W5 d2 + b5, Itakura-Saito terms, da -> U ----------------
-            WPre<P, NO / KS, P::PRE> w5t;
             const float invB_l = live ? g.invB : 0.f;                      // frames past B contribute nothing
-            // 16 full tiles, 4 per chain wave; the 17th tile holds ONE real feature (bin 512): chain wave 3 does it as a 128-term dot product
-            out_tiles<P>(g, wrs, W5s, cw, Hbr, U, Bias + OB5, xrow, invB_l, l31, h, rec_lane,
-                         [&]() { wprefetch<P, NO / KS>(w5t, wrs, W5tr, S4); });
+            // 16 full tiles, 4 per chain wave (tile cw + 4 i = stream segment G_W5A + i); the 17th tile holds ONE real
+            // feature (bin 512): chain wave 3 does it as a 128-term dot product
+            static_for<0, 4>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                const int t = cw + 4 * I;
+                zero_acc<P>(acc);
+                if constexpr (I < 3) xload(t + 4, xn);
+                gemm_seg<P, SC, D, G_W5A + I>(acc, ws, Hbr);
+                float da[16], b5v[16];
+                bias16(Bias + OB5, 32 * t, h, b5v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float xs = xq[r >> 2][r & 3];
+                    const float a = acc[r] + b5v[r];
+                    const float xe = xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
+                    rec_lane += xe - P::log_(xs + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
+                    da[r] = (1.f - xe) * invB_l;                         // d recon / d a
+                }
+                put_lds<P>(da, U, LDU, 32 * t, l31, h);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) xq[gq] = xn[gq];
+            });
             if (cw == 3) {
                 const float* wl = Bias + OB5 + NO + 64 * h;                 // this half's 64 weights (LDS broadcast reads)
                 const T* drow = Hb + l31 * LDH + 64 * h;
@@ -313,7 +286,6 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 }
                 s += __shfl_xor(s, 32, 64);
                 const float a = s + Bias[OB5 + XD - 1];
-                const float xv512 = g.x[rowx * g.ldx + XD - 1];
                 const float xe = xv512 * P::exp_(-a);
                 if (h == 0) rec_lane += xe - P::log_(xv512 + g.elbo_eps) + a - 1.f;
                 const float da512 = (1.f - xe) * invB_l;
@@ -339,9 +311,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(9);
             // ---------------- backward: d2 <- da ----------------
             zero_acc<P>(acc);
-            gemm_block<P, NO / KS, NoHook, P::PRE, P::DBIG>(acc, w5t, wrs, W5tr, Ur, S4);
-            WPre<P, HD / KS, P::PRE128> w4t;
-            wprefetch<P, HD / KS>(w4t, wrs, W4tr, S4);
+            gemm_seg<P, SC, D, G_W5T>(acc, ws, Ur);
             float dv[16];
             get_lds<P>(hv, Hb, LDH, fb, l31, h);                          // d2 of this lane's elements (every reader of Hb has passed BDA)
 #pragma unroll
@@ -351,11 +321,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(10);
             // ---------------- backward: d1 <- dpre_d2 ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w4t, wrs, W4tr, Hbr, S4);
-            WPre<P, HD / KS, P::PRE128> w3zt;
-            WPre<P, 32 / KS> wmvt;
-            if (cw == 0) wprefetch<P, HD / KS>(w3zt, wrs, W3ztr, S1);
-            wprefetch<P, 32 / KS>(wmvt, wrs, Wmvtr, S4);
+            gemm_seg<P, SC, D, G_W4T>(acc, ws, Hbr);
             get_lds<P>(hv, Ha, LDH, fb, l31, h);                          // d1: Ha has not been written since decoder layer 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) dv[r] = acc[r] * (1.f - hv[r] * hv[r]);
@@ -363,9 +329,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             wg_barrier();                                               // BDD1
             R2_STAMP(11);
             // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
-            if (cw == 0) {
-                zero_acc<P>(acc);
-                gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w3zt, wrs, W3ztr, Har, S1);
+            zero_acc<P>(acc);
+            gemm_seg<P, SC, D, G_W3ZT>(acc, ws, Har, true, w0);
+            if (w0) {
                 float dml[16];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -379,9 +345,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(12);
             // ---------------- backward: h2 <- [dmu | dlogvar] ----------------
             zero_acc<P>(acc);
-            gemm_block<P, 32 / KS>(acc, wmvt, wrs, Wmvtr, Zbr, S4);
-            WPre<P, HD / KS, P::PRE128> w2t;
-            wprefetch<P, HD / KS>(w2t, wrs, W2tr, S4);
+            gemm_seg<P, SC, D, G_WMVT>(acc, ws, Zbr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float hk = keep[(16 + r) * 256 + tid]; dv[r] = acc[r] * (1.f - hk * hk); }
             put_lds<P>(dv, Hb, LDH, fb, l31, h);
@@ -389,7 +353,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(13);
             // ---------------- backward: h1 <- dpre_h2 (inputs are data: stop here) ----------------
             zero_acc<P>(acc);
-            gemm_block<P, HD / KS, NoHook, P::PRE128, P::D128>(acc, w2t, wrs, W2tr, Hbr, S4);
+            gemm_seg<P, SC, D, G_W2T>(acc, ws, Hbr);
+            // the padding positions of the schedule (none for most shapes) keep the ring phase tile-invariant
+            { f32x16 dummy; zero_acc<P>(dummy); gemm_seg<P, SC, D, G_PAD>(dummy, ws, Hbr, true, false); }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float hk = keep[r * 256 + tid]; dv[r] = acc[r] * (1.f - hk * hk); }
             put_lds<P>(dv, Ha, LDH, fb, l31, h);
