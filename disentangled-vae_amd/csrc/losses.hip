@@ -80,12 +80,20 @@ __global__ __launch_bounds__(256) void elbo_final_kernel(const double* __restric
     }
 }
 
+// upstream scalars: either g2 = {d/d recon, d/d KL} (ga = gb = null), or the three gradients of the outputs (loss, recon, KL)
+// of elbo(), each a device scalar or null (= 0): d/d recon = g_loss + g_recon, d/d KL = g_loss + g_kl
 __global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r, int ldr,
                                                         const float* __restrict__ mu, const float* __restrict__ lv,
-                                                        const float* __restrict__ g2, int64_t B, int F, int Z,
+                                                        const float* __restrict__ g2, const float* __restrict__ ga, const float* __restrict__ gb,
+                                                        int three, int64_t B, int F, int Z,
                                                         float* __restrict__ dr, int lddr, float* __restrict__ dmu, float* __restrict__ dlv) {
     const float invB = 1.f / (float)B;
-    const float gr = g2[0] * invB, gk = g2[1] * invB;
+    float s_r, s_k;
+    if (three) {
+        const float gl = g2 ? g2[0] : 0.f;
+        s_r = gl + (ga ? ga[0] : 0.f); s_k = gl + (gb ? gb[0] : 0.f);
+    } else { s_r = g2[0]; s_k = g2[1]; }
+    const float gr = s_r * invB, gk = s_k * invB;
     const int64_t total = B * (int64_t)F, nz = B * (int64_t)Z;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / F;
@@ -210,8 +218,19 @@ extern "C" int dvae_elbo_bwd(const float* x, int ldx, const float* r, int ldr, c
     DVAE_CHECK_ARG(x && r && mu && logvar && g2 && B > 0 && F > 0 && Z > 0 && ldx >= F && ldr >= F && (!dr || lddr >= F), "elbo_bwd: bad argument");
     DVAE_CHECK_ARG(Z <= F, "elbo_bwd: latent dim larger than feature dim");
     hipLaunchKernelGGL(elbo_bwd_kernel, dim3(ew_blocks(B * (int64_t)F)), dim3(256), 0, (hipStream_t)stream,
-                       x, ldx, r, ldr, mu, logvar, g2, B, F, Z, dr, lddr, dmu, dlogvar);
+                       x, ldx, r, ldr, mu, logvar, g2, (const float*)nullptr, (const float*)nullptr, 0, B, F, Z, dr, lddr, dmu, dlogvar);
     DVAE_LAUNCH_OK("elbo_bwd");
+    return 0;
+}
+
+extern "C" int dvae_elbo_bwd3(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar,
+                              const float* g_loss, const float* g_recon, const float* g_kl, int64_t B, int F, int Z,
+                              float* dr, int lddr, float* dmu, float* dlogvar, void* stream) {
+    DVAE_CHECK_ARG(x && r && mu && logvar && B > 0 && F > 0 && Z > 0 && ldx >= F && ldr >= F && (!dr || lddr >= F), "elbo_bwd3: bad argument");
+    DVAE_CHECK_ARG(Z <= F, "elbo_bwd3: latent dim larger than feature dim");
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(ew_blocks(B * (int64_t)F)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, r, ldr, mu, logvar, g_loss, g_recon, g_kl, 1, B, F, Z, dr, lddr, dmu, dlogvar);
+    DVAE_LAUNCH_OK("elbo_bwd3");
     return 0;
 }
 

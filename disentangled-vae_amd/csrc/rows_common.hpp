@@ -59,6 +59,15 @@ struct RowsArgs {
     const float *bc1, *bc2, *wc3, *bc3, *ba1, *ba2, *wa3, *ba3;
     void *c1T, *c2T, *dc1T, *dc2T, *dc3T, *a1T, *a2T, *da1T, *da2T, *da3T;
     float alpha, beta, gamma;
+    // Whole-model autograd path of the drop-in modules (packages/models/models.py -> disentangled-vae_amd/module_path.py):
+    //   mode 0: fused train step (loss + backward on chip);
+    //   mode 1: forward only -- r = exp(a) [B, 513], mu / log_var / z [B, 16] are written out, nothing is stashed;
+    //   mode 2: backward from upstream gradients -- the forward is recomputed, d a = g_r * r, d mu += g_mu, d log_var += g_lv,
+    //           d z += g_z (any of them may be null = zero); the stash feeds the weight-gradient kernel as in mode 0.
+    int mode;
+    float *out_r, *out_mu, *out_lv, *out_z;
+    const float *g_r, *g_mu, *g_lv, *g_z;
+    int ld_r, ld_gr;
     double* partials;
     unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production

@@ -752,6 +752,15 @@ __global__ __launch_bounds__(256, DVAE_WGRAD_OCC) void wgrad_kernel(const GroupD
     else wgrad_body<P, false, false>(d, kbeg, kend, Bp, spl, slab, l31, h);
 }
 
+// dst = (accumulate ? dst : 0) + sum of the slabs (fixed order: deterministic)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride, float* __restrict__ dst, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = slabs[i];
+        for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
+        dst[i] = accumulate ? dst[i] + s : s;
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float s = slabs[i];
@@ -945,6 +954,14 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
 
 static bool g_prof = false;
 static thread_local bool g_eval_only = false;
+// dvae_module_forward / dvae_module_backward: rows-kernel mode and its extra operands for the next dvae_train_grads call
+struct ModeArgs {
+    int mode = 0;
+    float *out_r = nullptr, *out_mu = nullptr, *out_lv = nullptr, *out_z = nullptr;
+    const float *g_r = nullptr, *g_mu = nullptr, *g_lv = nullptr, *g_z = nullptr;
+    int ld_r = 0, ld_gr = 0;
+};
+static thread_local ModeArgs g_mode;
 static thread_local long long g_rng_step_override = -1;   // dvae_train_step: its `step` argument numbers the noise draw   // dvae_train_eval: skip the wgrad launch
 static unsigned long long* g_dbg = nullptr;   // set by dvae_train_debug_stamps
 static double g_ms[4] = {0, 0, 0, 0};
@@ -1029,6 +1046,7 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     return 0;
 }
 
+static int used_slabs(const dvae_train_plan_t* plan);
 static int64_t kper_of(const dvae_train_plan_t* p) {
     const int ks = is_bf(p->precision) ? 16 : 8;
     const int64_t unit = 4 * ks;
@@ -1254,6 +1272,10 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.spl = L.stash_rows * plan->Bp; a.wpl_bytes = (unsigned)(L.wcopy_elems * esz);
     a.dbg = g_dbg;
     { const char* ab = getenv("DVAE_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    a.mode = g_mode.mode;
+    a.out_r = g_mode.out_r; a.out_mu = g_mode.out_mu; a.out_lv = g_mode.out_lv; a.out_z = g_mode.out_z; a.ld_r = g_mode.ld_r;
+    a.g_r = g_mode.g_r; a.g_mu = g_mode.g_mu; a.g_lv = g_mode.g_lv; a.g_z = g_mode.g_z; a.ld_gr = g_mode.ld_gr;
+    DVAE_CHECK_ARG(a.mode == 0 || plan->rows_kernel == 2, "rows-kernel modes 1 / 2 exist in the 8-wave kernel only (plan->rows_kernel == 2)");
     char* st = w + L.o_stash;
     auto ST = [&](int64_t row) { return (void*)(st + row * plan->Bp * esz); };
     a.xT = ST(L.xT); a.yT = ST(L.yT); a.h1T = ST(L.h1T); a.h2T = ST(L.h2T); a.dh1T = ST(L.dh1T); a.dh2T = ST(L.dh2T);
@@ -1287,7 +1309,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         }
     }
     if (rc) return rc;
-    if (g_eval_only) return 0;
+    if (g_eval_only || a.mode == 1) return 0;
     const int64_t kper = kper_of(plan);
     const int ks = (int)((plan->Bp + kper - 1) / kper);
     DVAE_CHECK_ARG(ks <= plan->ksplit, "train_grads: internal k-split mismatch");
@@ -1336,6 +1358,41 @@ extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, flo
     g_rng_step_override = -1;
     if (rc) return rc;
     return dvae_train_apply(plan, params, m, v, ws, 0, step, lr, beta1, beta2, adam_eps, 1.0, losses3, stream);
+}
+
+/* ---- whole-model autograd path of the drop-in modules (packages/models/models.py) ---- */
+extern "C" int dvae_module_forward(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                                   const float* y, int ldy, const float* eps_noise, float* out_r, int ld_r, float* out_mu,
+                                   float* out_lv, float* out_z, int repack, void* stream) {
+    DVAE_CHECK_ARG(plan && params && ws && x && eps_noise && out_r && out_mu && out_lv && ld_r >= XD, "module_forward: bad argument");
+    DVAE_CHECK_ARG(plan->rows_kernel == 2 && plan->row_index == 0, "module_forward: needs the 8-wave rows kernel and no gather table");
+    if (repack) { int rc = dvae_train_repack(plan, params, ws, stream); if (rc) return rc; }
+    g_mode = ModeArgs();
+    g_mode.mode = 1; g_mode.out_r = out_r; g_mode.ld_r = ld_r; g_mode.out_mu = out_mu; g_mode.out_lv = out_lv; g_mode.out_z = out_z;
+    const int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, 0.f, 0, stream);
+    g_mode = ModeArgs();
+    return rc;
+}
+
+extern "C" int dvae_module_backward(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                                    const float* y, int ldy, const float* eps_noise, const float* g_r, int ld_gr,
+                                    const float* g_mu, const float* g_lv, const float* g_z, float* grad_flat, int accumulate,
+                                    void* stream) {
+    DVAE_CHECK_ARG(plan && params && ws && x && eps_noise && grad_flat, "module_backward: bad argument");
+    DVAE_CHECK_ARG(plan->rows_kernel == 2 && plan->row_index == 0, "module_backward: needs the 8-wave rows kernel and no gather table");
+    DVAE_CHECK_ARG(g_r == nullptr || ld_gr >= XD, "module_backward: ld_gr < 513");
+    g_mode = ModeArgs();
+    g_mode.mode = 2; g_mode.g_r = g_r; g_mode.ld_gr = ld_gr; g_mode.g_mu = g_mu; g_mode.g_lv = g_lv; g_mode.g_z = g_z;
+    const int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, 0.f, 0, stream);
+    g_mode = ModeArgs();
+    if (rc) return rc;
+    Layout L;
+    make_layout(*plan, L);
+    const float* slabs = (const float*)((const char*)ws + L.o_grads);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, slabs, plan->n_params, used_slabs(plan), plan->n_params,
+                       grad_flat, accumulate);
+    DVAE_LAUNCH_OK("slab_sum_kernel");
+    return 0;
 }
 
 extern "C" int dvae_train_debug_stamps(void* buf) {

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         const T* const Hbr = Hb + l31 * LDH + h * E;
         const T* const Zbr = Zb + l31 * LDZ + h * E;
         const bool w0 = cw == 0;
+        const int mode = g.mode;
         double tot_rec = 0.0, tot_kl = 0.0;
 
         for (int it = 0; it < ntl; ++it) {
@@ -198,6 +199,15 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if (live) kl_lane += lv - mu * mu - P::exp_(lv);   // utils.py:75
                 }
                 put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+                if (mode == 1 && live) {                                  // feature (r & 3) + 8 (r >> 2) + 4 h of this lane's frame
+                    const int64_t o = (b0 + l31) * ZD + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        *reinterpret_cast<f32x4*>(g.out_mu + o + 8 * q) = f32x4{acc[4 * q] + bv[4 * q], acc[4 * q + 1] + bv[4 * q + 1], acc[4 * q + 2] + bv[4 * q + 2], acc[4 * q + 3] + bv[4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(g.out_lv + o + 8 * q) = f32x4{acc[8 + 4 * q] + bv[8 + 4 * q], acc[9 + 4 * q] + bv[9 + 4 * q], acc[10 + 4 * q] + bv[10 + 4 * q], acc[11 + 4 * q] + bv[11 + 4 * q]};
+                        if (g.out_z) *reinterpret_cast<f32x4*>(g.out_z + o + 8 * q) = f32x4{zv[4 * q], zv[4 * q + 1], zv[4 * q + 2], zv[4 * q + 3]};
+                    }
+                }
             }
             // label block of decoder layer 1: independent of z (three of the four waves have nothing else to do in this phase)
             f32x16 accy;
@@ -224,17 +234,20 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             int64_t rowx;
             if (gather) rowx = rsrc[l31];
             else { rowx = b0 + l31; rowx = rowx < g.B ? rowx : g.B - 1; }
-            const float* const xrow = g.x + rowx * g.ldx + 4 * h;
+            int64_t rowb = b0 + l31; rowb = rowb < g.B ? rowb : g.B - 1;     // batch-order row (outputs, upstream gradients)
+            const float* const xrow = mode == 2 ? (g.g_r ? g.g_r + rowb * g.ld_gr + 4 * h : nullptr) : g.x + rowx * g.ldx + 4 * h;
+            float* const orow = g.out_r + rowb * g.ld_r + 4 * h;
             f32x4 xq[4], xn[4];
             auto xload = [&](int t, f32x4 (&q)[4]) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    if (g.ablate & 8) q[gq] = f32x4{1.f, 2.f, 3.f, 4.f};
+                    if (mode == 1 || xrow == nullptr) q[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
                     else q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
                 }
             };
             xload(cw, xq);
-            const float xv512 = cw == 3 ? g.x[rowx * g.ldx + XD - 1] : 0.f;      // bin 512 (wave 3's dot-product tile), requested a phase early
+            // bin 512 (wave 3's dot-product tile), requested a phase early
+            const float xv512 = (cw == 3 && mode != 1 && xrow != nullptr) ? (mode == 2 ? g.g_r[rowb * g.ld_gr + XD - 1] : g.x[rowx * g.ldx + XD - 1]) : 0.f;
             bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + bv[r]);
@@ -253,15 +266,28 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 gemm_seg<P, SC, D, G_W5A + I>(acc, ws, Hbr);
                 float da[16], b5v[16];
                 bias16(Bias + OB5, 32 * t, h, b5v);
+                if (mode == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float xs = xq[r >> 2][r & 3];
-                    const float a = acc[r] + b5v[r];
-                    const float xe = xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
-                    rec_lane += xe - P::log_(xs + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
-                    da[r] = (1.f - xe) * invB_l;                         // d recon / d a
+                    for (int r = 0; r < 16; ++r) {
+                        const float xs = xq[r >> 2][r & 3];
+                        const float a = acc[r] + b5v[r];
+                        const float xe = xs * P::exp_(-a);                   // x / r,  r = exp(a)  (models.py:122)
+                        rec_lane += xe - P::log_(xs + g.elbo_eps) + a - 1.f;   // utils.py:74 (log r = a)
+                        da[r] = (1.f - xe) * invB_l;                         // d recon / d a
+                    }
+                    put_lds<P>(da, U, LDU, 32 * t, l31, h);
+                } else if (mode == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) da[r] = live ? xq[r >> 2][r & 3] * P::exp_(acc[r] + b5v[r]) : 0.f;   // d a = (d L / d r) r
+                    put_lds<P>(da, U, LDU, 32 * t, l31, h);
+                } else if (live) {                                       // mode 1: the reconstruction itself
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        F4U o;
+                        o.v = f32x4{P::exp_(acc[4 * gq] + b5v[4 * gq]), P::exp_(acc[4 * gq + 1] + b5v[4 * gq + 1]), P::exp_(acc[4 * gq + 2] + b5v[4 * gq + 2]), P::exp_(acc[4 * gq + 3] + b5v[4 * gq + 3])};
+                        *reinterpret_cast<F4U*>(orow + 32 * t + 8 * gq) = o;
+                    }
                 }
-                put_lds<P>(da, U, LDU, 32 * t, l31, h);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) xq[gq] = xn[gq];
             });
@@ -287,8 +313,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 s += __shfl_xor(s, 32, 64);
                 const float a = s + Bias[OB5 + XD - 1];
                 const float xe = xv512 * P::exp_(-a);
-                if (h == 0) rec_lane += xe - P::log_(xv512 + g.elbo_eps) + a - 1.f;
-                const float da512 = (1.f - xe) * invB_l;
+                if (h == 0 && mode == 0) rec_lane += xe - P::log_(xv512 + g.elbo_eps) + a - 1.f;
+                if (mode == 1 && live && h == 0) g.out_r[rowb * g.ld_r + XD - 1] = P::exp_(a);
+                const float da512 = mode == 0 ? (1.f - xe) * invB_l : (mode == 2 && live ? xv512 * P::exp_(a) : 0.f);
                 // columns 512 .. 543 of this frame's da row: the value, then 31 zeros (16 per lane half)
                 float dz16[16];
 #pragma unroll
@@ -309,6 +336,12 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             }
             wg_barrier();                                               // BDA
             R2_STAMP(9);
+            if (mode == 1) {                                               // forward only: the helpers stage the next tile, then the stream restarts at position 0
+                wg_barrier();                                           // BDD2'
+                ws.fill();
+                wg_barrier();                                           // BRED'
+                continue;
+            }
             // ---------------- backward: d2 <- da ----------------
             zero_acc<P>(acc);
             gemm_seg<P, SC, D, G_W5T>(acc, ws, Ur);
@@ -330,14 +363,31 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             R2_STAMP(11);
             // ---------------- backward: z <- dpre_d1 (wave 0), then dmu / dlogvar ----------------
             zero_acc<P>(acc);
+            float gu[24];                                                  // mode 2: upstream d z | d mu | d log_var of this lane's 8 latent features
+#pragma unroll
+            for (int r = 0; r < 24; ++r) gu[r] = 0.f;
+            if (w0 && mode == 2) {
+                const int64_t o = (b0 + l31 < g.B ? b0 + l31 : g.B - 1) * ZD + 4 * h;
+                const float* srcs[3] = {g.g_z, g.g_mu, g.g_lv};
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (srcs[q] != nullptr) {
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(srcs[q] + o), hi4 = *reinterpret_cast<const f32x4*>(srcs[q] + o + 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { gu[8 * q + j] = lo4[j]; gu[8 * q + 4 + j] = hi4[j]; }
+                    }
+            }
             gemm_seg<P, SC, D, G_W3ZT>(acc, ws, Har, true, w0);
             if (w0) {
                 float dml[16];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float dz = acc[r], mu = keepz[r * 64 + lane], lv = keepz[(8 + r) * 64 + lane];
-                    dml[r] = live ? dz + mu * g.invB : 0.f;                                                         // dmu
-                    dml[r + 8] = live ? dz * ep_r[r] * (0.5f * P::exp_(0.5f * lv)) - 0.5f * g.invB * (1.f - P::exp_(lv)) : 0.f;   // dlogvar
+                    const float mu = keepz[r * 64 + lane], lv = keepz[(8 + r) * 64 + lane];
+                    const float dz = acc[r] + gu[r];
+                    const float kmu = mode == 0 ? mu * g.invB : gu[8 + r];                                         // KL term of the fused step / upstream d mu
+                    const float klv = mode == 0 ? -0.5f * g.invB * (1.f - P::exp_(lv)) : gu[16 + r];
+                    dml[r] = live ? dz + kmu : 0.f;                                                                 // dmu
+                    dml[r + 8] = live ? dz * ep_r[r] * (0.5f * P::exp_(0.5f * lv)) + klv : 0.f;                     // dlogvar
                 }
                 put_lds<P>(dml, Zb, LDZ, 0, l31, h);
             }
@@ -416,6 +466,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         };
         f32x4 xv[NQ513];
         bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
+        const bool st1 = g.mode != 1 && !(g.ablate & 1), st2 = g.mode != 1 && !(g.ablate & 2);   // forward-only launches stash nothing
         for (int it = 0; it < ntl; ++it) {
             const int tile = (int)blockIdx.x + it * (int)gridDim.x;
             const int64_t b0 = (int64_t)tile * TB;
@@ -455,7 +506,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             f32x4 yv[NQ513];
             if (YP > 0) {
                 if (Y513 && yfast) tile513_issue(g.y, rowof, yv, tl);
-                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
                 wg_barrier();                                           // BL1X
                 if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl);
                 else load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl, rowof);
@@ -467,33 +518,49 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) any |= (yv[i][j] - (float)P::cvt(yv[i][j])) != 0.f;
                     } else {
-                        for (int idx = tl; idx < TB * YP; idx += 256) any |= (float)U[Pl<P>::lds + (idx / YP) * LDU + idx % YP] != 0.f;
+                        constexpr int YPD = YP > 0 ? YP : 1;
+                        for (int idx = tl; idx < TB * YP; idx += 256) any |= (float)U[Pl<P>::lds + (idx / YPD) * LDU + idx % YPD] != 0.f;
                     }
                     if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
                 }
                 wg_barrier();                                           // BY
-                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+                if (st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
             } else {
-                if (!(g.ablate & 2)) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
             }
             wg_barrier();                                               // BH1
-            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BH2
-            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BZ
-            if (hw == 0 && !(g.ablate & 1)) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
+            if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
             if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
             wg_barrier();                                               // BD1
-            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BD2
-            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BDA
-            for (int t = hw; t < NT_OUT; t += 4) if (!(g.ablate & 1)) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
+            for (int t = hw; t < NT_OUT; t += 4) if (st1) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
             const bool more = it + 1 < ntl;
             const int ntile = tile + (int)gridDim.x;
             if (more && gather) fill_rows(ntile, (it + 1) & 1);
             wg_barrier();                                               // BDD2: da consumed, U is free
-            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dd2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (g.mode == 1) {                                             // forward only: stage the next tile's x right away
+                if (more) {
+                    const int64_t fb0 = (int64_t)ntile * TB;
+                    const int64_t* const fsrc = rowsrc + ((it + 1) & 1) * TB;
+                    auto frowof = [&](int r) -> int64_t {
+                        if (gather) return fsrc[r];
+                        const int64_t br = fb0 + r;
+                        return br < g.B ? br : g.B - 1;
+                    };
+                    if (g.fastx && (fb0 + TB) <= g.B) { tile513_issue(g.x, frowof, xv, tl); tile513_commit<P, XP>(xv, U, LDU, tl); }
+                    else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, fb0, g.B, U, LDU, tl, frowof);
+                }
+                wg_barrier();                                           // BRED'
+                continue;
+            }
+            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dd2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             // next tile's x: requested now, committed three phases later
             const int64_t nb0 = (int64_t)ntile * TB;
             const bool nfull = more && (nb0 + TB) <= g.B;
@@ -506,13 +573,13 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             x_in_regs = more && g.fastx && nfull;
             if (x_in_regs) tile513_issue(g.x, nrowof, xv, tl);
             wg_barrier();                                               // BDD1
-            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BDML
-            if (hw == 0 && !(g.ablate & 1)) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
+            if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
             wg_barrier();                                               // BDH2
-            if (!(g.ablate & 1)) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BDH1
-            if (!(g.ablate & 1)) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             if (more) {
                 if (x_in_regs) tile513_commit<P, XP>(xv, U, LDU, tl);
                 else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof);

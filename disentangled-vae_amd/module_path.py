@@ -1,0 +1,214 @@
+"""Whole-model autograd path of the drop-in modules.
+
+`packages.models.models.VariationalAutoencoder.forward` / `DeepGenerativeModel.forward` on CUDA tensors at the reference
+geometry (x 513, h [128, 128], z 16, y 0 / 1 / 513) run as ONE autograd Function instead of one Function per nn.Linear:
+
+    forward : dvae_module_forward  = weight-copy refresh + the 8-wave rows kernel in forward mode   (2 launches)
+    backward: dvae_module_backward = rows kernel in backward mode (forward recomputed on chip, then the backward from the
+              upstream gradients of r, z, mu, log_var) + weight-gradient kernel + slab sum             (3 launches)
+
+The training scripts keep `loss.backward()` and their own stock `torch.optim.Adam` (scripts/training_M2.py:122, 142-147).
+To make that cheap the engine keeps the module's 14 parameters as views of ONE flat fp32 buffer in the fused kernels'
+plan layout (they stay ordinary nn.Parameters: state_dict, load_state_dict, optimizers see nothing new), and the backward
+pass leaves every `.grad` as a view of one flat gradient buffer.  `.grad` is written by the Function's backward directly
+(accumulating if a gradient is already there), which is what AccumulateGrad would do with 14 separate tensors, minus 14
+clone kernels; hooks on parameters are therefore not run on this path -- set DVAE_MODULE_PATH=layers to take the
+layer-level Functions of ops.py instead (they also cover every other geometry).
+
+MFMA operand policy: DVAE_MODULE_PRECISION (default bf16x3, the parity-grade split-bf16 policy; bf16 = fast and loose).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import native as N
+from .trainer import MODEL_CODE, PREC_CODE, TENSOR_NAMES, TrainPlan
+
+
+def enabled():
+    return os.environ.get("DVAE_MODULE_PATH", "fused") != "layers"
+
+
+def _precision():
+    p = os.environ.get("DVAE_MODULE_PRECISION", "bf16x3")
+    if p not in ("bf16x3", "bf16"):
+        raise ValueError("DVAE_MODULE_PRECISION must be bf16x3 or bf16 (the fused module path has no fp32-MFMA kernel; use DVAE_MODULE_PATH=layers)")
+    return p
+
+
+class ModuleEngine:
+    """Fused kernels bound to one module instance (M1 or M2)."""
+
+    def __init__(self, module, model, y_dim):
+        self.lib = N.load()
+        self.model, self.y_dim = model, int(y_dim)
+        self.precision = _precision()
+        sd_names = [n for n, _ in module.named_parameters()]
+        if sd_names != TENSOR_NAMES:
+            raise RuntimeError(f"unexpected parameter set for the fused module path: {sd_names}")
+        self.params = [p for _, p in module.named_parameters()]
+        self.device = self.params[0].device
+        self.plans = {}
+        p0 = self._plan(128)[0]
+        self.n_params = int(p0.n_params)
+        self.spans = [(int(p0.tensor_offset[i]), int(p0.tensor_rows[i]) * int(p0.tensor_cols[i])) for i in range(len(self.params))]
+        with torch.cuda.device(self.device):
+            self.flat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.gflat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.gtmp = None
+        self.gviews = [self.gflat[o:o + n].view(p.shape) for p, (o, n) in zip(self.params, self.spans)]     # what .grad points at
+        self.gptrs = [v.data_ptr() for v in self.gviews]
+        self.pptrs = [self.flat.data_ptr() + 4 * o for o, _ in self.spans]
+        self._alias()
+
+    def __deepcopy__(self, memo):          # a copied module rebuilds its own engine on first use
+        return None
+
+    # ---- plans (one per batch size) ----
+    def _plan(self, B):
+        got = self.plans.get(B)
+        if got is None:
+            plan = TrainPlan()
+            N.check(self.lib.dvae_train_plan(MODEL_CODE[self.model], self.y_dim, PREC_CODE[self.precision], int(B), 0, ctypes.byref(plan)),
+                    "dvae_train_plan")
+            if plan.rows_kernel != 2:
+                raise RuntimeError("fused module path needs the 8-wave rows kernel (unset DVAE_ROWS)")
+            ws = None
+            got = [plan, ws, False]
+            self.plans[B] = got
+        return got
+
+    def _ready(self, B):
+        ent = self._plan(B)
+        if not ent[2]:
+            with torch.cuda.device(self.device):
+                ent[1] = torch.empty(ent[0].workspace_bytes, dtype=torch.uint8, device=self.device)
+                N.check(self.lib.dvae_train_init(ctypes.byref(ent[0]), N.ptr(self.flat), N.ptr(ent[1]), N.stream()), "dvae_train_init")
+            ent[2] = True
+        return ent[0], ent[1]
+
+    # ---- parameters as views of the flat buffer ----
+    def _alias(self):
+        for p, (o, n), want in zip(self.params, self.spans, self.pptrs):
+            if p.data_ptr() != want:
+                view = self.flat[o:o + n].view(p.shape)
+                with torch.no_grad():
+                    view.copy_(p.detach().to(device=self.device, dtype=torch.float32))
+                p.data = view
+
+    def usable(self, x):
+        return all(p.is_cuda and p.device == x.device and p.dtype == torch.float32 for p in self.params)
+
+    # ---- launches ----
+    def forward(self, x, y, eps):
+        B = x.shape[0]
+        if self.params[0].device != self.device:
+            raise RuntimeError("module moved to another device after the fused engine was built")
+        self._alias()
+        plan, ws = self._ready(B)
+        with torch.cuda.device(self.device):
+            r = torch.empty((B, 513), dtype=torch.float32, device=self.device)
+            mlz = torch.empty((3, B, 16), dtype=torch.float32, device=self.device)
+            yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
+            N.check(self.lib.dvae_module_forward(ctypes.byref(plan), N.ptr(self.flat), N.ptr(ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps),
+                                                 N.ptr(r), 513, N.ptr(mlz[0]), N.ptr(mlz[1]), N.ptr(mlz[2]), 1, N.stream()), "dvae_module_forward")
+        return r, mlz[2], mlz[0], mlz[1]
+
+    def backward(self, x, y, eps, gr, gz, gmu, glv):
+        B = x.shape[0]
+        plan, ws = self._ready(B)
+        grads = [p.grad for p in self.params]
+        if all(g is None for g in grads):
+            dst, acc, how = self.gflat, 0, "assign"
+        elif all(g is not None and g.data_ptr() == gp for g, gp in zip(grads, self.gptrs)):
+            dst, acc, how = self.gflat, 1, "inplace"          # gradient accumulation over several backward passes
+        else:
+            if self.gtmp is None:
+                self.gtmp = torch.empty_like(self.gflat)
+            dst, acc, how = self.gtmp, 0, "add"
+        c = lambda t: None if t is None else (t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().to(torch.float32))
+        gr_ = None if gr is None else (gr if (gr.stride(1) == 1 and gr.dtype == torch.float32) else gr.contiguous().to(torch.float32))
+        gz, gmu, glv = c(gz), c(gmu), c(glv)
+        with torch.cuda.device(self.device):
+            yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
+            N.check(self.lib.dvae_module_backward(ctypes.byref(plan), N.ptr(self.flat), N.ptr(ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps),
+                                                  N.ptr(gr_), 0 if gr_ is None else N.ld(gr_), N.ptr(gmu), N.ptr(glv), N.ptr(gz),
+                                                  N.ptr(dst), acc, N.stream()), "dvae_module_backward")
+        if how == "inplace":
+            return
+        if how == "assign":
+            for p, v in zip(self.params, self.gviews):
+                if p.requires_grad:
+                    p.grad = v
+            return
+        for p, g, (o, n) in zip(self.params, grads, self.spans):
+            if not p.requires_grad:
+                continue
+            view = dst[o:o + n].view(p.shape)
+            if g is None:
+                p.grad = view.clone()
+            else:
+                g.add_(view)
+
+
+class VaeFunction(torch.autograd.Function):
+    """(r, z, mu, log_var) = model(x, y) with reparametrisation noise eps; the parameters are passed so that autograd knows
+    the outputs depend on them -- their gradients are deposited in .grad by backward() itself (module docstring)."""
+
+    @staticmethod
+    def forward(ctx, engine, x, y, eps, *params):
+        r, z, mu, lv = engine.forward(x, y, eps)
+        ctx.engine = engine
+        ctx.has_y = y is not None
+        ctx.save_for_backward(x, y if y is not None else x.new_empty(0), eps)
+        ctx.set_materialize_grads(False)
+        return r, z, mu, lv
+
+    @staticmethod
+    def backward(ctx, gr, gz, gmu, glv):
+        x, y, eps = ctx.saved_tensors
+        ctx.engine.backward(x, y if ctx.has_y else None, eps, gr, gz, gmu, glv)
+        return (None,) * (4 + len(ctx.engine.params))
+
+
+def engine_for(module, model, x, y):
+    """The module's engine when this call can take the fused path, else None.  model: "M1" | "M2"."""
+    if not (enabled() and x.is_cuda and x.dim() == 2 and x.shape[1] == 513 and x.dtype == torch.float32 and x.shape[0] > 0):
+        return None
+    if x.requires_grad or (y is not None and y.requires_grad):
+        return None                                  # gradients with respect to the data are a layer-path feature
+    eng = module.__dict__.get("_dvae_engine")
+    if eng is None:
+        if module.__dict__.get("_dvae_engine_off"):
+            return None
+        ok = (module.z_dim == 16 and module.flow is None
+              and [tuple(l.weight.shape) for l in module.encoder.hidden] == [(128, 513 + (module.y_dim if model == "M2" else 0)), (128, 128)]
+              and [tuple(l.weight.shape) for l in module.decoder.hidden] == [(128, 16 + (module.y_dim if model == "M2" else 0)), (128, 128)]
+              and tuple(module.decoder.reconstruction.weight.shape) == (513, 128)
+              and (model == "M1" or module.y_dim in (1, 513))
+              and all(p.is_cuda and p.dtype == torch.float32 for p in module.parameters())
+              and [n for n, _ in module.named_parameters()] == TENSOR_NAMES)
+        if not ok:
+            object.__setattr__(module, "_dvae_engine_off", True)
+            return None
+        eng = ModuleEngine(module, model, module.y_dim if model == "M2" else 0)
+        object.__setattr__(module, "_dvae_engine", eng)
+    if not eng.usable(x):
+        return None
+    if model == "M2" and (y is None or y.dim() != 2 or y.shape != (x.shape[0], eng.y_dim) or y.dtype != torch.float32 or y.device != x.device):
+        return None
+    return eng
+
+
+def run(eng, x, y, eps):
+    """-> (r, z, mu, log_var).  eps: [B, 16] float32 on x's device."""
+    x = x if x.stride(1) == 1 else x.contiguous()
+    if y is not None:
+        y = y if y.stride(1) == 1 else y.contiguous()
+    eps = eps.to(device=x.device, dtype=torch.float32).contiguous()
+    if eps.shape != (x.shape[0], 16):
+        raise RuntimeError(f"reparametrisation noise must be [{x.shape[0]}, 16], got {tuple(eps.shape)}")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in eng.params):
+        return VaeFunction.apply(eng, x, y, eps, *eng.params)
+    return eng.forward(x, y, eps)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "dvae_elbo_workspace_bytes": (c_sz, [c_i64]),
     "dvae_elbo_fwd": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp]),
     "dvae_elbo_bwd": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_vp, c_i, c_vp, c_vp, c_vp]),
+    "dvae_elbo_bwd3": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_vp, c_i, c_vp, c_vp, c_vp]),
     "dvae_bce_fwd": (c_i, [c_vp, c_vp, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp]),
     "dvae_bce_bwd": (c_i, [c_vp, c_vp, c_f, c_vp, c_i64, c_i, c_i, c_vp, c_vp, c_vp]),
     "dvae_adam_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i64, c_d, c_d, c_d, c_d, c_i, c_d, c_vp]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "dvae_train_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_d, c_d, c_d, c_d, c_vp, c_vp]),
     "dvae_train_eval": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_vp, c_vp]),
     "dvae_train_noise": (c_i, [c_vp, ctypes.c_uint64, c_vp, c_vp]),
+    "dvae_module_forward": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_vp]),
+    "dvae_module_backward": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_vp]),
     "dvae_train_profile": (c_i, [c_i]),
     "dvae_train_debug_stamps": (c_i, [c_vp]),
     "dvae_train_profile_read": (c_i, [c_vp, c_vp]),

@@ -127,7 +127,8 @@ class Reparam(torch.autograd.Function):
 
 
 class Elbo(torch.autograd.Function):
-    """(recon + KL, recon, KL) of packages/models/utils.py:73-76 as one [3] tensor."""
+    """(recon + KL, recon, KL) of packages/models/utils.py:73-76 as three 0-dim tensors (views of one [3] buffer).  The three
+    upstream gradients go to the backward kernel as they are (device scalars or absent): no host-side tensor arithmetic."""
 
     @staticmethod
     def forward(ctx, x, r, mu, logvar, eps):
@@ -146,22 +147,23 @@ class Elbo(torch.autograd.Function):
                                   N.ptr(out3), None, N.ptr(ws), N.stream()), "dvae_elbo_fwd")
         ctx.save_for_backward(x_, r_, mu_, lv_)
         ctx.shapes = (r.shape, mu.shape, logvar.shape)
-        return out3
+        ctx.set_materialize_grads(False)
+        return out3[0], out3[1], out3[2]
 
     @staticmethod
-    def backward(ctx, g3):
+    def backward(ctx, g_loss, g_recon, g_kl):
         lib = N.load()
         x_, r_, mu_, lv_ = ctx.saved_tensors
         B, F = x_.shape
         Z = mu_.shape[1]
-        g3 = g3.to(torch.float32)
-        g2 = torch.stack((g3[0] + g3[1], g3[0] + g3[2])).contiguous()
+        f32 = lambda g: None if g is None else (g if g.dtype == torch.float32 else g.to(torch.float32))
+        g_loss, g_recon, g_kl = f32(g_loss), f32(g_recon), f32(g_kl)
         need_r, need_mu, need_lv = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         dr = _new((B, F), x_) if need_r else None
         dmu = torch.empty_like(mu_) if need_mu else None
         dlv = torch.empty_like(lv_) if need_lv else None
-        N.check(lib.dvae_elbo_bwd(N.ptr(x_), N.ld(x_), N.ptr(r_), N.ld(r_), N.ptr(mu_), N.ptr(lv_), N.ptr(g2), B, F, Z,
-                                  N.ptr(dr), F, N.ptr(dmu), N.ptr(dlv), N.stream()), "dvae_elbo_bwd")
+        N.check(lib.dvae_elbo_bwd3(N.ptr(x_), N.ld(x_), N.ptr(r_), N.ld(r_), N.ptr(mu_), N.ptr(lv_), N.ptr(g_loss), N.ptr(g_recon), N.ptr(g_kl),
+                                   B, F, Z, N.ptr(dr), F, N.ptr(dmu), N.ptr(dlv), N.stream()), "dvae_elbo_bwd3")
         rs, ms, ls = ctx.shapes
         return (None, None if dr is None else dr.reshape(rs), None if dmu is None else dmu.reshape(ms),
                 None if dlv is None else dlv.reshape(ls), None)

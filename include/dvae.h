@@ -92,6 +92,11 @@ int dvae_elbo_fwd(const float* x, int ldx, const float* r, int ldr, const float*
 int dvae_elbo_bwd(const float* x, int ldx, const float* r, int ldr, const float* mu,
                   const float* logvar, const float* g2, int64_t B, int F, int Z,
                   float* dr, int lddr, float* dmu, float* dlogvar, void* stream);
+/* The same with the three upstream gradients of elbo()'s outputs (loss, recon, KL) as device scalars, each may be NULL (= 0):
+ * d/d recon = *g_loss + *g_recon, d/d KL = *g_loss + *g_kl -- no host-side arithmetic on them (autograd hands them over separately). */
+int dvae_elbo_bwd3(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar,
+                   const float* g_loss, const float* g_recon, const float* g_kl, int64_t B, int F, int Z,
+                   float* dr, int lddr, float* dmu, float* dlogvar, void* stream);
 
 /* binary_cross_entropy family, utils.py:55-63: variant 0 = (r, x), 1 = _v2 (targets 0.5),
  * 2 = _v3 (targets r).  out1 = -mean_b sum_j [t log(r+eps) + (1-t) log(1-r+eps)]. */

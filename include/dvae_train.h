@@ -118,6 +118,21 @@ int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, floa
 int dvae_train_eval(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                     const float* y, int ldy, const float* eps_noise, float elbo_eps, float* losses3, void* stream);
 
+/* Whole-model autograd path of the drop-in modules (packages/models/models.py: VariationalAutoencoder.forward,
+ * DeepGenerativeModel.forward -- reference models.py:172-179, 200-203): ONE launch for the model forward instead of one per
+ * nn.Linear, and the backward pass as rows kernel + weight-gradient kernel + slab sum, under stock torch autograd / torch.optim.Adam
+ * (scripts/training_M2.py:142-147).  M1 / M2 with bf16 / bf16x3 operands (plan->rows_kernel == 2), no gather table.
+ *   dvae_module_forward : (repack != 0: rebuild the kernel-layout weight copies from `params` first) r = model(x, y) [B, 513] (ld_r),
+ *                         mu, log_var, z [B, 16] (out_z may be NULL); eps_noise [B, 16] is the reparametrisation noise.
+ *   dvae_module_backward: recomputes the forward, then the backward from the upstream gradients g_r [B, 513] (ld_gr), g_mu, g_lv,
+ *                         g_z [B, 16] (each may be NULL = zero); grad_flat[n_params] (plan layout) = (accumulate ? grad_flat : 0) + dL/dparams. */
+int dvae_module_forward(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                        const float* y, int ldy, const float* eps_noise, float* out_r, int ld_r, float* out_mu,
+                        float* out_lv, float* out_z, int repack, void* stream);
+int dvae_module_backward(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
+                         const float* y, int ldy, const float* eps_noise, const float* g_r, int ld_gr,
+                         const float* g_mu, const float* g_lv, const float* g_z, float* grad_flat, int accumulate, void* stream);
+
 /* The [B, 16] standard normals the rows kernel draws for (plan->rng_seed, step) when eps_noise == NULL. */
 int dvae_train_noise(const dvae_train_plan_t* plan, uint64_t step, float* eps_out, void* stream);
 

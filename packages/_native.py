@@ -26,6 +26,10 @@ def native():
     return importlib.import_module("disentangled-vae_amd.native")
 
 
+def module_path():
+    return importlib.import_module("disentangled-vae_amd.module_path")
+
+
 def stft_host():
     return importlib.import_module("disentangled-vae_amd.stft")
 

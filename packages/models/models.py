@@ -10,6 +10,10 @@ nn.Linear + activation pair is one call of `_dense`:
     Linear+tanh/relu/sigmoid/exp on the fp32 matrix cores, `torch.cat([x, y])`
     folded into the kernel as a two-block K loop.  No fallback: a missing
     library raises.
+  * CUDA tensors at the reference geometry (x 513, h [128, 128], z 16, y 0 / 1 / 513) through the M1 / M2 model forward
+    -> ONE autograd Function for the whole model (disentangled-vae_amd/module_path.py: 2 launches forward, 3 backward,
+    parameters and their gradients as views of flat buffers), so `loss.backward()` + stock `torch.optim.Adam` are bound by
+    PyTorch's own host cost, not by 64 launches per step.  DVAE_MODULE_PATH=layers keeps the per-layer Functions.
   * host tensors  -> the same ATen ops the reference runs on CPU (the
     reference's CPU mode; scripts select it when no GPU exists).  This is
     selected by the tensors' device only, never as a substitute for the HIP path.
@@ -71,6 +75,15 @@ class Stochastic(nn.Module):
     the reference's noise.  `Stochastic.epsilon_fn` (callable mu -> epsilon) overrides
     the source, e.g. a device generator in throughput runs or injected noise in tests."""
     epsilon_fn = None
+
+    @staticmethod
+    def draw_epsilon(shape, device):
+        """The same noise source for callers that have no mu yet (the whole-model fused forward): `epsilon_fn` sees a zero
+        tensor of mu's shape on mu's device."""
+        if Stochastic.epsilon_fn is not None:
+            return Stochastic.epsilon_fn(torch.zeros(shape, device=device))
+        epsilon = torch.randn(shape, requires_grad=False)
+        return epsilon.to(device, non_blocking=True) if device.type == "cuda" else epsilon
 
     def reparametrize(self, mu, log_var):
         if Stochastic.epsilon_fn is not None:
@@ -182,6 +195,21 @@ class VariationalAutoencoder(nn.Module):
         self.kl_divergence = 0
         _xavier_reset(self)
 
+    # kl_divergence ([B] tensor after forward, reference models.py:175) is a side value no script reads: the fused forward
+    # leaves it pending and it is evaluated when somebody asks
+    @property
+    def kl_divergence(self):
+        pend = self.__dict__.get("_kl_pending")
+        if pend is not None:
+            self.__dict__["_kl_value"] = self._kld_v2(None, pend)
+            self.__dict__["_kl_pending"] = None
+        return self.__dict__.get("_kl_value", 0)
+
+    @kl_divergence.setter
+    def kl_divergence(self, value):
+        self.__dict__["_kl_value"] = value
+        self.__dict__["_kl_pending"] = None
+
     def _kld(self, z, q_param, p_param=None):
         """log q(z|x) - log p(z) for one sample z (optionally through a normalising flow).  No script calls it
         (reference models.py:143-163 is equally unreachable); kept so the attribute exists."""
@@ -201,6 +229,12 @@ class VariationalAutoencoder(nn.Module):
         self.flow = flow
 
     def forward(self, x, y=None):
+        if x.is_cuda and type(self) is VariationalAutoencoder:
+            eng = _native.module_path().engine_for(self, "M1", x, None)
+            if eng is not None:
+                r, z, z_mu, z_log_var = _native.module_path().run(eng, x, None, Stochastic.draw_epsilon((x.shape[0], self.z_dim), x.device))
+                self.__dict__["_kl_pending"] = (z_mu.detach(), z_log_var.detach())
+                return r, z_mu, z_log_var
         z, z_mu, z_log_var = self.encoder(x)
         self.kl_divergence = self._kld_v2(z, (z_mu, z_log_var))
         return self.decoder(z), z_mu, z_log_var
@@ -230,6 +264,11 @@ class DeepGenerativeModel(VariationalAutoencoder):
         _xavier_reset(self)
 
     def forward(self, x, y):
+        if x.is_cuda and type(self) is DeepGenerativeModel:
+            eng = _native.module_path().engine_for(self, "M2", x, y)
+            if eng is not None:
+                r, z, z_mu, z_log_var = _native.module_path().run(eng, x, y, Stochastic.draw_epsilon((x.shape[0], self.z_dim), x.device))
+                return r, z_mu, z_log_var
         z, z_mu, z_log_var = _encode_xy(self.encoder, x, y)
         return _decode_zy(self.decoder, z, y), z_mu, z_log_var
 

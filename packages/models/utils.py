@@ -83,8 +83,7 @@ def ikatura_saito_divergence(r, x, eps):
 def elbo(x, r, mu, logvar, eps):
     """-> (recon + KL, recon, KL), 0-dim tensors (reference utils.py:73-76)."""
     if _on_gpu(x, r, mu, logvar):
-        out = _native.ops().Elbo.apply(x, r, mu, logvar, eps)
-        return out[0], out[1], out[2]
+        return _native.ops().Elbo.apply(x, r, mu, logvar, eps)
     recon = torch.mean(_is_rows(x, r, eps))
     KL = torch.mean(_kl_rows(mu, logvar))
     return recon + KL, recon, KL

@@ -21,10 +21,12 @@ class StepImpl:
 
 
 def check_case(impl, fix, case, rtol_out=2e-5, rtol_loss=2e-5, rtol_grad=1e-4, atol_grad=1e-7, atol_rel_grad=1e-5,
-               rtol_param=1e-6, atol_param=2e-7):
+               rtol_param=1e-6, atol_param=2e-7, atol_out=1e-6, bad_frac=None):
     name, model, dims, B, wscale = case
     # see golden_util.compare_params: saturated / tiny-gradient elements are Adam-ill-conditioned
     max_bad_frac = 0.12 if (wscale > 1.0 or B < 4) else 0.01
+    if bad_frac is not None:
+        max_bad_frac = max(max_bad_frac, bad_frac)
     seed = 100 + [c[0] for c in gu.CASES].index(name)
     params = gu.make_params(model, dims, seed, wscale)
     chk = gu.checksum(params.values())
@@ -42,7 +44,7 @@ def check_case(impl, fix, case, rtol_out=2e-5, rtol_loss=2e-5, rtol_grad=1e-4, a
             for k in keys:
                 if out.get(k) is None:      # the fused trainer keeps r / mu / logvar on chip
                     continue
-                np.testing.assert_allclose(out[k], fix[f"{pre}/{k}"], rtol=rtol_out, atol=1e-6, err_msg=f"{pre}/{k}")
+                np.testing.assert_allclose(out[k], fix[f"{pre}/{k}"], rtol=rtol_out, atol=atol_out, err_msg=f"{pre}/{k}")
             if model == "M1" and out.get("kl_divergence") is not None:
                 np.testing.assert_allclose(out["kl_divergence"], fix[pre + "/kl_divergence"], rtol=rtol_out, atol=1e-5)
             if model != "M2_info":

@@ -107,22 +107,26 @@ def test_fused_is_deterministic_and_ksplit_invariant():
             assert np.max(np.abs(res[0][1][k] - other[1][k])) <= 2.1e-4   # slab count only reorders fp32 sums
 
 
-def test_fused_matches_layer_level_path_at_full_batch():
-    """The two product paths (fused trainer, drop-in modules + autograd + torch Adam) agree at B = 8192."""
+@pytest.mark.parametrize("path,ltol,gtol", [("layers", 2e-5, 5e-5), ("fused", 2e-5, 1e-3)])
+def test_fused_matches_module_paths_at_full_batch(path, ltol, gtol, monkeypatch):
+    """The fp32 fused trainer against the drop-in modules + autograd + torch Adam at B = 8192: the per-layer fp32 Functions
+    (DVAE_MODULE_PATH=layers) and the whole-model path (one Function per forward, split-bf16 operands: measured 1.5e-4)."""
     from impl_modules import ModuleImpl
+    monkeypatch.setenv("DVAE_MODULE_PATH", path)
     dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
     params = gu.make_params("M2", dims, 5)
     x, y, e = gu.make_batch(dims, 8192, 6)
     mi = ModuleImpl("cuda")
     mi.load("M2", dims, {k: v.copy() for k, v in params.items()})
     out = mi.step(x, y, e)
+    assert (mi.m.__dict__.get("_dvae_engine") is not None) == (path == "fused")
     tr = trainer.Trainer("M2", dims, params, batch=8192, precision="fp32")
     t = lambda a: torch.from_numpy(a).cuda()
     losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
-    np.testing.assert_allclose(losses, out["losses"], rtol=2e-5)
+    np.testing.assert_allclose(losses, out["losses"], rtol=ltol)
     g = tr.grads_numpy()
     for k in params:
-        assert _relmax(g[k], out["grads"][k].astype(np.float64)) < 5e-5, k
+        assert _relmax(g[k], out["grads"][k].astype(np.float64)) < gtol, k
 
 
 def test_state_dict_round_trip_and_repack():

@@ -117,7 +117,8 @@ def test_reparam_elbo_bce_against_oracle():
     tr = dev(r).requires_grad_()
     out = ops.Elbo.apply(dev(x), tr, tmu, tlv, 1e-8)
     ref = vo.elbo(x.astype(np.float64), r.astype(np.float64), mu.astype(np.float64), lv.astype(np.float64), 1e-8)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=2e-6)
+    assert len(out) == 3 and all(o.dim() == 0 for o in out)                     # (recon + KL, recon, KL): three 0-dim tensors
+    np.testing.assert_allclose([o.item() for o in out], ref, rtol=2e-6)
     (out[0] * 1.5 + out[2] * 0.25 + z.sum() * 0.01).backward()
     da, dmu, dlv = vo.elbo_bwd(x.astype(np.float64), a.astype(np.float64), mu.astype(np.float64), lv.astype(np.float64))
     # dr = da / r ; loss weight 1.5 on recon, 1.75 on KL; z path adds 0.01 and 0.01*eps*0.5*std

@@ -15,8 +15,25 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("case", gu.CASES, ids=[c[0] for c in gu.CASES])
-def test_cuda_modules_match_reference_vectors(vae_golden, case):
+def test_cuda_modules_match_reference_vectors(vae_golden, case, monkeypatch):
+    """Per-layer Functions (exact fp32 MFMA): the round-1 bounds."""
+    monkeypatch.setenv("DVAE_MODULE_PATH", "layers")
     check_case(ModuleImpl("cuda"), vae_golden, case)
+
+
+FUSED_CASES = [c for c in gu.CASES if c[0] in ("M1_full", "M2_full_y1", "M2_full_y513", "M2_full_y513_hot")]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_cuda_modules_whole_model_path_matches_reference_vectors(vae_golden, case, monkeypatch):
+    """The default path for M1 / M2 at the reference geometry: one Function per model forward on the fused kernels
+    (disentangled-vae_amd/module_path.py), split-bf16 operands.  Outputs r / mu / logvar within 1e-4 (relative, with 5e-5 absolute
+    for the O(1) latents), losses 1e-5, every gradient element within 1e-3 of its tensor's maximum, parameters after 1 and 3 stock
+    torch.optim.Adam steps as for the fp32 path except for a larger share of sign-flipped tiny gradients."""
+    monkeypatch.delenv("DVAE_MODULE_PATH", raising=False)
+    impl = ModuleImpl("cuda")
+    check_case(impl, vae_golden, case, rtol_out=1e-4, atol_out=5e-5, rtol_loss=2e-5, rtol_grad=1e-3, atol_rel_grad=1e-3, bad_frac=0.06)
+    assert impl.m.__dict__.get("_dvae_engine") is not None, "the whole-model path did not run"
 
 
 def test_native_library_is_what_runs():
@@ -86,6 +103,7 @@ def test_eval_mode_and_no_grad_inference():
     # mcem-style direct calls: encoder on the concatenated tensor, decoder on [N, R, L]
     z, mu2, _ = m.encoder(torch.cat([x, y], dim=1))
     assert mu2.shape == (321, 16)
-    np.testing.assert_allclose(mu2.cpu().numpy(), mu.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    # m(x, y) runs the whole-model path (split-bf16 operands), m.encoder(...) the per-layer fp32 Functions: 1e-4 apart at most
+    np.testing.assert_allclose(mu2.cpu().numpy(), mu.cpu().numpy(), rtol=1e-4, atol=5e-5)
     zz = torch.randn(321, 3, 17, device="cuda")
     assert m.decoder(zz).shape == (321, 3, 513)
