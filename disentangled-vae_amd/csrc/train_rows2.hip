@@ -65,7 +65,9 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 #define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
-template <typename P, int YP, bool YENC>
+// MODE (RowsArgs::mode, compile time so the train-step instantiation carries none of the other modes' code or registers):
+// 0 fused train step, 1 forward outputs only, 2 backward from upstream gradients
+template <typename P, int YP, bool YENC, int MODE>
 __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         const T* const Hbr = Hb + l31 * LDH + h * E;
         const T* const Zbr = Zb + l31 * LDZ + h * E;
         const bool w0 = cw == 0;
-        const int mode = g.mode;
+        constexpr int mode = MODE;
         double tot_rec = 0.0, tot_kl = 0.0;
 
         for (int it = 0; it < ntl; ++it) {
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         };
         f32x4 xv[NQ513];
         bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
-        const bool st1 = g.mode != 1 && !(g.ablate & 1), st2 = g.mode != 1 && !(g.ablate & 2);   // forward-only launches stash nothing
+        const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2);   // forward-only launches stash nothing
         for (int it = 0; it < ntl; ++it) {
             const int tile = (int)blockIdx.x + it * (int)gridDim.x;
             const int64_t b0 = (int64_t)tile * TB;
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             const int ntile = tile + (int)gridDim.x;
             if (more && gather) fill_rows(ntile, (it + 1) & 1);
             wg_barrier();                                               // BDD2: da consumed, U is free
-            if (g.mode == 1) {                                             // forward only: stage the next tile's x right away
+            if (MODE == 1) {                                             // forward only: stage the next tile's x right away
                 if (more) {
                     const int64_t fb0 = (int64_t)ntile * TB;
                     const int64_t* const fsrc = rowsrc + ((it + 1) & 1) * TB;
@@ -589,21 +591,28 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     }
 }
 
-template <typename P, int YP, bool YENC>
-static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
+template <typename P, int YP, bool YENC, int MODE>
+static int launch_rows2_m(const RowsArgs& a, int grid, hipStream_t s) {
     const size_t lds = Lds2<P>::bytes;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(rows2 kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC, MODE>), dim3(grid), dim3(512), lds, s, a);
     DVAE_LAUNCH_OK("vae_rows2_kernel");
     return 0;
+}
+
+template <typename P, int YP, bool YENC>
+static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
+    if (a.mode == 1) return launch_rows2_m<P, YP, YENC, 1>(a, grid, s);
+    if (a.mode == 2) return launch_rows2_m<P, YP, YENC, 2>(a, grid, s);
+    return launch_rows2_m<P, YP, YENC, 0>(a, grid, s);
 }
 
 // model: DVAE_MODEL_M1 / DVAE_MODEL_M2 (M2_info stays on the 4-wave kernel); precision: DVAE_PREC_BF16 / DVAE_PREC_BF16X3
