@@ -752,6 +752,132 @@ __global__ __launch_bounds__(256, DVAE_WGRAD_OCC) void wgrad_kernel(const GroupD
     else wgrad_body<P, false, false>(d, kbeg, kend, Bp, spl, slab, l31, h);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients, workgroup-blocked: one 256-thread workgroup owns a 4 x 4 block of 32 x 32 tiles (128 output x 128 input
+// features of one layer), wave (wr, wc) the 2 x 2 group {2wr, 2wr+1} x {2wc, 2wc+1} of it.  The block's 4 + 4 operand tiles
+// are staged ONCE per k-step in LDS and shared by the four waves: the fragment-major stash tile of one k-step is 1 KB in
+// exactly the lane-linear order a direct-to-LDS load writes (LDS address = wave-uniform base + lane * 16), so a fragment
+// costs one `global_load_lds_dwordx4` and no registers.  A ring of NSTG stages x 2 k-steps keeps (NSTG - 1) stages in flight
+// across one raw workgroup barrier per stage (counted vmcnt, never 0: cdna_hip_programming.md "Pipelining across barriers").
+// Against the register-ring kernel above (every wave loads its own 2 + 2 fragments: each stash line crosses L2 -> CU 3.7
+// times) the operand traffic halves and the in-flight bytes no longer cost registers.
+struct BlockDesc {
+    const void* At[4];       // the block's A tiles (null = absent)
+    const void* Bt[4];
+    GroupDesc g[4];          // per wave (wr * 2 + wc): destinations of its 2 x 2 group; A[0] == null: nothing to do
+};
+
+template <typename P> struct WgLds {
+    static constexpr int KPS = 2;                                   // k-steps per stage
+    static constexpr int NSTG = 4;
+    static constexpr int FRAG = 1024;                               // bytes of one (tile, plane, k-step) fragment block
+    static constexpr int STAGE = 8 * P::NP * KPS * FRAG;
+    static constexpr int BYTES = NSTG * STAGE;
+    static constexpr int LOADS = 2 * P::NP * KPS;                   // direct-to-LDS loads per wave and stage (one A slot + one B slot)
+};
+
+template <typename P>
+__global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const BlockDesc* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
+                                                           int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
+    typedef typename P::T T;
+    typedef typename P::Frag Frag;
+    typedef WgLds<P> W;
+    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP, KPS = W::KPS, NSTG = W::NSTG;
+    constexpr int FB = 64 * E;
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int slice = blockIdx.x % ksplit, bi = blockIdx.x / ksplit;
+    if (bi >= nblocks) return;
+    const BlockDesc& bd = blocks[bi];
+    const GroupDesc d = bd.g[wave];
+    const int64_t kbeg = (int64_t)slice * kper;
+    int64_t kend = kbeg + kper;
+    if (kend > Bp) kend = Bp;
+    const int64_t sbeg = kbeg / KS, send = kend / KS;                 // k-steps of this frame slice
+    const int nst = (int)((send - sbeg + KPS - 1) / KPS);             // stages
+    float* slab = slabs + (int64_t)slice * slab_stride;
+    // this wave stages tile slots `wave` (an A tile) and 4 + `wave` (a B tile); absent tiles reload the block's first A tile so
+    // that every wave issues the same number of loads per stage (the vmcnt counts below are immediates)
+    const T* src[2];
+    src[0] = (const T*)(bd.At[wave] ? bd.At[wave] : bd.At[0]);
+    src[1] = (const T*)(bd.Bt[wave] ? bd.Bt[wave] : bd.At[0]);
+    auto issue = [&](int st) {                                        // stage st -> ring slot st % NSTG
+        char* base = wsm + (st % NSTG) * W::STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk) {
+                    int64_t sk = sbeg + (int64_t)st * KPS + kk; sk = sk < send ? sk : send - 1;   // past the slice: a harmless reload into a free slot
+                    const T* gp = src[q] + pl * spl + sk * FB + lane * E;
+                    char* lp = base + (((q * 4 + wave) * NP + pl) * KPS + kk) * W::FRAG;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+                }
+    };
+    f32x16 c00, c01, c10, c11, cb0, cb1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c00[i] = 0.f; c01[i] = 0.f; c10[i] = 0.f; c11[i] = 0.f; cb0[i] = 0.f; cb1[i] = 0.f; }
+    const bool have = d.A[0] != nullptr;
+    const bool A1 = d.A[1] != nullptr, B1 = d.Bm[1] != nullptr;
+    const bool bias0 = have && d.bias_off[0] >= 0, bias1 = A1 && d.bias_off[1] >= 0;
+    const Frag one = P::ones();
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int st = 0; st < NSTG - 1; ++st) issue(st);
+    for (int st = 0; st < nst; ++st) {
+        // stage st has landed for this wave's loads once at most (NSTG - 2) later stages are outstanding; the barrier extends that
+        // to every wave's loads and says that everybody has finished reading stage st - 1, whose slot the next issue overwrites
+        if constexpr (W::LOADS * (NSTG - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (W::LOADS * (NSTG - 2) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue(st + NSTG - 1);
+        const char* base = wsm + (st % NSTG) * W::STAGE;
+#pragma unroll
+        for (int kk = 0; kk < KPS; ++kk) {
+            if (sbeg + (int64_t)st * KPS + kk >= send) break;         // wave-uniform tail
+            auto frag = [&](int slot, int pl) -> Frag {
+                return *reinterpret_cast<const Frag*>(base + ((slot * NP + pl) * KPS + kk) * W::FRAG + lane * 16);
+            };
+            Frag a0[NP], a1[NP], b0[NP], b1[NP];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) { a0[pl] = frag(2 * wr, pl); a1[pl] = frag(2 * wr + 1, pl); b0[pl] = frag(4 + 2 * wc, pl); b1[pl] = frag(5 + 2 * wc, pl); }
+            if (have) {
+                mmap<P>(c00, a0, b0);
+                if (B1) mmap<P>(c01, a0, b1);
+                if (A1) mmap<P>(c10, a1, b0);
+                if (A1 && B1) mmap<P>(c11, a1, b1);
+                if (bias0) { P::mma(cb0, a0[0], one); if constexpr (NP == 2) P::mma(cb0, a0[1], one); }
+                if (bias1) { P::mma(cb1, a1[0], one); if constexpr (NP == 2) P::mma(cb1, a1[1], one); }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the clamped tail loads must land before the LDS is released
+    if (!have) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = feat_of(r, h);
+        if (row < d.mvalid[0]) {
+            const bool hi = d.split16 && row >= 16;
+            const int rr = hi ? row - 16 : row;
+            const int ldo = hi ? d.ldo_hi : d.ldo[0];
+            if (l31 < d.nvalid[0]) slab[(hi ? d.out_off_hi[0] : d.out_off[0][0]) + (int64_t)rr * ldo + l31] = c00[r];
+            if (B1) { if (l31 < d.nvalid[1]) slab[(hi ? d.out_off_hi[1] : d.out_off[0][1]) + (int64_t)rr * ldo + l31] = c01[r]; }
+            if (bias0 && l31 == 0) slab[(hi ? d.bias_off_hi : d.bias_off[0]) + rr] = cb0[r];
+        }
+        if (A1) {
+            if (row < d.mvalid[1]) {
+                if (l31 < d.nvalid[0]) slab[d.out_off[1][0] + (int64_t)row * d.ldo[1] + l31] = c10[r];
+                if (B1) { if (l31 < d.nvalid[1]) slab[d.out_off[1][1] + (int64_t)row * d.ldo[1] + l31] = c11[r]; }
+                if (bias1 && l31 == 0) slab[d.bias_off[1] + row] = cb1[r];
+            }
+        }
+    }
+}
+
 // dst = (accumulate ? dst : 0) + sum of the slabs (fixed order: deterministic)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride, float* __restrict__ dst, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -896,8 +1022,8 @@ struct Layout {
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
-    int64_t o_tiles, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
-    int ntiles;
+    int64_t o_tiles, o_blocks, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
+    int ntiles, nblocks;
 };
 
 static inline int64_t al(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -939,9 +1065,14 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     auto pr = [](int n) { return (n + 1) / 2; };
     L.ntiles = 2 * pr(NT_OUT + (L.ye ? nty : 0)) + 2 * 2 + 1 * 2 + 2 * pr(1 + (L.yd ? nty : 0)) + 2 * 2 + pr(NT_OUT) * 2;
     if (L.info) L.ntiles += 2 * pr(NT_OUT) + 2 * 2 + 1 * 2 + 2 * 1 + 2 * 2 + 1 * 2;   // clf L1, L2, out; aux L1, L2, out
+    // 4 x 4 blocks of the workgroup-blocked kernel: ceil(A tiles / 4) x ceil(B tiles / 4) per layer
+    auto q4 = [](int n) { return (n + 3) / 4; };
+    L.nblocks = q4(4) * q4(NT_OUT + (L.ye ? nty : 0)) + 1 + 1 + q4(4) * q4(1 + (L.yd ? nty : 0)) + 1 + q4(NT_OUT) * 1;
+    if (L.info) L.nblocks += q4(NT_OUT) + 1 + 1 + 1 + 1 + 1;
     int64_t b = 0;
     auto bytes = [&](int64_t n) { int64_t q = b; b += al(n, 256); return q; };
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
+    L.o_blocks = bytes((int64_t)L.nblocks * sizeof(BlockDesc));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
@@ -1024,8 +1155,10 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     // single-wave jobs fill the 1024 wave slots in one round (wgrad 164 -> 124 us at 65 536 frames, 2.49 -> 1.80 ms at 2^20).
     // fp32: the MFMA-bound wgrad needs a wave on every SIMD (>= 1024 wave jobs): 16.
     if (ks <= 0) {
-        const int cap = is_bf(precision) ? (plan->Bp > 12288 ? 12 : 8) : 16;
-        ks = (int)(plan->Bp / (is_bf(precision) ? 1024 : 512)); if (ks < 1) ks = 1; if (ks > cap) ks = cap;
+        // bf16x3: a wave issues 16 MFMAs per k-step (3 per tile product), ~15.6 us of matrix time per 1024-frame slice on its own SIMD, and
+        // 80 groups x 8 slices fill only 640 of the 1024 SIMDs: 12 slices (960 waves) take 3.3 us off the kernel and add 1.7 us of slab sums
+        const int cap = precision == DVAE_PREC_BF16X3 ? 12 : (is_bf(precision) ? (plan->Bp > 12288 ? 12 : 8) : 16);
+        ks = (int)(plan->Bp / (precision == DVAE_PREC_BF16X3 ? 640 : (is_bf(precision) ? 1024 : 512))); if (ks < 1) ks = 1; if (ks > cap) ks = cap;
     }
     if (ks > 64) ks = 64;
     plan->ksplit = ks;
@@ -1057,7 +1190,7 @@ struct ABlock { int64_t row; int mvalid; int tensor; int m0; int bias_tensor; in
 struct BBlock { int64_t row; int nvalid; int col; };
 
 template <typename T>
-static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, GroupDesc* groups, TensorDesc* td) {
+static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, GroupDesc* groups, BlockDesc* blocks, TensorDesc* td) {
     const int64_t Bp = p->Bp;
     T* stash = (T*)(ws_dev + L.o_stash);
     auto S = [&](int64_t row) { return (const void*)(stash + row * Bp); };
@@ -1071,36 +1204,52 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     auto addB = [&](int64_t row0, int N, int col0) {
         for (int n0 = 0; n0 < N; n0 += 32) bb[nb++] = BBlock{row0 + n0, N - n0 < 32 ? N - n0 : 32, col0 + n0};
     };
+    int nblk = 0;
+    // 2 x 2 group of tiles: A pair starting at block i, B pair starting at block j (all-null when out of range)
+    auto make_group = [&](int i, int j) {
+        GroupDesc d;
+        memset(&d, 0, sizeof(d));
+        d.bias_off[0] = d.bias_off[1] = -1;
+        if (i >= na || j >= nb) return d;
+        for (int ii = 0; ii < 2; ++ii) {
+            if (i + ii >= na) continue;
+            const ABlock& a = ab[i + ii];
+            d.A[ii] = S(a.row);
+            d.ldo[ii] = p->tensor_cols[a.tensor];
+            d.mvalid[ii] = a.mvalid;
+            if (a.bias_tensor >= 0 && j == 0) d.bias_off[ii] = p->tensor_offset[a.bias_tensor] + a.m0;
+            for (int jj = 0; jj < 2; ++jj) {
+                if (j + jj >= nb) continue;
+                d.out_off[ii][jj] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * d.ldo[ii] + bb[j + jj].col;
+                if (ii == 0 && a.tensor_hi >= 0) d.out_off_hi[jj] = p->tensor_offset[a.tensor_hi] + bb[j + jj].col;
+            }
+            if (ii == 0 && a.tensor_hi >= 0) {
+                d.split16 = 1;
+                d.ldo_hi = p->tensor_cols[a.tensor_hi];
+                d.bias_off_hi = p->tensor_offset[a.bias_hi];
+            }
+        }
+        for (int jj = 0; jj < 2; ++jj) {
+            if (j + jj >= nb) continue;
+            d.Bm[jj] = S(bb[j + jj].row);
+            d.nvalid[jj] = bb[j + jj].nvalid;
+        }
+        return d;
+    };
     auto emit = [&]() {
         for (int i = 0; i < na; i += 2)
-            for (int j = 0; j < nb; j += 2) {
-                GroupDesc d;
-                memset(&d, 0, sizeof(d));
-                for (int ii = 0; ii < 2; ++ii) {
-                    d.bias_off[ii] = -1;
-                    if (i + ii >= na) continue;
-                    const ABlock& a = ab[i + ii];
-                    d.A[ii] = S(a.row);
-                    d.ldo[ii] = p->tensor_cols[a.tensor];
-                    d.mvalid[ii] = a.mvalid;
-                    if (a.bias_tensor >= 0 && j == 0) d.bias_off[ii] = p->tensor_offset[a.bias_tensor] + a.m0;
-                    for (int jj = 0; jj < 2; ++jj) {
-                        if (j + jj >= nb) continue;
-                        d.out_off[ii][jj] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * d.ldo[ii] + bb[j + jj].col;
-                        if (ii == 0 && a.tensor_hi >= 0) d.out_off_hi[jj] = p->tensor_offset[a.tensor_hi] + bb[j + jj].col;
-                    }
-                    if (ii == 0 && a.tensor_hi >= 0) {
-                        d.split16 = 1;
-                        d.ldo_hi = p->tensor_cols[a.tensor_hi];
-                        d.bias_off_hi = p->tensor_offset[a.bias_hi];
-                    }
+            for (int j = 0; j < nb; j += 2) groups[n++] = make_group(i, j);
+        for (int i0 = 0; i0 < na; i0 += 4)
+            for (int j0 = 0; j0 < nb; j0 += 4) {
+                BlockDesc b;
+                memset(&b, 0, sizeof(b));
+                for (int k = 0; k < 4; ++k) {
+                    b.At[k] = i0 + k < na ? S(ab[i0 + k].row) : nullptr;
+                    b.Bt[k] = j0 + k < nb ? S(bb[j0 + k].row) : nullptr;
                 }
-                for (int jj = 0; jj < 2; ++jj) {
-                    if (j + jj >= nb) continue;
-                    d.Bm[jj] = S(bb[j + jj].row);
-                    d.nvalid[jj] = bb[j + jj].nvalid;
-                }
-                groups[n++] = d;
+                for (int wr = 0; wr < 2; ++wr)
+                    for (int wc = 0; wc < 2; ++wc) b.g[wr * 2 + wc] = make_group(i0 + 2 * wr, j0 + 2 * wc);
+                blocks[nblk++] = b;
             }
         na = 0; nb = 0;
     };
@@ -1119,7 +1268,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
         addA(L.da2T, HD, 22, 23); addB(L.a1T, HD, 0); emit();
         addA(L.da3T, 1, 24, 25); addB(L.a2T, HD, 0); emit();
     }
-    if (n != L.ntiles) { fprintf(stderr, "dvae: internal group count mismatch %d vs %d\n", n, L.ntiles); }
+    if (n != L.ntiles || nblk != L.nblocks) { fprintf(stderr, "dvae: internal group / block count mismatch %d vs %d, %d vs %d\n", n, L.ntiles, nblk, L.nblocks); }
     // tensors -> kernel-layout copies
     for (int i = 0; i < p->n_tensors; ++i) {
         TensorDesc t;
@@ -1194,12 +1343,14 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     char* w = (char*)ws;
     DVAE_HIP(hipMemsetAsync(w, 0, (size_t)L.total, s));
     GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
+    BlockDesc* blocks = new BlockDesc[L.nblocks + 8];
     TensorDesc td[DVAE_TRAIN_MAX_TENSORS];
     memset(td, 0, sizeof(td));
-    if (is_bf(plan->precision)) fill_tables<__bf16>(plan, L, w, tiles, td);
-    else fill_tables<float>(plan, L, w, tiles, td);
+    if (is_bf(plan->precision)) fill_tables<__bf16>(plan, L, w, tiles, blocks, td);
+    else fill_tables<float>(plan, L, w, tiles, blocks, td);
     hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(GroupDesc), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
+    hipError_t e5 = hipMemcpyAsync(w + L.o_blocks, blocks, (size_t)L.nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, s);
     const int64_t nchunks = plan->n_params / 64;
     unsigned char* ct = new unsigned char[nchunks + 64];
     memset(ct, 255, (size_t)nchunks + 64);
@@ -1210,8 +1361,9 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipError_t e4 = hipMemcpyAsync(w + L.o_chunks, ct, (size_t)nchunks, hipMemcpyHostToDevice, s);
     hipError_t e3 = hipStreamSynchronize(s);
     delete[] tiles;
+    delete[] blocks;
     delete[] ct;
-    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e3);
+    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e3);
     return dvae_train_repack(plan, params, ws, stream);
 }
 
@@ -1313,17 +1465,42 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     const int64_t kper = kper_of(plan);
     const int ks = (int)((plan->Bp + kper - 1) / kper);
     DVAE_CHECK_ARG(ks <= plan->ksplit, "train_grads: internal k-split mismatch");
+    float* slabs = (float*)(w + L.o_grads);
+    // DVAE_WGRAD=lds selects the workgroup-blocked kernel for the bf16 policies (operands staged once per 4 x 4 block in LDS: half the
+    // L2 -> CU operand traffic).  Measured (M2 y513, 8192 frames): 39.3 vs 32.9 us under bf16x3, 25.0 vs 21.4 us under bf16 -- SLOWER than the
+    // register-ring kernel at every k-split tried, and both kernels take the same time on a stash that is already cache-warm: the
+    // weight-gradient pass is bound neither by operand traffic nor by cold reads.  The register-ring kernel stays default.
+    const char* wk = getenv("DVAE_WGRAD");
+    int wrep = 1;
+    { const char* e = getenv("DVAE_WGRAD_REPEAT"); if (e) { wrep = atoi(e); if (wrep < 1) wrep = 1; } }   // diagnostic: re-run on the warm stash
+    for (int rep = 0; rep < wrep; ++rep)
+    if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
+        ProfScope ps(s, rep == 0 ? 1 : 2);
+        const dim3 g3((unsigned)(L.nblocks * ks));
+        static bool attr_done[64][2] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) dev = 0;
+        if (x3) {
+            if (!attr_done[dev][1]) { DVAE_HIP(hipFuncSetAttribute((const void*)wgrad_lds_kernel<PolX3>, hipFuncAttributeMaxDynamicSharedMemorySize, WgLds<PolX3>::BYTES)); attr_done[dev][1] = true; }
+            hipLaunchKernelGGL((wgrad_lds_kernel<PolX3>), g3, dim3(256), WgLds<PolX3>::BYTES, s, (const BlockDesc*)(w + L.o_blocks), L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        } else {
+            if (!attr_done[dev][0]) { DVAE_HIP(hipFuncSetAttribute((const void*)wgrad_lds_kernel<PolBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, WgLds<PolBF16>::BYTES)); attr_done[dev][0] = true; }
+            hipLaunchKernelGGL((wgrad_lds_kernel<PolBF16>), g3, dim3(256), WgLds<PolBF16>::BYTES, s, (const BlockDesc*)(w + L.o_blocks), L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        }
+        DVAE_LAUNCH_OK("wgrad_lds_kernel");
+    } else {
     int GPW = 2;                                            // groups (waves) per workgroup
     { const char* e = getenv("DVAE_GPW"); if (e) { GPW = atoi(e); if (GPW < 1 || GPW > 4) GPW = 2; } }   // diagnostic override
     const dim3 g2((unsigned)(((L.ntiles + GPW - 1) / GPW) * ks));
-    float* slabs = (float*)(w + L.o_grads);
     {
-        ProfScope ps(s, 1);
+        ProfScope ps(s, rep == 0 ? 1 : 2);
         if (x3) hipLaunchKernelGGL((wgrad_kernel<PolX3>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
         else if (bf) hipLaunchKernelGGL((wgrad_kernel<PolBF16>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
         else hipLaunchKernelGGL((wgrad_kernel<PolF32>), g2, dim3(64 * GPW), 0, s, (const GroupDesc*)(w + L.o_tiles), L.ntiles, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
     }
     DVAE_LAUNCH_OK("wgrad_kernel");
+    }
     if (reduce_slabs && ks > 1) {
         ProfScope ps(s, 2);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(512), dim3(256), 0, s, slabs, plan->n_params, ks, plan->n_params);

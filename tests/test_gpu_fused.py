@@ -129,6 +129,24 @@ def test_fused_matches_module_paths_at_full_batch(path, ltol, gtol, monkeypatch)
         assert _relmax(g[k], out["grads"][k].astype(np.float64)) < gtol, k
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_workgroup_blocked_wgrad_kernel_equals_the_default(precision, monkeypatch):
+    """DVAE_WGRAD=lds (4 x 4 tile blocks, operands staged once in LDS by direct-to-LDS loads) computes the same gradients as the
+    register-ring kernel: identical operands, same k-slices, only the order of the frame sum inside a slice is shared too."""
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 8)
+    x, y, e = gu.make_batch(dims, 3000, 9)                       # 94 tiles: ragged last tile, partial last k-slice
+    t = lambda a: torch.from_numpy(a).cuda()
+    got = {}
+    for kind in ("regs", "lds"):
+        monkeypatch.setenv("DVAE_WGRAD", kind)
+        tr = trainer.Trainer("M2", dims, params, batch=3000, precision=precision)
+        tr.step(t(x), t(y), t(e))
+        got[kind] = tr.grads_numpy()
+    for k in got["regs"]:
+        assert _relmax(got["lds"][k], got["regs"][k].astype(np.float64)) < 2e-6, k
+
+
 def test_state_dict_round_trip_and_repack():
     dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
     tr = trainer.Trainer("M2", dims, None, batch=64, precision="bf16", seed=0)
