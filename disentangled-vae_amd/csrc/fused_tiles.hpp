@@ -105,7 +105,10 @@ struct PolX3 : PolBF16 {
     static constexpr int PRE = 3;
     static constexpr int PRE128 = 4;
     static constexpr int PREBIG = 6;
-    static constexpr int WRING = 4;
+#ifndef DVAE_WRING_X3
+#define DVAE_WRING_X3 4
+#endif
+    static constexpr int WRING = DVAE_WRING_X3;
     static constexpr bool EARLY_Y = false;
     static constexpr bool XFULL = false;   // two operand planes fill the LDS: the fp32 x tile streams in 128-column slices
 };

@@ -23,6 +23,7 @@
 // constant-one fragment.
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "fused_tiles.hpp"
 #include "rows_common.hpp"
 #include "../../include/dvae_train.h"
@@ -878,6 +879,247 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const BlockDesc* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients, third form (default): one 256-thread workgroup = one 4 x 4 block of 32 x 32 tiles (128 output x 128 input
+// features of a layer) x one frame slice, ONE workgroup per CU.  EVERY wave owns the whole 4 x 4 block (256 accumulator
+// registers: the kernel runs at one wave per SIMD and has 512) on a QUARTER of the slice's frames: per k-step a wave loads 4 + 4
+// operand fragments and issues 16 tile products, so a byte pulled into the CU feeds twice the MFMAs of the 2 x 2 register-ring
+// kernel above (the measured bound there: ~55 GB/s of operand fragments per CU, 335 MB per launch, at 2.6 x the MFMA time).
+// The four partial blocks meet in LDS as a reduce-scatter in a fixed order (deterministic): wave w finishes and stores A row w.  Bias gradients are in-lane sums of the A fragments (a frame
+// sum needs no MFMA: one fp32 register per A tile instead of a 16-register accumulator against a constant-one operand).
+struct Block4 {
+    const void* At[4];       // stash rows of dPre^T, 32 output features each (null = absent; tiles are contiguous from 0)
+    const void* Bt[4];       // stash rows of In^T, 32 input features each
+    int64_t a_off[4];        // float offset, in a gradient slab, of (row 0 of A tile i, column 0) of its tensor
+    int64_t bias_off[4];     // float offset of the bias-gradient rows of A tile i, -1 = none (only a layer's first B column carries them)
+    int32_t ldo[4];          // row stride of A tile i's tensor
+    int32_t mvalid[4];
+    int32_t bcol[4];         // column of B tile j in the tensor
+    int32_t nvalid[4];
+    int32_t split16;         // A tile 0 holds two 16-row tensors (mu | log_var heads): rows >= 16 go to the *_hi targets
+    int32_t ldo_hi;
+    int64_t a_off_hi;
+    int64_t bias_off_hi;
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_w(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_w<I + 1, N>(f); }
+}
+
+template <typename P> struct Wg4 {
+#ifndef DVAE_W4RING_X3
+#define DVAE_W4RING_X3 3
+#endif
+#ifndef DVAE_W4RING
+#define DVAE_W4RING 4
+#endif
+    static constexpr int RD = P::NP == 2 ? DVAE_W4RING_X3 : DVAE_W4RING;      // k-steps of operand fragments in flight per wave
+    static constexpr size_t BYTES = (size_t)(8 * 16) * 64 * 16 + 12 * 64 * 4;           // 8 exchange slots of one A row (4 tiles x 16 registers x 64 lanes x 4 B) + the bias sums
+};
+
+// NA x NB = tiles of the block this instantiation computes (absent tiles alias tile 0 and are masked at the store: their
+// descriptors carry mvalid / nvalid 0).  Compile-time shapes keep every operand load unconditional: a load under a run-time
+// branch makes hipcc's wait-count pass fall back to vmcnt(0) in front of the first MFMA of every k-step (the ring then holds one).
+template <typename P, int NA, int NB>
+__device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __restrict__ bdg, char* wsm, int slice, int64_t Bp, int64_t spl, int64_t kper,
+                                            float* __restrict__ slabs, int64_t slab_stride, int lane, int wave) {
+    typedef typename P::T T;
+    typedef typename P::Frag Frag;
+    typedef Wg4<P> W;
+    typedef const __attribute__((address_space(1))) char* gptr;
+    typedef const __attribute__((address_space(1))) Frag* gfrag;
+    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP, RD = W::RD;
+    constexpr int64_t FBB = 64 * 16;                                     // bytes of one (feature tile, k-step) fragment block
+    const int l31 = lane & 31, h = lane >> 5;
+    // this wave's quarter of the slice's k-steps
+    const int64_t kbeg = (int64_t)slice * kper;
+    int64_t kend = kbeg + kper;
+    if (kend > Bp) kend = Bp;
+    const int64_t s0 = kbeg / KS, s1 = kend / KS;
+    const int64_t nq = (s1 - s0 + 3) / 4;
+    int64_t sbeg = s0 + (int64_t)wave * nq, send = sbeg + nq;
+    if (send > s1) send = s1;
+    if (sbeg > send) sbeg = send;
+    gptr ap[NA], bp[NB];
+    // NA == 4: wave w holds the A tiles rotated by w (local row i = A tile (i + w) % 4), so that "the row this wave finishes and
+    // stores" is local row 0 for every wave and the reduce-scatter below is ONE instruction stream with compile-time register indices
+    const int rot = NA == 4 ? wave : 0;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) { const void* q = NA == 4 ? bdg->At[(k + rot) & 3] : bd.At[k]; ap[k] = (gptr)(uintptr_t)(q ? q : bd.At[0]); }   // dynamic index: from the global copy (a scalar load), not a private-memory copy of bd
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bp[k] = (gptr)(uintptr_t)(bd.Bt[k] ? bd.Bt[k] : bd.Bt[0]);
+    const int64_t plb = spl * (int64_t)sizeof(T);                          // bytes between the hi and lo planes
+    const unsigned loff = (unsigned)lane * 16u;
+    f32x16 c[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    Frag a[RD][NA][NP], b[RD][NB][NP];
+    auto load = [&](auto sc, int64_t sk) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        const int64_t o = sk * FBB;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            a[s][k][0] = *(gfrag)(ap[k] + o + loff);
+            if constexpr (NP == 2) a[s][k][1] = *(gfrag)(ap[k] + plb + o + loff);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            b[s][k][0] = *(gfrag)(bp[k] + o + loff);
+            if constexpr (NP == 2) b[s][k][1] = *(gfrag)(bp[k] + plb + o + loff);
+        }
+    };
+    auto fsum = [&](const Frag& f) __attribute__((always_inline)) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < E; ++q) t += (float)f[q];
+        return t;
+    };
+    auto compute = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j]);
+            bs[i] += fsum(a[s][i][0]);                                   // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
+            if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+        }
+    };
+    // No branch around the loop (an empty range runs zero laps; its clamped prologue loads re-read the slice's last k-step): a
+    // conditional region here makes every accumulator a phi of (zero, loop result) and costs a 256-register copy.
+    {
+        const int64_t slast = (send > s0 ? send : s0 + 1) - 1;
+        static_for_w<0, RD>([&](auto sc) {
+            int64_t sk = sbeg + decltype(sc)::value; sk = sk < slast ? sk : slast;
+            load(sc, sk);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int64_t sk = sbeg; sk < send; sk += RD) {
+            static_for_w<0, RD>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if (sk + s < send) compute(sc);                         // wave-uniform
+                int64_t sn = sk + RD + s; sn = sn < slast ? sn : slast;     // last lap: a harmless reload, no branch around a load
+                load(sc, sn);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    }
+    // ---- the four partial blocks meet in LDS: a reduce-scatter in a fixed order (deterministic).  Wave w ends up with A tile row
+    // w of the block (its local row 0) and stores it: a single wave storing 8 tiles with per-element address arithmetic took
+    // 17 us (issue-bound), more than the main loop.
+    constexpr int ROWQ = 4 * 4 * 64;                                      // f32x4 quads of one A row (4 tiles x 16 registers x 64 lanes)
+    f32x4* const lds = reinterpret_cast<f32x4*>(wsm);
+    float* const lbias = reinterpret_cast<float*>(lds + 8 * ROWQ);        // [dest wave][source order][lane]
+    auto put_row = [&](auto ic, int slot) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                lds[slot * ROWQ + (j * 4 + q) * 64 + lane] = f32x4{c[i][j][4 * q], c[i][j][4 * q + 1], c[i][j][4 * q + 2], c[i][j][4 * q + 3]};
+    };
+    auto add_row0 = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = lds[slot * ROWQ + (j * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[0][j][4 * q + e] += v[e];
+            }
+    };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3;
+    if constexpr (NA == 1) {
+        // one A row: waves 1-3 hand it to wave 0
+        if (wave != 0) { put_row(I0{}, wave); lbias[wave * 64 + lane] = bs[0]; }
+        __syncthreads();
+        if (wave != 0) return;
+        add_row0(1); add_row0(2); add_row0(3);
+        bs[0] += lbias[64 + lane]; bs[0] += lbias[128 + lane]; bs[0] += lbias[192 + lane];
+    } else {
+        // round A: local rows 1, 2 go to waves (w + 1) % 4, (w + 2) % 4 (slot = 2 * destination + source order); round B: local row 3
+        const int d1 = (wave + 1) & 3, d2 = (wave + 2) & 3, d3 = (wave + 3) & 3;
+        put_row(I1{}, 2 * d1); put_row(I2{}, 2 * d2 + 1);
+        lbias[(3 * d1 + 0) * 64 + lane] = bs[1]; lbias[(3 * d2 + 1) * 64 + lane] = bs[2]; lbias[(3 * d3 + 2) * 64 + lane] = bs[3];
+        __syncthreads();
+        add_row0(2 * wave); add_row0(2 * wave + 1);                         // from wave (w - 1) % 4, then from wave (w - 2) % 4
+        __syncthreads();
+        put_row(I3{}, d3);
+        __syncthreads();
+        add_row0(wave);                                                   // from wave (w - 3) % 4
+        bs[0] += lbias[(3 * wave + 0) * 64 + lane]; bs[0] += lbias[(3 * wave + 1) * 64 + lane]; bs[0] += lbias[(3 * wave + 2) * 64 + lane];
+    }
+    // ---- store local row 0 = A tile `rot` of the block (descriptor fields of that tile: wave-uniform scalar loads)
+    float* const slab = slabs + (int64_t)slice * slab_stride;
+    const int mv = bdg->mvalid[rot], ldo = bdg->ldo[rot];
+    const int64_t a_off = bdg->a_off[rot], bias_off = bdg->bias_off[rot];
+    const bool split = rot == 0 && bd.split16;
+    if (mv == 32 && !split) {
+        // full tile rows: one exec region per tile, scalar row address + a per-lane 32-bit offset
+        const unsigned lo = (unsigned)(4 * h * ldo + l31);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (l31 < bd.nvalid[j]) {
+                float* const t0 = slab + a_off + bd.bcol[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* const rowp = t0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ldo;     // wave-uniform
+                    rowp[lo] = c[0][j][r];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = feat_of(r, h);
+                if (row < mv && l31 < bd.nvalid[j]) {
+                    const bool hi = split && row >= 16;
+                    const int rr = hi ? row - 16 : row;
+                    const int ld = hi ? bd.ldo_hi : ldo;
+                    slab[(hi ? bd.a_off_hi : a_off) + (int64_t)rr * ld + bd.bcol[j] + l31] = c[0][j][r];
+                }
+            }
+        }
+    }
+    const float tot = bs[0] + __shfl_xor(bs[0], 32, 64);                  // the two frame halves of feature row l31
+    if (h == 0 && l31 < mv && bias_off >= 0) {
+        const bool hi = split && l31 >= 16;
+        slab[hi ? bd.bias_off_hi + (l31 - 16) : bias_off + l31] = tot;
+    }
+}
+
+template <typename P>
+__global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
+                                                        int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slice = blockIdx.x % ksplit, bi = blockIdx.x / ksplit;
+    if (bi >= nblocks) return;
+    const Block4 bd = blocks[bi];                                       // by value: wave-uniform, lives in SGPRs (a reference would be re-read after every slab store)
+    int na = 0, nb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (bd.At[k] != nullptr) na = k + 1; if (bd.Bt[k] != nullptr) nb = k + 1; }
+    if (na == 1) {
+        if (nb == 1) wgrad4_body<P, 1, 1>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+        else if (nb == 2) wgrad4_body<P, 1, 2>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+        else wgrad4_body<P, 1, 4>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+    } else {
+        if (nb == 1) wgrad4_body<P, 4, 1>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+        else if (nb == 2) wgrad4_body<P, 4, 2>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+        else wgrad4_body<P, 4, 4>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+    }
+}
+
 // dst = (accumulate ? dst : 0) + sum of the slabs (fixed order: deterministic)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride, float* __restrict__ dst, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -963,15 +1205,20 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     float m_old = 0.f, v_old = 0.f, gi = 0.f;
     if (ADAM) {
         m_old = g.m[idx]; v_old = g.v[idx];
-        constexpr int NS = 8;
-        if (g.nslabs <= NS) {
+        auto sum_slabs = [&](auto nsc) __attribute__((always_inline)) {
+            constexpr int NS = decltype(nsc)::value;
             float part[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) part[k] = g.slabs[(k < g.nslabs ? k : 0) * g.slab_stride + idx];   // independent loads
-            gi = part[0];
+            float t = part[0];
 #pragma unroll
-            for (int k = 1; k < NS; ++k) if (k < g.nslabs) gi += part[k];                                    // fixed order: deterministic
-        } else {
+            for (int k = 1; k < NS; ++k) if (k < g.nslabs) t += part[k];                                    // fixed order: deterministic
+            return t;
+        };
+        if (g.nslabs <= 8) gi = sum_slabs(std::integral_constant<int, 8>{});
+        else if (g.nslabs <= 12) gi = sum_slabs(std::integral_constant<int, 12>{});
+        else if (g.nslabs <= 16) gi = sum_slabs(std::integral_constant<int, 16>{});
+        else {
             gi = g.slabs[idx];
             for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
         }
@@ -1022,7 +1269,7 @@ struct Layout {
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
-    int64_t o_tiles, o_blocks, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
+    int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
     int ntiles, nblocks;
 };
 
@@ -1073,6 +1320,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     auto bytes = [&](int64_t n) { int64_t q = b; b += al(n, 256); return q; };
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_blocks = bytes((int64_t)L.nblocks * sizeof(BlockDesc));
+    L.o_blocks4 = bytes((int64_t)L.nblocks * sizeof(Block4));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
@@ -1117,6 +1365,14 @@ struct ProfScope {
 using namespace dvae;
 using namespace dvae::fused;
 
+// weight-gradient kernel form: 4 = workgroup k-split 4 x 4 blocks (default), 2 = 2 x 2 register ring (DVAE_WGRAD=ring),
+// 1 = LDS-staged 4 x 4 blocks (DVAE_WGRAD=lds; bf16 policies only)
+static int wgrad_form(const char* wk) {
+    if (wk && strcmp(wk, "ring") == 0) return 2;
+    if (wk && strcmp(wk, "lds") == 0) return 1;
+    return 4;
+}
+
 extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_hint, dvae_train_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr && B > 0, "train_plan: bad argument");
     if (!((model == DVAE_MODEL_M1 && y_dim == 0) || (model == DVAE_MODEL_M2 && (y_dim == 1 || y_dim == 513)) ||
@@ -1154,6 +1410,22 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     // bf16: 8 slices up to 8192 frames (more slices = more slabs for the apply pass to sum); 12 beyond: 80 groups x 12 = 960
     // single-wave jobs fill the 1024 wave slots in one round (wgrad 164 -> 124 us at 65 536 frames, 2.49 -> 1.80 ms at 2^20).
     // fp32: the MFMA-bound wgrad needs a wave on every SIMD (>= 1024 wave jobs): 16.
+    if (ks <= 0 && wgrad_form(getenv("DVAE_WGRAD")) == 4) {
+        // workgroup k-split kernel: one workgroup per (4 x 4 tile block, frame slice) and per CU: as many slices as fill the 256 CUs
+        // in one round (M2 y513: 22 blocks x 11), at least 128 frames (two k-steps per wave) each, at most 16 (the apply pass sums them)
+        dvae_train_plan_t tmp = *plan;
+        tmp.ksplit = 1;
+        Layout L0;
+        make_layout(tmp, L0);
+        ks = 256 / L0.nblocks;
+        // bf16 policies are bound by the cold read of the stash: keep every slice on ONE XCD (workgroup i runs on XCD i % 8 and
+        // slice = i % ks), so that each stash line crosses the fabric once -- a multiple of 8 slices (M2 y513: 8 x 22 workgroups
+        // 28.5 us, 11 x 22 33.9 us under bf16x3).  The fp32 policy is MFMA-bound: as many workgroups as CUs (59 us at 11 slices, 71 at 8).
+        if (is_bf(precision) && ks >= 8) ks = ks / 8 * 8;
+        if (ks > plan->Bp / 128) ks = (int)(plan->Bp / 128);
+        if (ks > 16) ks = 16;
+        if (ks < 1) ks = 1;
+    }
     if (ks <= 0) {
         // bf16x3: a wave issues 16 MFMAs per k-step (3 per tile product), ~15.6 us of matrix time per 1024-frame slice on its own SIMD, and
         // 80 groups x 8 slices fill only 640 of the 1024 SIMDs: 12 slices (960 waves) take 3.3 us off the kernel and add 1.7 us of slab sums
@@ -1190,7 +1462,7 @@ struct ABlock { int64_t row; int mvalid; int tensor; int m0; int bias_tensor; in
 struct BBlock { int64_t row; int nvalid; int col; };
 
 template <typename T>
-static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, GroupDesc* groups, BlockDesc* blocks, TensorDesc* td) {
+static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, GroupDesc* groups, BlockDesc* blocks, Block4* blocks4, TensorDesc* td) {
     const int64_t Bp = p->Bp;
     T* stash = (T*)(ws_dev + L.o_stash);
     auto S = [&](int64_t row) { return (const void*)(stash + row * Bp); };
@@ -1249,6 +1521,31 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
                 }
                 for (int wr = 0; wr < 2; ++wr)
                     for (int wc = 0; wc < 2; ++wc) b.g[wr * 2 + wc] = make_group(i0 + 2 * wr, j0 + 2 * wc);
+                Block4 q;
+                memset(&q, 0, sizeof(q));
+                for (int k = 0; k < 4; ++k) {
+                    q.bias_off[k] = -1;
+                    if (i0 + k < na) {
+                        const ABlock& a = ab[i0 + k];
+                        q.At[k] = S(a.row);
+                        q.ldo[k] = p->tensor_cols[a.tensor];
+                        q.a_off[k] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * q.ldo[k];
+                        q.mvalid[k] = a.mvalid;
+                        if (a.bias_tensor >= 0 && j0 == 0) q.bias_off[k] = p->tensor_offset[a.bias_tensor] + a.m0;
+                        if (k == 0 && a.tensor_hi >= 0) {
+                            q.split16 = 1;
+                            q.ldo_hi = p->tensor_cols[a.tensor_hi];
+                            q.a_off_hi = p->tensor_offset[a.tensor_hi];
+                            q.bias_off_hi = p->tensor_offset[a.bias_hi];
+                        }
+                    }
+                    if (j0 + k < nb) {
+                        q.Bt[k] = S(bb[j0 + k].row);
+                        q.bcol[k] = bb[j0 + k].col;
+                        q.nvalid[k] = bb[j0 + k].nvalid;
+                    }
+                }
+                blocks4[nblk] = q;
                 blocks[nblk++] = b;
             }
         na = 0; nb = 0;
@@ -1344,13 +1641,15 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     DVAE_HIP(hipMemsetAsync(w, 0, (size_t)L.total, s));
     GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
     BlockDesc* blocks = new BlockDesc[L.nblocks + 8];
+    Block4* blocks4 = new Block4[L.nblocks + 8];
     TensorDesc td[DVAE_TRAIN_MAX_TENSORS];
     memset(td, 0, sizeof(td));
-    if (is_bf(plan->precision)) fill_tables<__bf16>(plan, L, w, tiles, blocks, td);
-    else fill_tables<float>(plan, L, w, tiles, blocks, td);
+    if (is_bf(plan->precision)) fill_tables<__bf16>(plan, L, w, tiles, blocks, blocks4, td);
+    else fill_tables<float>(plan, L, w, tiles, blocks, blocks4, td);
     hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(GroupDesc), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
     hipError_t e5 = hipMemcpyAsync(w + L.o_blocks, blocks, (size_t)L.nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, s);
+    hipError_t e6 = hipMemcpyAsync(w + L.o_blocks4, blocks4, (size_t)L.nblocks * sizeof(Block4), hipMemcpyHostToDevice, s);
     const int64_t nchunks = plan->n_params / 64;
     unsigned char* ct = new unsigned char[nchunks + 64];
     memset(ct, 255, (size_t)nchunks + 64);
@@ -1362,8 +1661,9 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipError_t e3 = hipStreamSynchronize(s);
     delete[] tiles;
     delete[] blocks;
+    delete[] blocks4;
     delete[] ct;
-    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e3);
+    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e6); DVAE_HIP(e3);
     return dvae_train_repack(plan, params, ws, stream);
 }
 
@@ -1474,7 +1774,26 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     int wrep = 1;
     { const char* e = getenv("DVAE_WGRAD_REPEAT"); if (e) { wrep = atoi(e); if (wrep < 1) wrep = 1; } }   // diagnostic: re-run on the warm stash
     for (int rep = 0; rep < wrep; ++rep)
-    if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
+    if (wgrad_form(wk) == 4) {
+        ProfScope ps(s, rep == 0 ? 1 : 2);
+        const dim3 g3((unsigned)(L.nblocks * ks));
+        static bool attr_done[64][3] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) dev = 0;
+        const int pi = x3 ? 2 : (bf ? 1 : 0);
+        if (!attr_done[dev][pi]) {
+            if (x3) DVAE_HIP(hipFuncSetAttribute((const void*)wgrad4_kernel<PolX3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg4<PolX3>::BYTES));
+            else if (bf) DVAE_HIP(hipFuncSetAttribute((const void*)wgrad4_kernel<PolBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg4<PolBF16>::BYTES));
+            else DVAE_HIP(hipFuncSetAttribute((const void*)wgrad4_kernel<PolF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg4<PolF32>::BYTES));
+            attr_done[dev][pi] = true;
+        }
+        const Block4* bl = (const Block4*)(w + L.o_blocks4);
+        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        DVAE_LAUNCH_OK("wgrad4_kernel");
+    } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
         const dim3 g3((unsigned)(L.nblocks * ks));
         static bool attr_done[64][2] = {};
