@@ -148,13 +148,20 @@ class McemBatch:
     one chain launch, three M-step launches, whatever the number of utterances.
 
     vae: a packages.models VAE (encoder / decoder / z_dim).  label_in_encoder / label_in_decoder select the
-    reference variant: MCEM_M1 (False, False), MCEM_M2 (True, True), MCEM_M2v2 / M2v3 (False, True).
+    reference variant: MCEM_M1 (False, False), MCEM_M2 (True, True), MCEM_M2v2 / M2v3 (False, True).  For the M1 variant the
+    chain lengths follow what the reference actually runs (its argument-shift quirk, see __init__).
     """
 
     def __init__(self, vae, niter=100, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, var_RW=0.01,
-                 nmf_rank=10, eps=2.220446049250313e-16, label_in_encoder=True, label_in_decoder=True, precision="fp32"):
+                 nmf_rank=10, eps=2.220446049250313e-16, label_in_encoder=True, label_in_decoder=True, precision="fp32",
+                 reference_m1_counts=True):
         self.vae, self.niter = vae, niter
         self.n_e, self.b_e, self.n_wf, self.b_wf = nsamples_E_step, burnin_E_step, nsamples_WF, burnin_WF
+        if reference_m1_counts and not label_in_encoder and not label_in_decoder:
+            # MCEM_M1 passes (Z, nsamples, burnin) positionally into sample_posterior(Z, y, nsamples=10, burnin=30)
+            # (reference mcem.py:207, 297-298, 314-315): the chain it actually runs keeps `burnin` samples after the
+            # default burn-in of 30.  Same chain lengths here (reference_m1_counts=False: the lengths as written).
+            self.n_e, self.b_e, self.n_wf, self.b_wf = burnin_E_step, 30, burnin_WF, 30
         self.var_RW, self.K, self.eps = var_RW, nmf_rank, eps
         self.label_in_encoder, self.label_in_decoder = label_in_encoder, label_in_decoder
         self.precision = precision

@@ -312,9 +312,13 @@ class Trainer:
         """rows + wgrad kernels without the optimiser (tests / gradient inspection)."""
         self._check_inputs(x, y, None, eps_noise)
         self._sync_copies()
+        x = x if x.stride(1) == 1 else x.contiguous()
+        if self.y_dim:
+            y = y if y.stride(1) == 1 else y.contiguous()
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
-        N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
-                                          N.ptr(eps_noise.contiguous()), self.elbo_eps, 1 if reduce else 0, N.stream()), "dvae_train_grads")
+        with torch.cuda.device(self.device):
+            N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
+                                              N.ptr(eps_noise.contiguous()), self.elbo_eps, 1 if reduce else 0, N.stream()), "dvae_train_grads")
         self._reduced = bool(reduce)
 
     # ---- per-kernel device time (hipEvents on the launch stream) ----

@@ -80,3 +80,17 @@ def test_m_step_and_wiener_alone(case):
     np.testing.assert_allclose(H1, fix["H"][0], rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(g1, fix["g"][0], rtol=2e-4)
     np.testing.assert_allclose(cost, fix["cost"][0], rtol=1e-5)
+
+
+def test_mcem_batch_runs_the_reference_m1_chain_lengths():
+    """McemBatch mirrors MCEM_M1's argument shift (reference mcem.py:207, 297-298, 314-315): nsamples <- burnin, burnin <- 30."""
+    import importlib
+    dev = importlib.import_module("disentangled-vae_amd.mcem")
+    case = dict(model="M1", n_e=10, b_e=30, n_wf=25, b_wf=75)
+    mb = dev.McemBatch(None, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, label_in_encoder=False, label_in_decoder=False)
+    assert (mb.n_e, mb.b_e, mb.n_wf, mb.b_wf) == mc.effective_counts(case)
+    mb = dev.McemBatch(None, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, label_in_encoder=False, label_in_decoder=False,
+                       reference_m1_counts=False)
+    assert (mb.n_e, mb.b_e, mb.n_wf, mb.b_wf) == (10, 30, 25, 75)
+    mb = dev.McemBatch(None, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75)          # M2: as written
+    assert (mb.n_e, mb.b_e, mb.n_wf, mb.b_wf) == mc.effective_counts(dict(model="M2", n_e=10, b_e=30, n_wf=25, b_wf=75))

@@ -12,6 +12,11 @@ tr = T.Trainer("M2", dims, None, batch=B, precision=prec, seed=0)
 x, y, e = (torch.from_numpy(a).cuda() for a in gu.make_batch(dims, B, 1))
 run = (lambda: tr.grads_only(x, y, e)) if noapply else (lambda: tr.step(x, y, e))
 for _ in range(5): run()
+if os.environ.get("DVAE_COLD"):      # inputs cold in HBM, as in bench.py: cycle through a > 1 GB pool before the stamped step
+    pool = [(torch.rand_like(x) * 3 + 1e-3, (torch.rand_like(y) > 0.5).float(), torch.randn_like(e)) for _ in range(36)]
+    for (px, py, pe) in pool: tr.step(px, py, pe)
+    x, y, e = pool[0]
+    run = (lambda: tr.grads_only(x, y, e)) if noapply else (lambda: tr.step(x, y, e))
 buf = torch.zeros(tr.plan.rows_grid * 32, dtype=torch.int64, device="cuda")
 N.load().dvae_train_debug_stamps(N.ptr(buf)); run(); torch.cuda.synchronize(); N.load().dvae_train_debug_stamps(None)
 s = buf.cpu().numpy().reshape(-1, 32)[:, :16].astype(np.float64) * 0.01      # us
