@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
             for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
         }
     }
-    const int t = g.chunk_tensor[idx >> 6];
+    // a wave covers one 64-float chunk: its tensor and the descriptor are wave-uniform, fetched by scalar loads
+    const int t = g.chunk_tensor[__builtin_amdgcn_readfirstlane((int)(idx >> 6))];
     if (t == 255) return;
     const TensorDesc d = g.tensors[t];
     const int64_t i = idx - d.off;
