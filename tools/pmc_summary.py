@@ -6,7 +6,7 @@
 import csv, glob, json, sys
 from collections import defaultdict
 
-KEYS = ("vae_rows2_kernel", "vae_rows_kernel", "wgrad_lds_kernel", "wgrad_kernel", "apply_kernel", "slab_sum_kernel", "slab_reduce_kernel", "elbo")
+KEYS = ("vae_rows2_kernel", "vae_rows_kernel", "wgrad4_kernel", "wgrad_lds_kernel", "wgrad_kernel", "apply_kernel", "slab_sum_kernel", "slab_reduce_kernel", "elbo")
 
 
 def short(name):
