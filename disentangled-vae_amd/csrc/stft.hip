@@ -369,6 +369,172 @@ __global__ __launch_bounds__(256) void istft1024_frames_kernel(const float2* __r
     }
 }
 
+// nfft = 1024, hop = 256 (every caller of the reference): inverse FFT AND overlap-add in one kernel, no frame scratch.
+// The two-kernel form above writes every windowed frame to HBM in double (8 KB per frame: 307 MB for ten minutes of audio) and
+// gathers it back; here a workgroup owns a chunk of IF_K consecutive frames and the IF_K * 256 output samples they complete.
+// It computes the chunk's frames plus the three frames in front of it (whose tails reach into the chunk: 10 % more FFTs, no
+// exchange between workgroups), one wave per frame, four consecutive frames per round; after each round the four frames sit in
+// LDS and all 256 threads add them into the chunk's float output image IN FRAME ORDER with one float rounding per addition --
+// exactly the arithmetic of librosa's in-place `y[...] += ytmp` and of istft_ola_kernel (the results are bit-identical).
+// Chunk sizes: NPASS staging passes of IF_FR frames (one 8 * IF_FR-byte run per bin), three of the frames halo; short
+// utterances take small chunks so that the launch still covers the CUs.  The next pass's S values are requested into registers
+// before the current pass's FFT rounds and committed to LDS after them.
+constexpr int IF_H = 3;
+template <int IF_FR, int NPASS> struct IstftFusedLds {
+    static constexpr int R = NPASS * IF_FR, K = R - IF_H;   // frames computed / owned per chunk
+    static constexpr int ACC = R * 256 + 768;                  // floats of the output image: frame R - 1 ends at (R - 1) * 256 + 1023
+    double ex[4][1152];                                        // per wave: FFT exchange buffers (re: 576, im: 576), then its windowed frame (1024)
+    float2 stage[513][IF_FR + 1];                           // IF_FR frames of S, one (8 * IF_FR)-byte run per bin
+    float acc[ACC];
+    float wss4[256];                                           // window sum of squares of a sample covered by four frames, by src mod hop
+};
+template <int IF_FR, int NPASS>
+__global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __restrict__ S, int64_t T, int64_t ldT,
+                                                              const double* __restrict__ window, int64_t start,
+                                                              float* __restrict__ y, int64_t out_len) {
+    typedef IstftFusedLds<IF_FR, NPASS> LT;
+    constexpr int M = 512, F = 513, HOP = 256, NF = 1024, IF_K = LT::K, IF_ACC = LT::ACC;
+    constexpr int NPRE = (F * IF_FR + 255) / 256;              // staged values per thread and pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LT& L = *reinterpret_cast<LT*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* re = L.ex[wave];
+    double* im = L.ex[wave] + 576;
+    double wa[8], wb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)] * (1.0 / M); wb[r] = window[2 * (lane + 64 * r) + 1] * (1.0 / M); }
+    Fft512 fft;
+    fft.init(lane);
+    double sr[8], si[8];                                          // exp(+2 pi i k / 1024), k = lane + 64 r
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sincospi(2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);
+    const int64_t ntot = (int64_t)NF + (int64_t)HOP * (T - 1);
+    const int64_t nchunks = (T + IF_K - 1) / IF_K;
+    {   // frames in ascending order: window positions m0 + 768, + 512, + 256, + 0; float rounding after every addition (as the generic loop)
+        float w4 = 0.f;
+#pragma unroll
+        for (int f = 3; f >= 0; --f) { const double w = window[tid + f * HOP]; w4 = (float)((double)w4 + w * w); }
+        L.wss4[tid] = w4;
+    }
+    float2 pre[NPRE];
+    auto request = [&](int64_t ts) __attribute__((always_inline)) {   // eight frames starting at ts (frames outside [0, T): zeros)
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = tid + 256 * u;
+            const int f = idx / IF_FR, q = idx - f * IF_FR;
+            const int64_t t = ts + q;
+            pre[u] = (idx < F * IF_FR && t >= 0 && t < T) ? S[(int64_t)f * ldT + t] : float2{0.f, 0.f};
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int idx = tid + 256 * u;
+            const int f = idx / IF_FR, q = idx - f * IF_FR;
+            if (idx < F * IF_FR) L.stage[f][q] = pre[u];
+        }
+    };
+    if ((int64_t)blockIdx.x < nchunks) request((int64_t)blockIdx.x * IF_K - IF_H);
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t t0 = c * IF_K, tb = t0 - IF_H;              // first own frame, first computed frame (may be < 0)
+        __syncthreads();                                          // the previous chunk's output pass is done with acc
+        for (int i = tid; i < IF_ACC; i += 256) L.acc[i] = 0.f;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int64_t ts = tb + (int64_t)pass * IF_FR;     // first frame of this staging pass
+            commit();                                             // every reader of `stage` passed the barrier that closed the last round
+            __syncthreads();
+            // next pass (of this chunk or of this workgroup's next chunk): in flight during the FFT rounds
+            if (pass + 1 < NPASS) request(ts + IF_FR);
+            else if (c + gridDim.x < nchunks) request((c + gridDim.x) * IF_K - IF_H);
+            for (int rr = 0; rr < IF_FR / 4; ++rr) {
+                const int q = 4 * rr + wave;
+                const int64_t t = ts + q;
+                const bool valid = t >= 0 && t < T;               // wave-uniform
+                if (valid) {
+                    cd v[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int k = lane + 64 * r;
+                        const float2 a = L.stage[k][q], b = L.stage[M - k][q];
+                        cd xk = cd{(double)a.x, (double)a.y}, xc = cd{(double)b.x, -(double)b.y};   // X[k], conj(X[M-k])
+                        if (k == 0) { xk.y = 0.0; xc.y = 0.0; }                                      // C2R ignores imag of DC / Nyquist
+                        const cd e = cd{0.5 * (xk.x + xc.x), 0.5 * (xk.y + xc.y)};
+                        const cd o = cmulc(cd{0.5 * (xk.x - xc.x), 0.5 * (xk.y - xc.y)}, sr[r], si[r]);
+                        v[r] = cd{e.x - o.y, -(e.y + o.x)};       // conj(E + i O)
+                    }
+                    fft.run(v, re, im, lane);
+                    __builtin_amdgcn_wave_barrier();              // every lane has read its pass-2 inputs: the buffer becomes the frame
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int i = lane + 64 * r;
+                        reinterpret_cast<double2*>(L.ex[wave])[i] = double2{wa[r] * v[r].x, -wb[r] * v[r].y};   // conj, 1/M folded into the window
+                    }
+                }
+                __syncthreads();                                  // the round's four frames are in LDS
+                // overlap-add of frames ts + 4 rr .. + 3, in frame order, one float rounding per addition
+                const int j0 = pass * IF_FR + 4 * rr;          // index of the round's first frame in the chunk
+#pragma unroll
+                for (int sidx0 = 0; sidx0 < 3 * HOP + NF; sidx0 += 256) {     // seven independent chains per thread (the float <-> double conversions are slow and dependent)
+                    const int sidx = sidx0 + tid;
+                    float a = L.acc[j0 * HOP + sidx];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int m = sidx - f * HOP;
+                        const int64_t tf = ts + 4 * rr + f;
+                        if (m >= 0 && m < NF && tf >= 0 && tf < T) a = (float)((double)a + L.ex[f][m]);
+                    }
+                    L.acc[j0 * HOP + sidx] = a;
+                }
+                __syncthreads();                                  // before the next round reuses the exchange buffers (and `stage`, after the last round)
+            }
+        }
+        // output: the samples this chunk completes (the last chunk also owns everything behind its frames)
+        const int64_t s_lo = t0 * HOP;
+        const bool last = c == nchunks - 1;
+        const int64_t s_hi = last ? start + out_len : (t0 + IF_K) * HOP;
+        for (int64_t src = s_lo + tid; src < s_hi; src += 256) {
+            const int64_t i = src - start;
+            if (i < 0 || i >= out_len) continue;
+            float a = 0.f, wss = 0.f;
+            if (src < ntot) {
+                a = L.acc[src - tb * HOP];
+                if (src >= NF - HOP && src / HOP <= T - 1) wss = L.wss4[src & (HOP - 1)];   // covered by four frames: the window sum depends on src mod hop only
+                else {
+                    int64_t tlo = (src - NF + HOP) / HOP;
+                    if (src < NF) tlo = 0;
+                    int64_t thi = src / HOP;
+                    if (thi > T - 1) thi = T - 1;
+                    for (int64_t t = tlo; t <= thi; ++t) {
+                        const int m = (int)(src - t * HOP);
+                        wss = (float)((double)wss + window[m] * window[m]);
+                    }
+                }
+                if (wss > FLT_MIN) a = a / wss;
+            }
+            y[i] = a;
+        }
+    }
+}
+
+template <int IF_FR, int NPASS>
+static int launch_istft_fused(const float2* S, int64_t T, int64_t ldT, const double* window, int64_t start, float* y, int64_t out_len, hipStream_t s) {
+    typedef IstftFusedLds<IF_FR, NPASS> LT;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        DVAE_HIP(hipFuncSetAttribute((const void*)(istft1024_fused_kernel<IF_FR, NPASS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LT)));
+        attr_done[dev] = true;
+    }
+    const int64_t nchunks = cdiv(T, LT::K);
+    const int per_cu = sizeof(LT) <= 80 * 1024 ? 2 : 1;           // workgroups resident per CU (LDS)
+    const int wb = (int)(nchunks < 256 * per_cu ? nchunks : 256 * per_cu);
+    hipLaunchKernelGGL((istft1024_fused_kernel<IF_FR, NPASS>), dim3(wb), dim3(256), sizeof(LT), s, S, T, ldT, window, start, y, out_len);
+    DVAE_LAUNCH_OK("istft1024_fused_kernel");
+    return 0;
+}
+
 // frames[t][m] = window[m] * irfft(S[:, t])[m]   (double scratch)
 __global__ __launch_bounds__(256) void istft_frames_pow2_kernel(const float* __restrict__ S, int64_t T, int64_t ldT,
                                                                  const double* __restrict__ window, int nfft, int logM,
@@ -533,6 +699,15 @@ extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* w
     const int blocks = (int)(T < 2048 ? T : 2048);
     const int lg = ilog2_exact(nfft);
     static const bool legacy = getenv("DVAE_STFT_LEGACY") != nullptr;
+    const bool two_pass = getenv("DVAE_ISTFT_2PASS") != nullptr;             // A/B switch (read per call): frames to scratch + gather overlap-add
+    if (nfft == 1024 && hop == 256 && !legacy && !two_pass) {
+        if (out_len == 0) return 0;
+        // chunk size by length: enough chunks to cover the CUs first, then the least halo work (3 of 8 / 16 / 32 frames)
+        // chunk size by length: enough chunks to cover the CUs first, then wider runs per bin and less halo work (3 of 8 / 16 / 32 frames)
+        if (T <= 5 * 512) return launch_istft_fused<8, 1>((const float2*)S, T, ldT, window, start, y, out_len, s);
+        if (T <= 13 * 512) return launch_istft_fused<16, 1>((const float2*)S, T, ldT, window, start, y, out_len, s);
+        return launch_istft_fused<16, 2>((const float2*)S, T, ldT, window, start, y, out_len, s);
+    }
     if (nfft == 1024 && !legacy) {
         const size_t lds = (size_t)513 * (ISTFT_FR + 1) * sizeof(float2);
         static bool attr_done = false;

@@ -1,5 +1,6 @@
 """GPU parity of STFT / ISTFT (packages.processing.stft on the HIP path) against the numpy
 oracle, the reference's own HDF5 power frames, and round-trip properties."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -148,3 +149,22 @@ def test_long_audio_many_frames_per_wave(dtype):
     y = ps.istft(got, max_len=n, **KW)
     lo, hi = 1024, n - 1280
     np.testing.assert_allclose(y[lo:hi], x[lo:hi].astype(np.float32), atol=2e-5 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("n,center", [(300, False), (16000, False), (73045, True), (16000 * 90, False)])
+def test_istft_fused_overlap_add_equals_two_pass_bitwise(n, center):
+    """The one-kernel ISTFT (inverse FFT + overlap-add in LDS, frame order, one float rounding per addition) gives the very
+    bits of the frames-to-scratch + gather form (DVAE_ISTFT_2PASS), chunk borders, halo frames and the tail included."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(max(n, 1024))
+    kw = dict(fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=center)
+    S = so.stft(x, **kw)
+    for max_len in (None, len(x), len(x) + 5000, max(len(x) - 700, 1)):
+        fused = ps.istft(S, max_len=max_len, **kw)
+        os.environ["DVAE_ISTFT_2PASS"] = "1"
+        try:
+            two = ps.istft(S, max_len=max_len, **kw)
+        finally:
+            del os.environ["DVAE_ISTFT_2PASS"]
+        assert fused.shape == two.shape and fused.dtype == two.dtype == np.float32
+        assert np.array_equal(fused.view(np.uint32), two.view(np.uint32))
