@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip parity_mode / spread / b128 (they run outside the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--prewarm-ms", type=float, default=200.0,
+                    help="untimed train steps for this long BEFORE the W warmup steps, so that the K timed steps run at the clocks a training run "
+                         "sees (from idle the shader clock needs tens of ms of load to settle: 20 steps right after 5 measure 87.6 us/step, "
+                         "the same 20 steps after 200 ms of steps 80); reported as `prewarm_steps`; 0 disables")
     return ap.parse_args()
 
 
@@ -232,6 +236,21 @@ def main():
     else:
         impl = ModulesImpl(a.model, dims, device, world)
 
+    prewarm_steps = 0
+    if a.prewarm_ms > 0:                                                            # untimed: bring the GPU to its sustained clocks
+        torch.cuda.synchronize()
+        t_pw = time.perf_counter()
+        while True:
+            for i in range(50):
+                impl.step(*batches[(prewarm_steps + i) % nb])
+            prewarm_steps += 50
+            torch.cuda.synchronize()
+            go = torch.tensor([1 if (time.perf_counter() - t_pw) * 1e3 < a.prewarm_ms else 0], dtype=torch.int32,
+                              device=device if backend in (None, "nccl") else "cpu")
+            if dist is not None:
+                dist.broadcast(go, src=0)                                           # every rank makes the same number of steps (they all-reduce)
+            if int(go.item()) == 0:
+                break
     for i in range(a.warmup):
         impl.step(*batches[i % nb])
     dt, last = timed_steps(impl, batches, a.warmup, a.steps, dist, device)          # THE timed region: exactly K steps
@@ -253,6 +272,7 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
+        "prewarm_steps": prewarm_steps,
         "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True,
         "scaling": "weak",
