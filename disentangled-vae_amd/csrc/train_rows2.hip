@@ -109,7 +109,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         ws.pl = g.wpl_bytes;
         {
             auto mo = [&](const void* Wp) { return (unsigned)((const char*)Wp - (const char*)g.wcopy); };
+#ifdef R2_SAMEW
+            const unsigned tw = 0;                                            // diagnostic: every chain wave streams the SAME fragments (3 of 4 loads hit L1)
+#else
             const unsigned tw = (unsigned)cw * FBB;                          // this wave's row tile in the 4-tile matrices
+#endif
             constexpr unsigned KB1 = (XP / KS) * 4 * FBB, KB3 = (ZD / KS) * 4 * FBB;   // label k-blocks behind the x / z blocks of W1 / W3
             ws.sb[G_W1X] = mo(g.W1s) + tw;  ws.sb[G_W1Y] = mo(g.W1s) + tw + KB1;
             ws.sb[G_W2] = mo(g.W2s) + tw;   ws.sb[G_WMV] = mo(g.Wmvs);

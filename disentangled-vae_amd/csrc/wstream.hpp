@@ -83,10 +83,18 @@ __device__ __forceinline__ void gemm_seg(f32x16& acc, WS& w, const typename P::T
         static_for<0, N>([&](auto ic) {
             constexpr int I = decltype(ic)::value;
             if (active) {
+#ifndef R2_NOMFMA
                 mmap<P>(acc, w.r[(Q0 + I) % D], bq[I % BD], blo);
+#else
+                acc[0] += (float)w.r[(Q0 + I) % D][0][0] + (float)bq[I % BD][0][0];      // experiment: operands consumed, no MFMA
+#endif
+#ifndef R2_NOBLOAD
                 if constexpr (I + BD < N) bloadp<P>(bq[I % BD], brow + (I + BD) * STR);
+#endif
             }
+#ifndef R2_NOWLOAD
             w.template req<(Q0 + I + D) % SC::total>();
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     }
