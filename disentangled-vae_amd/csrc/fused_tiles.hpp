@@ -147,12 +147,17 @@ struct PolX3 : PolBF16 {
 #ifndef R2_PBIG_BF
 #define R2_PBIG_BF 4
 #endif
+#ifndef R2_PDO_X3
+#define R2_PDO_X3 6
+#endif
 struct PolX3v2 : PolX3 {
+    static constexpr int PDO = R2_PDO_X3;     // ring depth of the train-step instantiation (loss epilogue on the helper waves)
     static constexpr int PD = R2_PD_X3, PRE = R2_PRE_X3, PRE128 = R2_P128_X3, PREBIG = R2_PBIG_X3;   // PD / PRE: the output-layer loop (the register peak)
     static constexpr int DBIG = R2_DBIG_X3, D128 = R2_D128_X3;   // ring depths of the long GEMMs / the 128-deep layers
     static constexpr int BDMAX = R2_BD_X3;
 };
 struct PolBF16v2 : PolBF16 {
+    static constexpr int PDO = R2_PD_BF;
     static constexpr int PD = R2_PD_BF, PRE = R2_PRE_BF, PRE128 = 8, PREBIG = R2_PBIG_BF;
     static constexpr int DBIG = R2_DBIG_BF, D128 = 8;
     static constexpr bool XFULL = false, EARLY_Y = false;

@@ -28,6 +28,7 @@
 //   [C] dec L1 z (Zb), d1 -> Ha    [H] stash z (Zb)                        | BD1
 //   [C] dec L2 (Ha), d2 -> Hb      [H] stash d1 (Ha)                       | BD2
 //   [C] output layer (Hb), loss, da -> U          [H] stash d2 (Hb)        | BDA
+//       (train step under bf16x3: four rounds [C] GEMM of a tile, a -> U raw | RBi | [H] loss terms of the round's tiles, da -> U)
 //   [C] bwd out (U), dpre_d2 -> Hb (over d2)      [H] stash da (U), next gather table     | BDD2
 //   [C] bwd d2 (Hb), dpre_d1 -> Ha (over d1)      [H] stash dpre_d2 (Hb), next x loads issued | BDD1
 //   [C] bwd z (Ha), dmu|dlv -> Zb  [H] stash dpre_d1 (Ha)                  | BDML
@@ -63,6 +64,26 @@ template <typename P> struct Lds2 {
 // between the roles does not exist: the stash is consumed by the NEXT kernel, inputs are read-only.
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Output-layer hand-over between the roles (train step, two operand planes): a chain wave leaves the fp32 pre-activations of its
+// 32 x 32 tile in the tile's OWN columns of U -- upper 16 bits of every value in plane 0, lower 16 bits in plane 1 -- and the partner
+// helper wave turns them in place into the (hi, lo) planes of da.  Same lane, same elements on both sides: no extra LDS.
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+template <typename P>
+__device__ __forceinline__ void put_raw4(const float (&v)[4], typename P::T* lds, int ldl, int col, int l31) {
+    u16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const unsigned b = __float_as_uint(v[j]); hi[j] = (unsigned short)(b >> 16); lo[j] = (unsigned short)(b & 0xffffu); }
+    *reinterpret_cast<u16x4*>(lds + l31 * ldl + col) = hi;
+    *reinterpret_cast<u16x4*>(lds + Pl<P>::lds + l31 * ldl + col) = lo;
+}
+template <typename P>
+__device__ __forceinline__ void get_raw4(float (&v)[4], const typename P::T* lds, int ldl, int col, int l31) {
+    const u16x4 hi = *reinterpret_cast<const u16x4*>(lds + l31 * ldl + col);
+    const u16x4 lo = *reinterpret_cast<const u16x4*>(lds + Pl<P>::lds + l31 * ldl + col);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(((unsigned)hi[j] << 16) | (unsigned)lo[j]);
+}
+
 #define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
 // MODE (RowsArgs::mode, compile time so the train-step instantiation carries none of the other modes' code or registers):
@@ -74,6 +95,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
     constexpr int LDU = Ld<T>::u, LDH = Ld<T>::hh, LDZ = Ld<T>::z;
     constexpr bool Y513 = (YP == XP);
+    // train step with two operand planes: the loss epilogue of the output layer runs on the helper waves (see put_raw4), which takes
+    // 64 registers (x prefetch, terms) off the chain waves' peak and pays for a deeper weight ring (PDO): the GEMM phases are
+    // latency-bound by that depth (k-step time = t0 + L / D: 207 / 132 / 100 ns at D = 2 / 4 / 6)
+#ifndef R2_OFFL
+#define R2_OFFL 1
+#endif
+#ifndef R2_LATE_Y
+#define R2_LATE_Y 1
+#endif
+    constexpr bool OFFL = R2_OFFL && MODE == 0 && NP == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const U = reinterpret_cast<T*>(smem);
     T* const Ha = U + TB * LDU;
@@ -99,7 +130,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     if (wave_u < 4) {
         // =========================================================== chain waves ===========================================================
         const int cw = wave_u, fb = 32 * cw;
-        constexpr int D = P::PD;
+        constexpr int D = OFFL ? P::PDO : P::PD;
         typedef Sched<P, YP, YENC, D> SC;
         typedef WStream<P, SC, D> WS;
         constexpr unsigned FBB = SC::FBB;
@@ -251,7 +282,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     else q[gq] = reinterpret_cast<const F4U*>(xrow + 32 * t + 8 * gq)->v;
                 }
             };
-            xload(cw, xq);
+            if constexpr (!OFFL) xload(cw, xq);
             // bin 512 (wave 3's dot-product tile), requested a phase early
             const float xv512 = (cw == 3 && mode != 1 && xrow != nullptr) ? (mode == 2 ? g.g_r[rowb * g.ld_gr + XD - 1] : g.x[rowx * g.ldx + XD - 1]) : 0.f;
             bias16(Bias + OB4, fb, h, bv);
@@ -264,6 +295,21 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             const float invB_l = live ? g.invB : 0.f;                      // frames past B contribute nothing
             // 16 full tiles, 4 per chain wave (tile cw + 4 i = stream segment G_W5A + i); the 17th tile holds ONE real
             // feature (bin 512): chain wave 3 does it as a 128-term dot product
+            if constexpr (OFFL) {
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    const int t = cw + 4 * I;
+                    zero_acc<P>(acc);
+                    gemm_seg<P, SC, D, G_W5A + I>(acc, ws, Hbr);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 b5q = *reinterpret_cast<const f32x4*>(Bias + OB5 + 32 * t + 8 * gq + 4 * h);
+                        const float a4[4] = {acc[4 * gq] + b5q[0], acc[4 * gq + 1] + b5q[1], acc[4 * gq + 2] + b5q[2], acc[4 * gq + 3] + b5q[3]};
+                        put_raw4<P>(a4, U, LDU, 32 * t + 8 * gq + 4 * h, l31);
+                    }
+                    wg_barrier();                                       // RB0 .. RB3: the round's four tiles go to the helpers
+                });
+            } else
             static_for<0, 4>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 const int t = cw + 4 * I;
@@ -424,6 +470,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             wg_barrier();                                               // BRED (the next tile's x image is in U)
             if (tid == 0) {
                 tot_rec += (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+                if constexpr (OFFL) tot_rec += (double)red[8] + (double)red[9] + (double)red[10] + (double)red[11];   // the helpers' share
                 tot_kl += -0.5 * (double)red[4];
             }
         }
@@ -530,7 +577,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
                 }
                 wg_barrier();                                           // BY
+#if !R2_LATE_Y
                 if (st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+#endif
             } else {
                 if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
             }
@@ -538,6 +587,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BH2
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+#if R2_LATE_Y
+            // the label tile stays in U until the output layer: its stash waits for this phase, away from the window in which every CU
+            // reads x and y and writes the x stash (the first 10 us of the kernel move 68 MB: HBM-bound)
+            if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+#endif
             wg_barrier();                                               // BZ
             if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
             if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
@@ -545,6 +599,51 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BD2
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            float rec_h = 0.f;
+            if constexpr (OFFL) {
+                // loss epilogue of the output layer: tile hw + 4 I of round I (x of all four tiles requested up front: the tile was read a
+                // few microseconds ago, L2 / MALL)
+                // per-iteration opaque copy of the lane id: keeps this block's 40-odd LDS / global addresses out of loop-invariant hoisting
+                // (hoisted to the tile loop's preheader they stay live across every phase and spill)
+                int lo_ = lane;
+                asm volatile("" : "+v"(lo_));
+                const int l31o = lo_ & 31, ho = lo_ >> 5;
+                const bool live = (b0 + l31o) < g.B;
+                const float invB_l = live ? g.invB : 0.f;                  // frames past B contribute nothing
+                const float* const xrow = g.x + rowof(l31o) * g.ldx + 4 * ho;
+                f32x4 xo[4], xnx[4];                                        // this round's x, the next round's (requested a round ahead)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) xo[gq] = reinterpret_cast<const F4U*>(xrow + 32 * hw + 8 * gq)->v;
+#pragma unroll 1
+                for (int I = 0; I < 4; ++I) {                               // rolled: unrolled, the scheduler interleaves the rounds and the block spills
+                    const int t = hw + 4 * I;
+                    if (I < 3) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) xnx[gq] = reinterpret_cast<const F4U*>(xrow + 32 * (t + 4) + 8 * gq)->v;
+                    }
+                    wg_barrier();                                       // RB0 .. RB3
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float a4[4], da4[4];
+                        get_raw4<P>(a4, U, LDU, 32 * t + 8 * gq + 4 * ho, l31o);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xs = xo[gq][j];
+                            const float xe = xs * P::exp_(-a4[j]);               // x / r,  r = exp(a)  (models.py:122)
+                            rec_h += xe - P::log_(xs + g.elbo_eps) + a4[j] - 1.f;   // utils.py:74 (log r = a)
+                            da4[j] = (1.f - xe) * invB_l;                        // d recon / d a
+                        }
+                        typename P::Pack4 ph, pl;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { ph[j] = P::cvt(da4[j]); pl[j] = P::cvt(da4[j] - (float)ph[j]); }
+                        *reinterpret_cast<typename P::Pack4*>(U + l31o * LDU + 32 * t + 8 * gq + 4 * ho) = ph;
+                        *reinterpret_cast<typename P::Pack4*>(U + Pl<P>::lds + l31o * LDU + 32 * t + 8 * gq + 4 * ho) = pl;
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) xo[gq] = xnx[gq];
+                }
+                if (!live) rec_h = 0.f;
+            }
             wg_barrier();                                               // BDA
             for (int t = hw; t < NT_OUT; t += 4) if (st1) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
             const bool more = it + 1 < ntl;
@@ -578,6 +677,10 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             };
             x_in_regs = more && g.fastx && nfull;
             if (x_in_regs) tile513_issue(g.x, nrowof, xv, tl);
+            else {                                                         // a full redefinition: without it the register image of the PREVIOUS tile
+#pragma unroll                                                             // stays live around the whole loop (conditional definition) -- 68 registers
+                for (int i = 0; i < NQ513; ++i) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             wg_barrier();                                               // BDD1
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BDML
@@ -590,6 +693,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 if (x_in_regs) tile513_commit<P, XP>(xv, U, LDU, tl);
                 else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof);
             }
+            if constexpr (OFFL) { const float rs = wave_sum(rec_h); if (lane == 0) red[8 + hw] = rs; }
             wg_barrier();                                               // BRED
         }
     }
