@@ -71,6 +71,7 @@ struct RowsArgs {
     double* partials;
     unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
+    int stash_inputs;           // 0: the weight-gradient kernel reads x / y from the input matrices, no stash for them (8-wave kernel only)
 };
 
 #ifdef DVAE_FINE_STAMPS

@@ -900,6 +900,10 @@ struct Block4 {
     int32_t ldo_hi;
     int64_t a_off_hi;
     int64_t bias_off_hi;
+    // B tiles that are columns of the step's INPUTS (x: raw = 1, labels: raw = 2): the kernel can take them straight from the fp32
+    // input matrix (the rows kernel then writes no stash for them); blocks never mix input tiles with stash tiles
+    int32_t raw, rncols;     // rncols: columns of the input matrix (513 / y_dim)
+    int32_t rcol[4];         // first column of B tile j in the input matrix
 };
 
 template <int I, int N, typename F>
@@ -921,16 +925,23 @@ template <typename P> struct Wg4 {
 // NA x NB = tiles of the block this instantiation computes (absent tiles alias tile 0 and are masked at the store: their
 // descriptors carry mvalid / nvalid 0).  Compile-time shapes keep every operand load unconditional: a load under a run-time
 // branch makes hipcc's wait-count pass fall back to vmcnt(0) in front of the first MFMA of every k-step (the ring then holds one).
-template <typename P, int NA, int NB>
+struct RawIn { const float* x; const float* y; int ldx, ldy; int64_t B; };
+
+template <typename P, int NA, int NB, int RAW>
 __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __restrict__ bdg, char* wsm, int slice, int64_t Bp, int64_t spl, int64_t kper,
-                                            float* __restrict__ slabs, int64_t slab_stride, int lane, int wave) {
+                                            float* __restrict__ slabs, int64_t slab_stride, int lane, int wave, const RawIn& ri) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     typedef Wg4<P> W;
     typedef const __attribute__((address_space(1))) char* gptr;
     typedef const __attribute__((address_space(1))) Frag* gfrag;
-    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP, RD = W::RD;
+    // RAW: 0 = B tiles from the stash; 1 = from the fp32 input matrix by dword loads (any shape); 2 = from the input matrix through
+    // this wave's LDS staging rows (four full tiles): 16 frames x 128 columns per k-step arrive as eight 1 KB row loads, are split
+    // into (hi, lo) bf16, written as [frame][column] rows and read back transposed (ds_read_b64_tr_b16) into MFMA fragments.
+    // Mode 1 needs 32 loads per k-step and overruns the 6-bit vmcnt (at most 63 loads in flight: 1.5 k-steps); mode 2 needs 16.
+    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP, RD = RAW == 2 ? 2 : W::RD;
     constexpr int64_t FBB = 64 * 16;                                     // bytes of one (feature tile, k-step) fragment block
+    constexpr int SLD = 128 + 8, SPL = 16 * SLD;                         // staging rows: elements per frame row (odd number of 16-byte slots), per plane
     const int l31 = lane & 31, h = lane >> 5;
     // this wave's quarter of the slice's k-steps
     const int64_t kbeg = (int64_t)slice * kper;
@@ -959,7 +970,22 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    Frag a[RD][NA][NP], b[RD][NB][NP];
+    Frag a[RD][NA][NP], b[RAW == 1 ? 1 : (RAW == 2 ? 1 : RD)][RAW == 1 ? 1 : NB][NP];   // RAW == 2: b[0] = the fragments of the k-step being multiplied
+    // RAW: the B fragments come from the fp32 input matrix itself -- lane (feature l31, frame half h) of tile j needs E consecutive
+    // frames of ONE column: E dword loads, each wave-instruction two 128-byte row segments; split into (hi, lo) when consumed.
+    // Frames past the batch repeat its last row (their dPre operand is zero), pad columns repeat the last column (never stored).
+    float braw[RAW == 1 ? RD : 1][RAW == 1 ? NB : 1][E];
+    f32x4 rawq[RAW == 2 ? RD : 1][RAW == 2 ? 8 : 1];                        // RAW == 2: row 2u + (lane >> 5), columns 4 (lane & 31) .. + 3 of the k-step's block
+    typedef const __attribute__((address_space(1))) float* gflt;
+    const gflt rsrc = (gflt)(uintptr_t)(RAW ? (bd.raw == 1 ? ri.x : ri.y) : nullptr);
+    const int rld = RAW ? (bd.raw == 1 ? ri.ldx : ri.ldy) : 0;
+    int rcolv[RAW == 1 ? NB : 1];
+    if constexpr (RAW == 1) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int cc = bd.rcol[k] + l31; rcolv[k] = cc < bd.rncols ? cc : bd.rncols - 1; }
+    }
+    T* const stg = reinterpret_cast<T*>(wsm) + wave * (SPL * NP);          // RAW == 2: this wave's staging rows
+    const int rcol4 = RAW == 2 ? bd.rcol[0] + 4 * l31 : 0;
     auto load = [&](auto sc, int64_t sk) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         const int64_t o = sk * FBB;
@@ -968,10 +994,27 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
             a[s][k][0] = *(gfrag)(ap[k] + o + loff);
             if constexpr (NP == 2) a[s][k][1] = *(gfrag)(ap[k] + plb + o + loff);
         }
+        if constexpr (RAW == 1) {
+            const int64_t f0 = sk * KS + h * E;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            b[s][k][0] = *(gfrag)(bp[k] + o + loff);
-            if constexpr (NP == 2) b[s][k][1] = *(gfrag)(bp[k] + plb + o + loff);
+            for (int e = 0; e < E; ++e) {
+                int64_t fr = f0 + e; fr = fr < ri.B ? fr : ri.B - 1;
+                const gflt rowp = rsrc + fr * rld;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) braw[s][k][e] = rowp[rcolv[k]];
+            }
+        } else if constexpr (RAW == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int64_t fr = sk * KS + 2 * u + h; fr = fr < ri.B ? fr : ri.B - 1;
+                rawq[s][u] = reinterpret_cast<const __attribute__((address_space(1))) F4U*>(rsrc + fr * rld + rcol4)->v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                b[s][k][0] = *(gfrag)(bp[k] + o + loff);
+                if constexpr (NP == 2) b[s][k][1] = *(gfrag)(bp[k] + plb + o + loff);
+            }
         }
     };
     auto fsum = [&](const Frag& f) __attribute__((always_inline)) {
@@ -980,14 +1023,68 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
         for (int q = 0; q < E; ++q) t += (float)f[q];
         return t;
     };
+    // RAW == 2: stage s of the raw ring -> (hi, lo) rows in LDS -> transposed fragments b[0][j]
+    auto prepare = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (RAW == 2) {
+            typedef typename P::Pack4 Pack4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                Pack4 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ph[e] = P::cvt(rawq[s][u][e]); pl[e] = P::cvt(rawq[s][u][e] - (float)ph[e]); }
+                T* const rowp = stg + (2 * u + h) * SLD + 4 * l31;
+                *reinterpret_cast<Pack4*>(rowp) = ph;
+                if constexpr (NP == 2) *reinterpret_cast<Pack4*>(rowp + SPL) = pl;
+            }
+            const int i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int pln = 0; pln < NP; ++pln) {
+                    const T* bpj = stg + pln * SPL + q * SLD + 32 * j + 16 * cg + 4 * pp;
+                    const s16x4 r0 = lds_tr16(bpj + (8 * h) * SLD), r1 = lds_tr16(bpj + (8 * h + 4) * SLD);
+                    const s16x8 raw8 = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                    b[0][j][pln] = __builtin_bit_cast(Frag, raw8);
+                }
+        }
+    };
     auto compute = [&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
+        if constexpr (RAW == 2) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
+            for (int i = 0; i < NA; ++i) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j]);
-            bs[i] += fsum(a[s][i][0]);                                   // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
-            if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[0][j]);
+                bs[i] += fsum(a[s][i][0]);
+                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+            }
+        } else if constexpr (RAW == 1) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                Frag bj[NP];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    bj[0][e] = P::cvt(braw[s][j][e]);
+                    if constexpr (NP == 2) bj[1][e] = P::cvt(braw[s][j][e] - (float)bj[0][e]);
+                }
+#pragma unroll
+                for (int i = 0; i < NA; ++i) mmap<P>(c[i][j], a[s][i], bj);
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                bs[i] += fsum(a[s][i][0]);
+                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j]);
+                bs[i] += fsum(a[s][i][0]);                               // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
+                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+            }
         }
     };
     // No branch around the loop (an empty range runs zero laps; its clamped prologue loads re-read the slice's last k-step): a
@@ -999,16 +1096,23 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
             load(sc, sk);
         });
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RAW == 2) prepare(std::integral_constant<int, 0>{});
 #pragma unroll 1
         for (int64_t sk = sbeg; sk < send; sk += RD) {
             static_for_w<0, RD>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if (sk + s < send) compute(sc);                         // wave-uniform
                 int64_t sn = sk + RD + s; sn = sn < slast ? sn : slast;     // last lap: a harmless reload, no branch around a load
+                if constexpr (RAW == 2) {
+                    // the MFMAs of this k-step are in the pipe (their operands are read): stage the NEXT k-step's B tiles in their shadow
+                    // -- its raw values are consumed before this slot's reload below overwrites the ring
+                    prepare(std::integral_constant<int, (s + 1) % RD>{});
+                }
                 load(sc, sn);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        if constexpr (RAW == 2) __syncthreads();                        // every wave is done with its staging rows: the reduce-scatter below reuses the LDS
     }
     // ---- the four partial blocks meet in LDS: a reduce-scatter in a fixed order (deterministic).  Wave w ends up with A tile row
     // w of the block (its local row 0) and stores it: a single wave storing 8 tiles with per-element address arithmetic took
@@ -1099,7 +1203,8 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 
 template <typename P>
 __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
-                                                        int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride) {
+                                                        int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride,
+                                                        const RawIn ri, int use_raw) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1109,15 +1214,26 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
     int na = 0, nb = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { if (bd.At[k] != nullptr) na = k + 1; if (bd.Bt[k] != nullptr) nb = k + 1; }
-    if (na == 1) {
-        if (nb == 1) wgrad4_body<P, 1, 1>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
-        else if (nb == 2) wgrad4_body<P, 1, 2>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
-        else wgrad4_body<P, 1, 4>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+#define W4_GO(NA_, NB_, RAW_) wgrad4_body<P, NA_, NB_, RAW_>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave, ri)
+    bool raw = false;
+    if constexpr (sizeof(typename P::T) == 2) raw = use_raw && bd.raw != 0;       // input-matrix B tiles (16-bit operand policies only)
+    if (raw) {
+        if constexpr (sizeof(typename P::T) == 2) {
+            if (nb == 4 && bd.rcol[0] + 128 <= bd.rncols) W4_GO(4, 4, 2);      // four full tiles: through the LDS staging rows
+            else if (nb == 1) W4_GO(4, 1, 1);
+            else if (nb == 2) W4_GO(4, 2, 1);
+            else W4_GO(4, 4, 1);
+        }
+    } else if (na == 1) {
+        if (nb == 1) W4_GO(1, 1, 0);
+        else if (nb == 2) W4_GO(1, 2, 0);
+        else W4_GO(1, 4, 0);
     } else {
-        if (nb == 1) wgrad4_body<P, 4, 1>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
-        else if (nb == 2) wgrad4_body<P, 4, 2>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
-        else wgrad4_body<P, 4, 4>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave);
+        if (nb == 1) W4_GO(4, 1, 0);
+        else if (nb == 2) W4_GO(4, 2, 0);
+        else W4_GO(4, 4, 0);
     }
+#undef W4_GO
 }
 
 // dst = (accumulate ? dst : 0) + sum of the slabs (fixed order: deterministic)
@@ -1271,7 +1387,7 @@ struct Layout {
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
     int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
-    int ntiles, nblocks;
+    int ntiles, nblocks, nblocks4;
 };
 
 static inline int64_t al(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -1317,11 +1433,14 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     auto q4 = [](int n) { return (n + 3) / 4; };
     L.nblocks = q4(4) * q4(NT_OUT + (L.ye ? nty : 0)) + 1 + 1 + q4(4) * q4(1 + (L.yd ? nty : 0)) + 1 + q4(NT_OUT) * 1;
     if (L.info) L.nblocks += q4(NT_OUT) + 1 + 1 + 1 + 1 + 1;
+    // blocks of the workgroup k-split kernel: as above, but a block never mixes input-matrix tiles (x, labels) with stash tiles
+    L.nblocks4 = q4(4) * (q4(NT_OUT) + (L.ye ? q4(nty) : 0)) + 1 + 1 + q4(4) * (1 + (L.yd ? q4(nty) : 0)) + 1 + q4(NT_OUT) * 1;
+    if (L.info) L.nblocks4 += q4(NT_OUT) + 1 + 1 + 1 + 1 + 1;
     int64_t b = 0;
     auto bytes = [&](int64_t n) { int64_t q = b; b += al(n, 256); return q; };
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_blocks = bytes((int64_t)L.nblocks * sizeof(BlockDesc));
-    L.o_blocks4 = bytes((int64_t)L.nblocks * sizeof(Block4));
+    L.o_blocks4 = bytes((int64_t)L.nblocks4 * sizeof(Block4));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
@@ -1418,7 +1537,7 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
         tmp.ksplit = 1;
         Layout L0;
         make_layout(tmp, L0);
-        ks = 256 / L0.nblocks;
+        ks = 256 / L0.nblocks4;
         // bf16 policies are bound by the cold read of the stash: keep every slice on ONE XCD (workgroup i runs on XCD i % 8 and
         // slice = i % ks), so that each stash line crosses the fabric once -- a multiple of 8 slices (M2 y513: 8 x 22 workgroups
         // 28.5 us, 11 x 22 33.9 us under bf16x3).  The fp32 policy is MFMA-bound: as many workgroups as CUs (59 us at 11 slices, 71 at 8).
@@ -1460,7 +1579,7 @@ static int64_t kper_of(const dvae_train_plan_t* p) {
 }
 
 struct ABlock { int64_t row; int mvalid; int tensor; int m0; int bias_tensor; int tensor_hi; int bias_hi; };
-struct BBlock { int64_t row; int nvalid; int col; };
+struct BBlock { int64_t row; int nvalid; int col; int kind; int scol; int sncols; };   // kind 1 / 2: columns scol.. of the input matrix x / y (sncols wide)
 
 template <typename T>
 static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_dev, GroupDesc* groups, BlockDesc* blocks, Block4* blocks4, TensorDesc* td) {
@@ -1474,10 +1593,10 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     auto addA = [&](int64_t row0, int M, int tensor, int bias_tensor) {
         for (int m0 = 0; m0 < M; m0 += 32) ab[na++] = ABlock{row0 + m0, M - m0 < 32 ? M - m0 : 32, tensor, m0, bias_tensor, -1, -1};
     };
-    auto addB = [&](int64_t row0, int N, int col0) {
-        for (int n0 = 0; n0 < N; n0 += 32) bb[nb++] = BBlock{row0 + n0, N - n0 < 32 ? N - n0 : 32, col0 + n0};
+    auto addB = [&](int64_t row0, int N, int col0, int kind = 0) {
+        for (int n0 = 0; n0 < N; n0 += 32) bb[nb++] = BBlock{row0 + n0, N - n0 < 32 ? N - n0 : 32, col0 + n0, kind, n0, N};
     };
-    int nblk = 0;
+    int nblk = 0, nblk4 = 0;
     // 2 x 2 group of tiles: A pair starting at block i, B pair starting at block j (all-null when out of range)
     auto make_group = [&](int i, int j) {
         GroupDesc d;
@@ -1522,51 +1641,62 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
                 }
                 for (int wr = 0; wr < 2; ++wr)
                     for (int wc = 0; wc < 2; ++wc) b.g[wr * 2 + wc] = make_group(i0 + 2 * wr, j0 + 2 * wc);
-                Block4 q;
-                memset(&q, 0, sizeof(q));
-                for (int k = 0; k < 4; ++k) {
-                    q.bias_off[k] = -1;
-                    if (i0 + k < na) {
-                        const ABlock& a = ab[i0 + k];
-                        q.At[k] = S(a.row);
-                        q.ldo[k] = p->tensor_cols[a.tensor];
-                        q.a_off[k] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * q.ldo[k];
-                        q.mvalid[k] = a.mvalid;
-                        if (a.bias_tensor >= 0 && j0 == 0) q.bias_off[k] = p->tensor_offset[a.bias_tensor] + a.m0;
-                        if (k == 0 && a.tensor_hi >= 0) {
-                            q.split16 = 1;
-                            q.ldo_hi = p->tensor_cols[a.tensor_hi];
-                            q.a_off_hi = p->tensor_offset[a.tensor_hi];
-                            q.bias_off_hi = p->tensor_offset[a.bias_hi];
-                        }
-                    }
-                    if (j0 + k < nb) {
-                        q.Bt[k] = S(bb[j0 + k].row);
-                        q.bcol[k] = bb[j0 + k].col;
-                        q.nvalid[k] = bb[j0 + k].nvalid;
-                    }
-                }
-                blocks4[nblk] = q;
                 blocks[nblk++] = b;
             }
+        // blocks of the workgroup k-split kernel: per run of B tiles of one kind (stash / x / labels)
+        for (int r0 = 0; r0 < nb;) {
+            int r1 = r0;
+            while (r1 < nb && bb[r1].kind == bb[r0].kind) ++r1;
+            for (int i0 = 0; i0 < na; i0 += 4)
+                for (int j0 = r0; j0 < r1; j0 += 4) {
+                    Block4 q;
+                    memset(&q, 0, sizeof(q));
+                    q.raw = bb[r0].kind; q.rncols = bb[r0].sncols;
+                    for (int k = 0; k < 4; ++k) {
+                        q.bias_off[k] = -1;
+                        if (i0 + k < na) {
+                            const ABlock& a = ab[i0 + k];
+                            q.At[k] = S(a.row);
+                            q.ldo[k] = p->tensor_cols[a.tensor];
+                            q.a_off[k] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * q.ldo[k];
+                            q.mvalid[k] = a.mvalid;
+                            if (a.bias_tensor >= 0 && j0 == 0) q.bias_off[k] = p->tensor_offset[a.bias_tensor] + a.m0;
+                            if (k == 0 && a.tensor_hi >= 0) {
+                                q.split16 = 1;
+                                q.ldo_hi = p->tensor_cols[a.tensor_hi];
+                                q.a_off_hi = p->tensor_offset[a.tensor_hi];
+                                q.bias_off_hi = p->tensor_offset[a.bias_hi];
+                            }
+                        }
+                        if (j0 + k < r1) {
+                            q.Bt[k] = S(bb[j0 + k].row);
+                            q.bcol[k] = bb[j0 + k].col;
+                            q.nvalid[k] = bb[j0 + k].nvalid;
+                            q.rcol[k] = bb[j0 + k].scol;
+                        }
+                    }
+                    blocks4[nblk4++] = q;
+                }
+            r0 = r1;
+        }
         na = 0; nb = 0;
     };
     const int ye = p->model == DVAE_MODEL_M2 ? p->y_dim : 0, yd = p->y_dim;
-    addA(L.dh1T, HD, 0, 1); addB(L.xT, XD, 0); if (ye) addB(L.yT, ye, XD); emit();
+    addA(L.dh1T, HD, 0, 1); addB(L.xT, XD, 0, 1); if (ye) addB(L.yT, ye, XD, 2); emit();
     addA(L.dh2T, HD, 2, 3); addB(L.h1T, HD, 0); emit();
     ab[na++] = ABlock{L.dmlvT, 32, 4, 0, 5, 6, 7}; addB(L.h2T, HD, 0); emit();   // one tile: rows 0-15 mu head, 16-31 log_var head
-    addA(L.dd1T, HD, 8, 9); addB(L.zT, ZD, 0); if (yd) addB(L.yT, yd, ZD); emit();
+    addA(L.dd1T, HD, 8, 9); addB(L.zT, ZD, 0); if (yd) addB(L.yT, yd, ZD, 2); emit();
     addA(L.dd2T, HD, 10, 11); addB(L.d1T, HD, 0); emit();
     addA(L.daT, XD, 12, 13); addB(L.d2T, HD, 0); emit();
     if (L.info) {   // classifier (tensors 14-19) and auxiliary net (20-25): scripts/training_M2_info_vad.py:141-143
-        addA(L.dc1T, HD, 14, 15); addB(L.xT, XD, 0); emit();
+        addA(L.dc1T, HD, 14, 15); addB(L.xT, XD, 0, 1); emit();
         addA(L.dc2T, HD, 16, 17); addB(L.c1T, HD, 0); emit();
         addA(L.dc3T, 1, 18, 19); addB(L.c2T, HD, 0); emit();
         addA(L.da1T, HD, 20, 21); addB(L.zT, ZD, 0); emit();
         addA(L.da2T, HD, 22, 23); addB(L.a1T, HD, 0); emit();
         addA(L.da3T, 1, 24, 25); addB(L.a2T, HD, 0); emit();
     }
-    if (n != L.ntiles || nblk != L.nblocks) { fprintf(stderr, "dvae: internal group / block count mismatch %d vs %d, %d vs %d\n", n, L.ntiles, nblk, L.nblocks); }
+    if (n != L.ntiles || nblk != L.nblocks || nblk4 != L.nblocks4) { fprintf(stderr, "dvae: internal group / block count mismatch %d vs %d, %d vs %d, %d vs %d\n", n, L.ntiles, nblk, L.nblocks, nblk4, L.nblocks4); }
     // tensors -> kernel-layout copies
     for (int i = 0; i < p->n_tensors; ++i) {
         TensorDesc t;
@@ -1642,7 +1772,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     DVAE_HIP(hipMemsetAsync(w, 0, (size_t)L.total, s));
     GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
     BlockDesc* blocks = new BlockDesc[L.nblocks + 8];
-    Block4* blocks4 = new Block4[L.nblocks + 8];
+    Block4* blocks4 = new Block4[L.nblocks4 + 8];
     TensorDesc td[DVAE_TRAIN_MAX_TENSORS];
     memset(td, 0, sizeof(td));
     if (is_bf(plan->precision)) fill_tables<__bf16>(plan, L, w, tiles, blocks, blocks4, td);
@@ -1650,7 +1780,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipError_t e1 = hipMemcpyAsync(w + L.o_tiles, tiles, (size_t)L.ntiles * sizeof(GroupDesc), hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
     hipError_t e5 = hipMemcpyAsync(w + L.o_blocks, blocks, (size_t)L.nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, s);
-    hipError_t e6 = hipMemcpyAsync(w + L.o_blocks4, blocks4, (size_t)L.nblocks * sizeof(Block4), hipMemcpyHostToDevice, s);
+    hipError_t e6 = hipMemcpyAsync(w + L.o_blocks4, blocks4, (size_t)L.nblocks4 * sizeof(Block4), hipMemcpyHostToDevice, s);
     const int64_t nchunks = plan->n_params / 64;
     unsigned char* ct = new unsigned char[nchunks + 64];
     memset(ct, 255, (size_t)nchunks + 64);
@@ -1725,6 +1855,13 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.spl = L.stash_rows * plan->Bp; a.wpl_bytes = (unsigned)(L.wcopy_elems * esz);
     a.dbg = g_dbg;
     { const char* ab = getenv("DVAE_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    // DVAE_RAW_INPUTS=1 (opt-in, tested): the weight-gradient kernel takes x and the labels straight from the fp32 input matrices and the
+    // rows kernel writes no stash for them (35 MB of writes less in its HBM-bound opening window).  Measured (M2 y513, 8192 frames, bf16x3,
+    // same box, alternating): rows 46.0 -> 44.0 us, but the weight-gradient kernel 29.0 -> 34.6 us -- its input-fed blocks convert and
+    // transpose 8 KB per k-step and wave through LDS behind a two-deep ring -- so the stash stays the default (step 78.6 vs 81.8 us).
+    const bool raw_inputs = getenv("DVAE_RAW_INPUTS") != nullptr && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) &&
+                            a.rows == nullptr && wgrad_form(getenv("DVAE_WGRAD")) == 4 && g_mode.mode != 1;
+    a.stash_inputs = raw_inputs ? 0 : 1;
     a.mode = g_mode.mode;
     a.out_r = g_mode.out_r; a.out_mu = g_mode.out_mu; a.out_lv = g_mode.out_lv; a.out_z = g_mode.out_z; a.ld_r = g_mode.ld_r;
     a.g_r = g_mode.g_r; a.g_mu = g_mode.g_mu; a.g_lv = g_mode.g_lv; a.g_z = g_mode.g_z; a.ld_gr = g_mode.ld_gr;
@@ -1777,7 +1914,10 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     for (int rep = 0; rep < wrep; ++rep)
     if (wgrad_form(wk) == 4) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
-        const dim3 g3((unsigned)(L.nblocks * ks));
+        const dim3 g3((unsigned)(L.nblocks4 * ks));
+        RawIn ri;
+        ri.x = x; ri.y = y; ri.ldx = ldx; ri.ldy = plan->y_dim ? ldy : 0; ri.B = plan->B;
+        const int use_raw = raw_inputs ? 1 : 0;
         static bool attr_done[64][3] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1790,9 +1930,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             attr_done[dev][pi] = true;
         }
         const Block4* bl = (const Block4*)(w + L.o_blocks4);
-        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
-        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
-        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
+        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw);
+        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw);
+        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw);
         DVAE_LAUNCH_OK("wgrad4_kernel");
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);

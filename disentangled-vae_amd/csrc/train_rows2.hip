@@ -519,7 +519,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         };
         f32x4 xv[NQ513];
         bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
-        const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2);   // forward-only launches stash nothing
+        const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2) && g.stash_inputs;   // forward-only launches stash nothing
         for (int it = 0; it < ntl; ++it) {
             const int tile = (int)blockIdx.x + it * (int)gridDim.x;
             const int64_t b0 = (int64_t)tile * TB;

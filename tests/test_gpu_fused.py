@@ -3,6 +3,7 @@ golden vectors from the reference (fp32 operand mode, the parity mode), the nump
 BASELINE.json's batch size, ragged batches, determinism, and the bf16 operand mode with its
 measured deviation stated."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -474,3 +475,28 @@ def test_kernels_stay_inside_their_buffers(model, y_dim, B, precision):
     assert torch.isfinite(out).all()
     for name, raw in raws.items():
         assert bool((raw[:G] == 0xA5).all()) and bool((raw[-G:] == 0xA5).all()), f"{name}: guard band overwritten"
+
+
+@pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M1", 0, 1000), ("M2", 1, 20000), ("M2", 513, 33)])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_weight_gradients_from_raw_inputs_equal_the_stash_path(model, y_dim, B, precision):
+    """DVAE_RAW_INPUTS=1 (opt-in): the weight-gradient kernel reads x / y from the fp32 input matrices (dword loads for ragged tiles,
+    LDS-staged transposition for full ones) and the rows kernel writes no x / y stash.  Same operand values, same summation order:
+    the gradients equal the default path's bit for bit."""
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 31)
+    x, y, e = gu.make_batch(dims, B, 32)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    out = {}
+    for raw in (False, True):
+        if raw:
+            os.environ["DVAE_RAW_INPUTS"] = "1"
+        try:
+            tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+            losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+            out[raw] = (losses, tr.grads_numpy())
+        finally:
+            os.environ.pop("DVAE_RAW_INPUTS", None)
+    np.testing.assert_array_equal(out[False][0], out[True][0])
+    for k in out[False][1]:
+        np.testing.assert_array_equal(out[False][1][k], out[True][1][k], err_msg=k)
