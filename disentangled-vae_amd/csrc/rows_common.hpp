@@ -183,8 +183,9 @@ __device__ __forceinline__ void tile513_issue(const float* __restrict__ base, Ro
     __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
 }
 template <typename P, int PCOLS>
-__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr) {
+__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr, bool* any_lo = nullptr) {
     typedef typename P::Pack4 Pack4;
+    unsigned long long lo_bits = 0ull;                          // OR of every lo-plane word this thread writes (any_lo: is the lo plane needed at all?)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = tid + 256 * i;
@@ -201,6 +202,7 @@ __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename
             pl[0] = P::cvt(v[i][0] - (float)pk[0]); pl[1] = P::cvt(v[i][1] - (float)pk[1]);
             pl[2] = P::cvt(v[i][2] - (float)pk[2]); pl[3] = P::cvt(v[i][3] - (float)pk[3]);
             *reinterpret_cast<Pack4*>(U + Pl<P>::lds + row * ldu + col) = pl;
+            if (any_lo) lo_bits |= __builtin_bit_cast(unsigned long long, pl) & 0x7fff7fff7fff7fffull;   // -0 is not "non-zero"
         }
     }
     constexpr int PADC = PCOLS - XD;                            // column 512, then PADC zero columns
@@ -208,8 +210,13 @@ __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename
         if (xf) xf[tid * XD + XD - 1] = v[16][0];
         const typename P::T vh = P::cvt(v[16][0]);
         U[tid * ldu + XD - 1] = vh;
-        if constexpr (P::NP == 2) U[Pl<P>::lds + tid * ldu + XD - 1] = P::cvt(v[16][0] - (float)vh);
+        if constexpr (P::NP == 2) {
+            const typename P::T vl = P::cvt(v[16][0] - (float)vh);
+            U[Pl<P>::lds + tid * ldu + XD - 1] = vl;
+            if (any_lo && (float)vl != 0.f) lo_bits |= 1ull;
+        }
     }
+    if (any_lo) *any_lo = lo_bits != 0ull;
     for (int idx = tid; idx < TB * PADC; idx += 256) {
         const int r = idx / PADC, c = XD + idx - r * PADC;
         U[r * ldu + c] = P::cvt(0.f);

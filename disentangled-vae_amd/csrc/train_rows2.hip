@@ -85,6 +85,7 @@ __device__ __forceinline__ void get_raw4(float (&v)[4], const typename P::T* lds
 }
 
 #define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#define R2_HSTAMP(i) do { if (g.dbg && ht == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 
 // MODE (RowsArgs::mode, compile time so the train-step instantiation carries none of the other modes' code or registers):
 // 0 fused train step, 1 forward outputs only, 2 backward from upstream gradients
@@ -103,6 +104,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #endif
 #ifndef R2_LATE_Y
 #define R2_LATE_Y 1
+#endif
+#ifndef R2_EARLY_Y
+#define R2_EARLY_Y 0
 #endif
     constexpr bool OFFL = R2_OFFL && MODE == 0 && NP == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,10 +537,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             // per-iteration opaque copy of the thread id: keeps the per-thread staging addresses out of loop-invariant hoisting
             int tl = ht;
             asm volatile("" : "+v"(tl));
+            const bool yfast = Y513 && g.fasty && full;
+            f32x4 yv[NQ513];
+            bool y_early = false;
             if (it == 0) {
                 if (gather) { fill_rows(tile, 0); wg_barrier(); }       // BROW
                 if (g.fastx && full) {
                     tile513_issue(g.x, rowof, xv, tl);
+#if R2_EARLY_Y
+                    if (YP > 0 && Y513 && g.fasty) { tile513_issue(g.y, rowof, yv, tl); y_early = true; }
+#endif
 #pragma unroll
                     for (int q = 0; q < NB; ++q) {
                         const int i = ht + 256 * q;
@@ -555,27 +565,26 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 wg_barrier();                                           // BX
             }
             // ---- chain: L1 x GEMM.  y loads in flight, x -> stash
-            const bool yfast = Y513 && g.fasty && full;
-            f32x4 yv[NQ513];
             if (YP > 0) {
-                if (Y513 && yfast) tile513_issue(g.y, rowof, yv, tl);
+                if (Y513 && yfast && !y_early) tile513_issue(g.y, rowof, yv, tl);
+                R2_HSTAMP(16);
                 if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                R2_HSTAMP(17);
                 wg_barrier();                                           // BL1X
-                if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl);
+                R2_HSTAMP(18);
+                bool any = false;                                          // does the label tile need its lo plane?  (found while committing)
+                if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl, nullptr, NP == 2 ? &any : nullptr);
                 else load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl, rowof);
-                if constexpr (NP == 2) {                                   // does the label tile need its lo plane?
-                    bool any = false;
+                R2_HSTAMP(19);
+                if constexpr (NP == 2) {
                     if (Y513 && yfast) {
-#pragma unroll
-                        for (int i = 0; i < NQ513; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) any |= (yv[i][j] - (float)P::cvt(yv[i][j])) != 0.f;
                     } else {
                         constexpr int YPD = YP > 0 ? YP : 1;
                         for (int idx = tl; idx < TB * YP; idx += 256) any |= (float)U[Pl<P>::lds + (idx / YPD) * LDU + idx % YPD] != 0.f;
                     }
                     if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
                 }
+                R2_HSTAMP(20);
                 wg_barrier();                                           // BY
 #if !R2_LATE_Y
                 if (st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);

@@ -32,6 +32,12 @@ if os.environ.get("DVAE_FINE"):
     print("  out tile 4 (wave 0, us): gemm=%.2f prefetch=%.2f x+bias lds reads=%.2f epilogue math=%.2f put=%.2f" % tuple(np.median(np.diff(f2, axis=1), axis=0)))
     print("  L2 fine (us, median): ring filled=%.2f stash issued=%.2f gemm done=%.2f tanh done=%.2f lds put=%.2f barrier=%.2f" % tuple(np.median(np.diff(f, axis=1), axis=0)))
 
+if os.environ.get("DVAE_HSTAMPS"):
+    r = buf.cpu().numpy().reshape(-1, 32).astype(np.float64) * 0.01
+    t0 = r[:, 0:1]
+    names_h = ["helper: y issued", "x stash issued", "past BL1X", "y committed", "lo-plane check done (at BY)"]
+    print("  helper (us since tile start, median): " + "  ".join(f"{n}={np.median(r[:, 16 + i] - t0[:, 0]):.2f}" for i, n in enumerate(names_h)) +
+          f"  | chain: BX={np.median(r[:,1]-t0[:,0]):.2f} L1x done={np.median(r[:,2]-t0[:,0]):.2f} L1y done={np.median(r[:,3]-t0[:,0]):.2f}")
 raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64)
 cyc = raw[:, 31] - raw[:, 30]; us = (raw[:, 15] - raw[:, 0]) * 0.01
 print("  shader clock during the kernel: %.0f MHz (median over workgroups)" % np.median(cyc / us))
