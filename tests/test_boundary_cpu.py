@@ -145,3 +145,30 @@ def test_non_integer_window_raises():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no GPU"):
             ps.stft(np.zeros(4000), fs=16000, wlen_sec=64e-3, center=False)
+
+
+@pytest.mark.parametrize("model,y_dim", [("M1", 0), ("M2", 1), ("M2", 513), ("M2_info", 1)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+def test_train_plan_is_host_only_and_consistent(model, y_dim, precision):
+    """dvae_train_plan is pure host logic (no GPU): tensor table in state_dict order, frame padding, and the slice count of the
+    weight-gradient pass -- a multiple of 8 for the bf16 policies at 8192 frames (one slice per XCD, so that every stash line
+    crosses the fabric once), at most 16 (the apply pass sums that many slabs with independent loads), never more than the
+    frames allow; an explicit hint wins."""
+    T = importlib.import_module("disentangled-vae_amd.trainer")
+    lib = native.load()
+    for B in (1, 33, 128, 8192, 1 << 20):
+        plan = T.TrainPlan()
+        native.check(lib.dvae_train_plan(T.MODEL_CODE[model], y_dim, T.PREC_CODE[precision], B, 0, ctypes.byref(plan)), "dvae_train_plan")
+        assert plan.B == B and plan.Bp % 128 == 0 and B <= plan.Bp < B + 128
+        assert plan.n_tensors == (26 if model == "M2_info" else 14)
+        offs = [plan.tensor_offset[i] for i in range(plan.n_tensors)]
+        assert offs == sorted(offs) and all(o % 64 == 0 for o in offs) and plan.n_params >= offs[-1]
+        assert 1 <= plan.ksplit <= 16 and plan.ksplit <= max(1, plan.Bp // 128)
+        if B == 8192 and precision != "fp32":
+            assert plan.ksplit % 8 == 0
+        assert plan.workspace_bytes > plan.grad_offset_bytes > 0
+        assert plan.workspace_bytes - plan.grad_offset_bytes >= plan.ksplit * plan.n_params * 4
+        assert 1 <= plan.rows_grid <= 512
+    plan = T.TrainPlan()
+    native.check(lib.dvae_train_plan(T.MODEL_CODE[model], y_dim, T.PREC_CODE[precision], 8192, 5, ctypes.byref(plan)), "dvae_train_plan")
+    assert plan.ksplit == 5
