@@ -690,6 +690,12 @@ extern "C" size_t dvae_istft_workspace_bytes(int64_t T, int nfft) {
     return (size_t)(T > 0 ? T : 0) * (size_t)nfft * sizeof(double);
 }
 
+// the 1024 / 256 transform (every caller of the reference) runs as one kernel and needs no frame scratch
+extern "C" size_t dvae_istft_workspace_bytes_hop(int64_t T, int nfft, int hop) {
+    if (nfft == 1024 && hop == 256 && getenv("DVAE_STFT_LEGACY") == nullptr && getenv("DVAE_ISTFT_2PASS") == nullptr) return 16;
+    return dvae_istft_workspace_bytes(T, nfft);
+}
+
 extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,
                           int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
     DVAE_CHECK_ARG(S && window && y && ws && T > 0 && ldT >= T && nfft >= 4 && (nfft % 2) == 0 && hop > 0 && start >= 0 && out_len >= 0,

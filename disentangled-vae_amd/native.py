@@ -41,6 +41,7 @@ SIGNATURES = {
     "dvae_adam_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i64, c_d, c_d, c_d, c_d, c_i, c_d, c_vp]),
     "dvae_stft": (c_i, [c_vp, c_i, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i, c_vp]),
     "dvae_istft_workspace_bytes": (c_sz, [c_i64, c_i]),
+    "dvae_istft_workspace_bytes_hop": (c_sz, [c_i64, c_i, c_i]),
     "dvae_istft": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dvae_transpose": (c_i, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "dvae_gather_rows": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i, c_vp, c_i64, c_vp, c_vp]),

@@ -79,7 +79,7 @@ def istft_device(S_dev, window, nfft, hop, n_frames, start, out_len):
         raise TypeError("istft_device: complex64 [nfft/2+1, T] CUDA tensor required")
     S_dev = S_dev.contiguous()
     y = torch.empty((out_len,), dtype=torch.float32, device=S_dev.device)
-    ws = torch.empty(max(lib.dvae_istft_workspace_bytes(n_frames, nfft), 8), dtype=torch.uint8, device=S_dev.device)
+    ws = torch.empty(max(lib.dvae_istft_workspace_bytes_hop(n_frames, nfft, hop), 16), dtype=torch.uint8, device=S_dev.device)
     N.check(lib.dvae_istft(N.ptr(S_dev), n_frames, S_dev.shape[1], N.ptr(window), nfft, hop, start, N.ptr(y), out_len,
                            N.ptr(ws), N.stream()), "dvae_istft")
     return y
