@@ -630,7 +630,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) xnx[gq] = reinterpret_cast<const F4U*>(xrow + 32 * (t + 4) + 8 * gq)->v;
                     }
+                    R2_HSTAMP(21 + 2 * I);
                     wg_barrier();                                       // RB0 .. RB3
+                    R2_HSTAMP(22 + 2 * I);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         float a4[4], da4[4];

@@ -37,6 +37,8 @@ if os.environ.get("DVAE_HSTAMPS"):
     t0 = r[:, 0:1]
     names_h = ["helper: y issued", "x stash issued", "past BL1X", "y committed", "lo-plane check done (at BY)"]
     print("  helper (us since tile start, median): " + "  ".join(f"{n}={np.median(r[:, 16 + i] - t0[:, 0]):.2f}" for i, n in enumerate(names_h)) +
+          "\n  out layer, helper (us since BD2): " + "  ".join(f"{'arrive' if i % 2 == 0 else 'pass'} RB{i // 2}={np.median(r[:, 21 + i] - r[:, 8]):.2f}" for i in range(8)) +
+          f" BDA={np.median(r[:, 9] - r[:, 8]):.2f}" +
           f"  | chain: BX={np.median(r[:,1]-t0[:,0]):.2f} L1x done={np.median(r[:,2]-t0[:,0]):.2f} L1y done={np.median(r[:,3]-t0[:,0]):.2f}")
 raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64)
 cyc = raw[:, 31] - raw[:, 30]; us = (raw[:, 15] - raw[:, 0]) * 0.01
