@@ -521,8 +521,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 rowsrc[half * TB + ht] = r;
             }
         };
-        f32x4 xv[NQ513];
+        f32x4 xv[NQ513], yv[NQ513];
         bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
+        bool y_in_regs = false;       // persistent loop: the NEXT tile's label tile is requested during this tile's backward phases too
         const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2) && g.stash_inputs;   // forward-only launches stash nothing
         for (int it = 0; it < ntl; ++it) {
             const int tile = (int)blockIdx.x + it * (int)gridDim.x;
@@ -538,8 +539,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             int tl = ht;
             asm volatile("" : "+v"(tl));
             const bool yfast = Y513 && g.fasty && full;
-            f32x4 yv[NQ513];
-            bool y_early = false;
+            bool y_early = it > 0 && y_in_regs;
             if (it == 0) {
                 if (gather) { fill_rows(tile, 0); wg_barrier(); }       // BROW
                 if (g.fastx && full) {
@@ -695,6 +695,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             wg_barrier();                                               // BDD1
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BDML
+            if constexpr (YP > 0 && Y513) {
+                // the next tile's labels: in flight from here to the next tile's BL1X (requested there, the 64 KB per CU take 4 us to
+                // arrive beside the weight stream and the chain waits for them)
+                y_in_regs = more && g.fasty && nfull;
+                if (y_in_regs) tile513_issue(g.y, nrowof, yv, tl);
+                else {
+#pragma unroll
+                    for (int i = 0; i < NQ513; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // full redefinition (see xv above)
+                }
+            }
             if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
             wg_barrier();                                               // BDH2
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
