@@ -1912,7 +1912,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     int wrep = 1;
     { const char* e = getenv("DVAE_WGRAD_REPEAT"); if (e) { wrep = atoi(e); if (wrep < 1) wrep = 1; } }   // diagnostic: re-run on the warm stash
     for (int rep = 0; rep < wrep; ++rep)
-    if (wgrad_form(wk) == 4) {
+    if (wgrad_form(wk) == 4 && (plan->Bp > 128 || raw_inputs || wk != nullptr)) {      // one 128-frame slice: the 2 x 2 kernel's short epilogue wins (11.2 vs 12.8 us)
         ProfScope ps(s, rep == 0 ? 1 : 2);
         const dim3 g3((unsigned)(L.nblocks4 * ks));
         RawIn ri;

@@ -488,15 +488,19 @@ def test_weight_gradients_from_raw_inputs_equal_the_stash_path(model, y_dim, B, 
     x, y, e = gu.make_batch(dims, B, 32)
     t = lambda a: None if a is None else torch.from_numpy(a).cuda()
     out = {}
-    for raw in (False, True):
-        if raw:
-            os.environ["DVAE_RAW_INPUTS"] = "1"
-        try:
-            tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
-            losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
-            out[raw] = (losses, tr.grads_numpy())
-        finally:
-            os.environ.pop("DVAE_RAW_INPUTS", None)
+    os.environ["DVAE_WGRAD"] = "wg4"            # the workgroup k-split kernel on both sides (steps of <= 128 frames default to the 2 x 2 kernel)
+    try:
+        for raw in (False, True):
+            if raw:
+                os.environ["DVAE_RAW_INPUTS"] = "1"
+            try:
+                tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+                losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+                out[raw] = (losses, tr.grads_numpy())
+            finally:
+                os.environ.pop("DVAE_RAW_INPUTS", None)
+    finally:
+        os.environ.pop("DVAE_WGRAD", None)
     np.testing.assert_array_equal(out[False][0], out[True][0])
     for k in out[False][1]:
         np.testing.assert_array_equal(out[False][1][k], out[True][1][k], err_msg=k)
