@@ -1208,8 +1208,24 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slice = blockIdx.x % ksplit, bi = blockIdx.x / ksplit;
-    if (bi >= nblocks) return;
+    // Workgroup -> (slice, block), XCD-aware (workgroup i runs on XCD i % 8).  The first 8 * (ksplit / 8) slices are "pure": slice s lives
+    // on XCD s % 8 with all of its blocks, so every stash line of it crosses the fabric once.  The ksplit % 8 remaining slices are
+    // dealt out block-wise, `per` consecutive blocks (neighbours share their A tiles) of them per XCD: a few lines are fetched by
+    // more than one XCD, and in exchange the grid covers the CUs (M2 y513: 10 slices x 24 blocks = 240 workgroups, 13 k-steps per
+    // wave instead of 16 at 8 slices).
+    int slice, bi;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int a8 = ksplit >> 3, r8 = ksplit & 7;
+        const int npure = a8 * nblocks;
+        if (j < npure) { slice = xcd + 8 * (j / nblocks); bi = j % nblocks; }
+        else {
+            const int per = (r8 * nblocks + 7) >> 3;
+            const int e = xcd * per + (j - npure);
+            if (j - npure >= per || e >= r8 * nblocks) return;
+            slice = 8 * a8 + e / nblocks; bi = e % nblocks;
+        }
+    }
     const Block4 bd = blocks[bi];                                       // by value: wave-uniform, lives in SGPRs (a reference would be re-read after every slab store)
     int na = 0, nb = 0;
 #pragma unroll
@@ -1538,10 +1554,8 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
         Layout L0;
         make_layout(tmp, L0);
         ks = 256 / L0.nblocks4;
-        // bf16 policies are bound by the cold read of the stash: keep every slice on ONE XCD (workgroup i runs on XCD i % 8 and
-        // slice = i % ks), so that each stash line crosses the fabric once -- a multiple of 8 slices (M2 y513: 8 x 22 workgroups
-        // 28.5 us, 11 x 22 33.9 us under bf16x3).  The fp32 policy is MFMA-bound: as many workgroups as CUs (59 us at 11 slices, 71 at 8).
-        if (is_bf(precision) && ks >= 8) ks = ks / 8 * 8;
+        // as many slices as fill the CUs; the kernel's XCD-aware index map keeps 8 * (ks / 8) of them on one XCD each (the bf16 policies
+        // are bound by the cold read of the stash) and deals the rest out block-wise
         if (ks > plan->Bp / 128) ks = (int)(plan->Bp / 128);
         if (ks > 16) ks = 16;
         if (ks < 1) ks = 1;
@@ -1914,7 +1928,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     for (int rep = 0; rep < wrep; ++rep)
     if (wgrad_form(wk) == 4 && (plan->Bp > 128 || raw_inputs || wk != nullptr)) {      // one 128-frame slice: the 2 x 2 kernel's short epilogue wins (11.2 vs 12.8 us)
         ProfScope ps(s, rep == 0 ? 1 : 2);
-        const dim3 g3((unsigned)(L.nblocks4 * ks));
+        const dim3 g3((unsigned)(8 * ((ks >> 3) * L.nblocks4 + (((ks & 7) * L.nblocks4 + 7) >> 3))));   // see the index map at the top of wgrad4_kernel
         RawIn ri;
         ri.x = x; ri.y = y; ri.ldx = ldx; ri.ldy = plan->y_dim ? ldy : 0; ri.B = plan->B;
         const int use_raw = raw_inputs ? 1 : 0;

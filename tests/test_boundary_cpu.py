@@ -151,8 +151,8 @@ def test_non_integer_window_raises():
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_train_plan_is_host_only_and_consistent(model, y_dim, precision):
     """dvae_train_plan is pure host logic (no GPU): tensor table in state_dict order, frame padding, and the slice count of the
-    weight-gradient pass -- a multiple of 8 for the bf16 policies at 8192 frames (one slice per XCD, so that every stash line
-    crosses the fabric once), at most 16 (the apply pass sums that many slabs with independent loads), never more than the
+    weight-gradient pass -- as many as fill the CUs in one round (the kernel's XCD-aware index map keeps 8 * (ks / 8) of them on
+    one XCD each), at most 16 (the apply pass sums that many slabs with independent loads), never more than the
     frames allow; an explicit hint wins."""
     T = importlib.import_module("disentangled-vae_amd.trainer")
     lib = native.load()
@@ -164,8 +164,8 @@ def test_train_plan_is_host_only_and_consistent(model, y_dim, precision):
         offs = [plan.tensor_offset[i] for i in range(plan.n_tensors)]
         assert offs == sorted(offs) and all(o % 64 == 0 for o in offs) and plan.n_params >= offs[-1]
         assert 1 <= plan.ksplit <= 16 and plan.ksplit <= max(1, plan.Bp // 128)
-        if B == 8192 and precision != "fp32":
-            assert plan.ksplit % 8 == 0
+        if B == 8192:
+            assert plan.ksplit >= 7          # enough (slice, block) workgroups to cover the CUs in one round
         assert plan.workspace_bytes > plan.grad_offset_bytes > 0
         assert plan.workspace_bytes - plan.grad_offset_bytes >= plan.ksplit * plan.n_params * 4
         assert 1 <= plan.rows_grid <= 512
