@@ -8,35 +8,41 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-_pkg = None
+_cache = {}
+
+
+def _mod(name):
+    """The named submodule of the native package, imported once (importlib.import_module costs ~10 us per call even when the module
+    is loaded, and the drop-in modules come through here three times per training step)."""
+    m = _cache.get(name)
+    if m is None:
+        m = _cache[name] = importlib.import_module("disentangled-vae_amd" + ("." + name if name else ""))
+    return m
 
 
 def pkg():
-    global _pkg
-    if _pkg is None:
-        _pkg = importlib.import_module("disentangled-vae_amd")
-    return _pkg
+    return _mod("")
 
 
 def ops():
-    return importlib.import_module("disentangled-vae_amd.ops")
+    return _mod("ops")
 
 
 def native():
-    return importlib.import_module("disentangled-vae_amd.native")
+    return _mod("native")
 
 
 def module_path():
-    return importlib.import_module("disentangled-vae_amd.module_path")
+    return _mod("module_path")
 
 
 def stft_host():
-    return importlib.import_module("disentangled-vae_amd.stft")
+    return _mod("stft")
 
 
 def mcem_dev():
-    return importlib.import_module("disentangled-vae_amd.mcem")
+    return _mod("mcem")
 
 
 def target_dev():
-    return importlib.import_module("disentangled-vae_amd.target")
+    return _mod("target")
