@@ -1252,21 +1252,37 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
 #undef W4_GO
 }
 
+// sum of up to NS slabs at element i: every load issued before the first addition (a run-time loop makes each addition wait for
+// its own load: ten dependent round trips), additions in slab order (deterministic)
+template <int NS>
+__device__ __forceinline__ float slab_total(const float* __restrict__ slabs, int64_t i, int nslabs, int64_t stride) {
+    float part[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) part[k] = slabs[(int64_t)(k < nslabs ? k : 0) * stride + i];
+    float t = part[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) if (k < nslabs) t += part[k];
+    return t;
+}
+__device__ __forceinline__ float slab_total_any(const float* __restrict__ slabs, int64_t i, int nslabs, int64_t stride) {
+    if (nslabs <= 8) return slab_total<8>(slabs, i, nslabs, stride);
+    if (nslabs <= 16) return slab_total<16>(slabs, i, nslabs, stride);
+    float s = slabs[i];
+    for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
+    return s;
+}
+
 // dst = (accumulate ? dst : 0) + sum of the slabs (fixed order: deterministic)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride, float* __restrict__ dst, int accumulate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = slabs[i];
-        for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
+        const float s = slab_total_any(slabs, i, nslabs, stride);
         dst[i] = accumulate ? dst[i] + s : s;
     }
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int64_t n, int nslabs, int64_t stride) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = slabs[i];
-        for (int k = 1; k < nslabs; ++k) s += slabs[k * stride + i];
-        slabs[i] = s;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        slabs[i] = slab_total_any(slabs, i, nslabs, stride);
 }
 
 // ---------------------------------------------------------------------------------------------
