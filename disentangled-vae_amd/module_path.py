@@ -9,11 +9,17 @@ geometry (x 513, h [128, 128], z 16, y 0 / 1 / 513) run as ONE autograd Function
 
 The training scripts keep `loss.backward()` and their own stock `torch.optim.Adam` (scripts/training_M2.py:122, 142-147).
 To make that cheap the engine keeps the module's 14 parameters as views of ONE flat fp32 buffer in the fused kernels'
-plan layout (they stay ordinary nn.Parameters: state_dict, load_state_dict, optimizers see nothing new), and the backward
-pass leaves every `.grad` as a view of one flat gradient buffer.  `.grad` is written by the Function's backward directly
-(accumulating if a gradient is already there), which is what AccumulateGrad would do with 14 separate tensors, minus 14
-clone kernels; hooks on parameters are therefore not run on this path -- set DVAE_MODULE_PATH=layers to take the
-layer-level Functions of ops.py instead (they also cover every other geometry).
+plan layout (they stay ordinary nn.Parameters: state_dict, load_state_dict, optimizers see nothing new).  The Function's
+backward RETURNS the 14 parameter gradients -- views of one flat buffer allocated per backward pass -- so everything
+autograd does with a gradient stays autograd's: AccumulateGrad takes the views as `.grad` without a copy when there is
+none yet (the scripts' zero_grad() sets them to None every step) and adds otherwise, tensor hooks and post-accumulate
+hooks run, `torch.autograd.grad(loss, params)` works.  The forward is recomputed on chip in the backward from the CURRENT
+parameters, so a parameter changed in place between forward and backward raises, like autograd's version check does.
+
+Only grad-mode forwards take this path: inference (no_grad, or every parameter frozen -- scripts/reconstruct_M2.py:111-113)
+runs the per-layer Functions of ops.py on the exact fp32 matrix cores, like direct `model.encoder(...)` /
+`model.decoder(...)` calls (packages/models/mcem.py) do, so the two agree to fp32 rounding and no per-batch-size
+workspace is ever built for a forward-only call.  DVAE_MODULE_PATH=layers takes the per-layer path everywhere.
 
 MFMA operand policy: DVAE_MODULE_PRECISION (default bf16x3, the parity-grade split-bf16 policy; bf16 = fast and loose).
 """
@@ -55,20 +61,23 @@ class ModuleEngine:
         self.spans = [(int(p0.tensor_offset[i]), int(p0.tensor_rows[i]) * int(p0.tensor_cols[i])) for i in range(len(self.params))]
         with torch.cuda.device(self.device):
             self.flat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
-            self.gflat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
-            self.gtmp = None
-        self.gviews = [self.gflat[o:o + n].view(p.shape) for p, (o, n) in zip(self.params, self.spans)]     # what .grad points at
-        self.gptrs = [v.data_ptr() for v in self.gviews]
         self.pptrs = [self.flat.data_ptr() + 4 * o for o, _ in self.spans]
         self._alias()
 
     def __deepcopy__(self, memo):          # a copied module rebuilds its own engine on first use
         return None
 
-    # ---- plans (one per batch size) ----
+    # ---- plans (one per batch size; each holds a training workspace: stash, gradient slabs, weight copies).  At most
+    # MAX_PLANS are kept, least recently used first out (a training loop sees its batch size and the last, shorter batch)
+    MAX_PLANS = 4
+
     def _plan(self, B):
-        got = self.plans.get(B)
+        got = self.plans.pop(B, None)
+        if got is not None:
+            self.plans[B] = got                    # most recently used last
         if got is None:
+            while len(self.plans) >= self.MAX_PLANS:
+                self.plans.pop(next(iter(self.plans)))
             plan = TrainPlan()
             N.check(self.lib.dvae_train_plan(MODEL_CODE[self.model], self.y_dim, PREC_CODE[self.precision], int(B), 0, ctypes.byref(plan)),
                     "dvae_train_plan")
@@ -115,52 +124,42 @@ class ModuleEngine:
                                                  N.ptr(r), 513, N.ptr(mlz[0]), N.ptr(mlz[1]), N.ptr(mlz[2]), 1, N.stream()), "dvae_module_forward")
         return r, mlz[2], mlz[0], mlz[1]
 
-    def backward(self, x, y, eps, gr, gz, gmu, glv):
+    def backward(self, x, y, eps, gr, gz, gmu, glv, needs):
+        """-> list of 14 parameter gradients (None where `needs` is False): views of one flat buffer of this call."""
         B = x.shape[0]
         plan, ws = self._ready(B)
-        grads = [p.grad for p in self.params]
-        if all(g is None for g in grads):
-            dst, acc, how = self.gflat, 0, "assign"
-        elif all(g is not None and g.data_ptr() == gp for g, gp in zip(grads, self.gptrs)):
-            dst, acc, how = self.gflat, 1, "inplace"          # gradient accumulation over several backward passes
-        else:
-            if self.gtmp is None:
-                self.gtmp = torch.empty_like(self.gflat)
-            dst, acc, how = self.gtmp, 0, "add"
-        c = lambda t: None if t is None else (t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().to(torch.float32))
-        gr_ = None if gr is None else (gr if (gr.stride(1) == 1 and gr.dtype == torch.float32) else gr.contiguous().to(torch.float32))
-        gz, gmu, glv = c(gz), c(gmu), c(glv)
+        f32c = lambda t: None if t is None else _rows_ok(t.to(torch.float32))
+        gr_, gz, gmu, glv = f32c(gr), f32c(gz), f32c(gmu), f32c(glv)
+        if gz is not None: gz = gz.contiguous()
+        if gmu is not None: gmu = gmu.contiguous()
+        if glv is not None: glv = glv.contiguous()
         with torch.cuda.device(self.device):
+            dst = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
             yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
             N.check(self.lib.dvae_module_backward(ctypes.byref(plan), N.ptr(self.flat), N.ptr(ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps),
                                                   N.ptr(gr_), 0 if gr_ is None else N.ld(gr_), N.ptr(gmu), N.ptr(glv), N.ptr(gz),
-                                                  N.ptr(dst), acc, N.stream()), "dvae_module_backward")
-        if how == "inplace":
-            return
-        if how == "assign":
-            for p, v in zip(self.params, self.gviews):
-                if p.requires_grad:
-                    p.grad = v
-            return
-        for p, g, (o, n) in zip(self.params, grads, self.spans):
-            if not p.requires_grad:
-                continue
-            view = dst[o:o + n].view(p.shape)
-            if g is None:
-                p.grad = view.clone()
-            else:
-                g.add_(view)
+                                                  N.ptr(dst), 0, N.stream()), "dvae_module_backward")
+        return [dst[o:o + n].view(p.shape) if need else None for p, (o, n), need in zip(self.params, self.spans, needs)]
+
+
+def _rows_ok(t):
+    """A [B, C] operand the kernels can address: unit column stride and a row stride that covers the row (an expanded /
+    broadcast tensor -- the gradient of r.sum(0), an expanded input row -- has stride 0 and is materialised)."""
+    if t.dim() != 2 or (t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+        return t
+    return t.contiguous()
 
 
 class VaeFunction(torch.autograd.Function):
-    """(r, z, mu, log_var) = model(x, y) with reparametrisation noise eps; the parameters are passed so that autograd knows
-    the outputs depend on them -- their gradients are deposited in .grad by backward() itself (module docstring)."""
+    """(r, z, mu, log_var) = model(x, y) with reparametrisation noise eps; the parameters are inputs of the Function and
+    backward returns their gradients (module docstring)."""
 
     @staticmethod
     def forward(ctx, engine, x, y, eps, *params):
         r, z, mu, lv = engine.forward(x, y, eps)
         ctx.engine = engine
         ctx.has_y = y is not None
+        ctx.versions = [p._version for p in params]
         ctx.save_for_backward(x, y if y is not None else x.new_empty(0), eps)
         ctx.set_materialize_grads(False)
         return r, z, mu, lv
@@ -168,8 +167,17 @@ class VaeFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gr, gz, gmu, glv):
         x, y, eps = ctx.saved_tensors
-        ctx.engine.backward(x, y if ctx.has_y else None, eps, gr, gz, gmu, glv)
-        return (None,) * (4 + len(ctx.engine.params))
+        eng = ctx.engine
+        # the backward kernel recomputes the forward from the flat parameter buffer as it is NOW
+        for p, v0, name in zip(eng.params, ctx.versions, TENSOR_NAMES):
+            if p._version != v0:
+                raise RuntimeError(f"one of the variables needed for gradient computation has been modified by an inplace operation: parameter "
+                                   f"'{name}' is at version {p._version}, the forward saw version {v0} (an optimizer step or load_state_dict "
+                                   f"between forward and backward); run the forward again")
+        if any(p.data_ptr() != want for p, want in zip(eng.params, eng.pptrs)):
+            raise RuntimeError("a parameter's storage was replaced between forward and backward (module.to() / .data assignment): run the forward again")
+        grads = eng.backward(x, y if ctx.has_y else None, eps, gr, gz, gmu, glv, ctx.needs_input_grad[4:])
+        return (None, None, None, None, *grads)
 
 
 def engine_for(module, model, x, y):
@@ -178,6 +186,8 @@ def engine_for(module, model, x, y):
         return None
     if x.requires_grad or (y is not None and y.requires_grad):
         return None                                  # gradients with respect to the data are a layer-path feature
+    if not torch.is_grad_enabled():
+        return None                                  # inference: the exact-fp32 per-layer kernels (module docstring)
     eng = module.__dict__.get("_dvae_engine")
     if eng is None:
         if module.__dict__.get("_dvae_engine_off"):
@@ -194,7 +204,7 @@ def engine_for(module, model, x, y):
             return None
         eng = ModuleEngine(module, model, module.y_dim if model == "M2" else 0)
         object.__setattr__(module, "_dvae_engine", eng)
-    if not eng.usable(x):
+    if not eng.usable(x) or not any(p.requires_grad for p in eng.params):
         return None
     if model == "M2" and (y is None or y.dim() != 2 or y.shape != (x.shape[0], eng.y_dim) or y.dtype != torch.float32 or y.device != x.device):
         return None
@@ -203,12 +213,10 @@ def engine_for(module, model, x, y):
 
 def run(eng, x, y, eps):
     """-> (r, z, mu, log_var).  eps: [B, 16] float32 on x's device."""
-    x = x if x.stride(1) == 1 else x.contiguous()
+    x = _rows_ok(x)
     if y is not None:
-        y = y if y.stride(1) == 1 else y.contiguous()
+        y = _rows_ok(y)
     eps = eps.to(device=x.device, dtype=torch.float32).contiguous()
     if eps.shape != (x.shape[0], 16):
         raise RuntimeError(f"reparametrisation noise must be [{x.shape[0]}, 16], got {tuple(eps.shape)}")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in eng.params):
-        return VaeFunction.apply(eng, x, y, eps, *eng.params)
-    return eng.forward(x, y, eps)
+    return VaeFunction.apply(eng, x, y, eps, *eng.params)

@@ -43,6 +43,20 @@ def test_fused_fp32_matches_reference_vectors(vae_golden, case):
     check_case(FusedImpl("fp32"), vae_golden, case)
 
 
+ALL_FULL = FULL + [c for c in gu.CASES if c[0] in ("M2info_full", "M2info_full_b1")]
+
+
+@pytest.mark.parametrize("case", ALL_FULL, ids=[c[0] for c in ALL_FULL])
+def test_fused_bf16x3_matches_reference_vectors(vae_golden, case):
+    """The BENCHMARKED operand policy (bf16x3: split-bf16 operands, three MFMAs per product) against the vectors captured from the
+    reference itself (fp32 torch on CPU), all six reference-geometry cases, three Adam steps each.  Stated bounds: loss scalars 1e-5
+    relative; every gradient element within 1e-4 relative + 2e-4 of its tensor's maximum (measured worst: profiles/r03_parity.json);
+    parameters after 1 and 3 Adam steps within steps x lr everywhere and within the fp32 bound for all but 6 % of the elements
+    (Adam's first steps are sign-like: an element whose gradient is rounding noise moves by +-lr in any two correct implementations)."""
+    impl = FusedInfoImpl("bf16x3") if case[1] == "M2_info" else FusedImpl("bf16x3")
+    check_case(impl, vae_golden, case, rtol_loss=1e-5, rtol_grad=1e-4, atol_rel_grad=2e-4, bad_frac=0.06)
+
+
 def _oracle_step(model, dims, params, x, y, e):
     p = {k: v.copy() for k, v in params.items()}
     opt = vo.AdamState(list(p))
@@ -59,8 +73,8 @@ def _relmax(a, b):
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_fused_step_vs_oracle(model, y_dim, B, precision):
     """fp32 operand mode: <= 1e-4 relative (north_star bar) on losses and gradients.
-    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-4 relative (measured ~1e-6),
-    every gradient tensor within 1e-3 of its maximum (measured <= 2e-4; tools/exp_precision.py predicts 1e-4).
+    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-5 relative (measured <= 3e-7),
+    every gradient tensor within 2e-4 of its maximum (measured <= 1.1e-4, profiles/r03_parity.json; tools/exp_precision.py predicts 1e-4).
     bf16 (one bf16 per operand, opt-in fast mode): the synthetic power spectra span 1e-12 .. 1e4, so bf16
     rounding of x and W1 moves encoder pre-activations by O(1) on the loudest frames; measured deviation bound
     stated here: losses 2e-3 relative, every gradient tensor cosine >= 0.99 with the fp64 oracle and within 0.3 of its max."""
@@ -73,7 +87,7 @@ def test_fused_step_vs_oracle(model, y_dim, B, precision):
     t = lambda a: None if a is None else torch.from_numpy(a).cuda()
     losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
     ref = np.array([out["loss"], out["recon"], out["kl"]])
-    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-3), "bf16": (2e-3, 0.3)}[precision]
+    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16x3": (1e-5, 2e-4), "bf16": (2e-3, 0.3)}[precision]
     np.testing.assert_allclose(losses, ref, rtol=ltol)
     g = tr.grads_numpy()
     worst = max(_relmax(g[k], np.asarray(grads[k], np.float64).reshape(g[k].shape)) for k in grads)

@@ -129,6 +129,93 @@ def test_parameters_stay_ordinary_parameters(monkeypatch):
         M.Stochastic.epsilon_fn = None
 
 
+def test_autograd_semantics_hooks_grad_versions_and_broadcast_gradients(monkeypatch):
+    """The whole-model Function returns real parameter gradients, so autograd's own machinery applies: tensor hooks and
+    post-accumulate hooks fire, torch.autograd.grad works and leaves .grad alone, a parameter changed in place between
+    forward and backward raises (the backward recomputes the forward from the current parameters), and upstream gradients /
+    inputs with broadcast strides (the gradient of r.sum(0)) are accepted.  Checked against the per-layer path."""
+    from packages.models import models as M
+    from packages.models.utils import elbo
+    monkeypatch.delenv("DVAE_MODULE_PATH", raising=False)
+    dims, m, ref = _models("M2", 513, 21)
+    x, y, e = (torch.from_numpy(a).cuda() for a in gu.make_batch(dims, 96, 3))
+    M.Stochastic.epsilon_fn = lambda mu: e
+    try:
+        def loss_of(mod):
+            r, mu, lv = mod(x, y)
+            return r.sum(0).sum() * 1e-3 + mu.mean() + elbo(x, r, mu, lv, 1e-8)[0]      # r.sum(0): stride-0 upstream gradient
+        monkeypatch.setenv("DVAE_MODULE_PATH", "layers")
+        want = torch.autograd.grad(loss_of(ref), list(ref.parameters()))
+        monkeypatch.delenv("DVAE_MODULE_PATH")
+        # torch.autograd.grad: gradients come back, .grad stays untouched
+        got = torch.autograd.grad(loss_of(m), list(m.parameters()))
+        assert m.__dict__.get("_dvae_engine") is not None
+        assert all(p.grad is None for p in m.parameters())
+        for g, w, (k, _) in zip(got, want, m.named_parameters()):
+            d = (g - w).abs().max().item() / (w.abs().max().item() + 1e-30)
+            assert d < 2e-4, (k, d)
+        # hooks run
+        fired = {"tensor": 0, "post": 0}
+        first = next(m.parameters())
+        h1 = first.register_hook(lambda g: fired.__setitem__("tensor", fired["tensor"] + 1))
+        h2 = first.register_post_accumulate_grad_hook(lambda p: fired.__setitem__("post", fired["post"] + 1))
+        loss_of(m).backward()
+        assert fired == {"tensor": 1, "post": 1}
+        torch.testing.assert_close(first.grad, got[0], rtol=0, atol=0)            # deterministic: the same numbers as above
+        h1.remove(); h2.remove()
+        # an expanded input row (stride 0) is materialised, not rejected
+        xe = x[:1].expand(96, 513)
+        r_e = m(xe, y)[0]
+        monkeypatch.setenv("DVAE_MODULE_PATH", "layers")
+        r_l = ref(xe, y)[0]
+        monkeypatch.delenv("DVAE_MODULE_PATH")
+        np.testing.assert_allclose(r_e.detach().cpu().numpy(), r_l.detach().cpu().numpy(), rtol=2e-4)
+        # a parameter changed in place between forward and backward: error, like autograd's version check
+        m.zero_grad()
+        l = loss_of(m)
+        with torch.no_grad():
+            first.add_(0.01)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            l.backward()
+    finally:
+        M.Stochastic.epsilon_fn = None
+
+
+def test_workspaces_stay_bounded_over_many_batch_sizes(monkeypatch):
+    """scripts/reconstruct_M2.py:193 calls model(S.T, y.T) once per utterance with T frames under no_grad / frozen parameters:
+    that is the per-layer path (no per-batch-size state at all).  Training-mode forwards keep at most ModuleEngine.MAX_PLANS
+    workspaces (least recently used first out)."""
+    from packages.models import models as M
+    monkeypatch.delenv("DVAE_MODULE_PATH", raising=False)
+    dims, m, _ = _models("M2", 1, 5)
+    M.Stochastic.epsilon_fn = lambda mu: torch.zeros_like(mu)
+    try:
+        x = torch.rand(400, 513, device="cuda") + 0.01
+        y = (torch.rand(400, 1, device="cuda") > 0.5).float()
+        with torch.no_grad():
+            m(x[:50], y[:50])
+        assert m.__dict__.get("_dvae_engine") is None                               # inference never builds the fused engine
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        with torch.no_grad():
+            for T in range(60, 360, 6):                                             # 50 distinct utterance lengths
+                r = m(x[:T], y[:T])[0]
+        del r
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() - base < (1 << 20)
+        sizes = []
+        for i, B in enumerate(range(32, 32 + 12 * 32, 32)):                         # 12 distinct training batch sizes
+            m(x[:B], y[:B])[0].sum().backward()
+            m.zero_grad()
+            torch.cuda.synchronize()
+            sizes.append(torch.cuda.memory_allocated())
+        eng = m.__dict__["_dvae_engine"]
+        assert len(eng.plans) <= eng.MAX_PLANS
+        assert max(sizes[6:]) - min(sizes[6:]) < (8 << 20), sizes                   # steady state: eviction keeps it flat
+    finally:
+        M.Stochastic.epsilon_fn = None
+
+
 def test_default_noise_is_the_reference_host_generator(monkeypatch):
     """Without an epsilon hook the fused forward draws torch.randn on the HOST generator like the reference (quirk Q1): the same
     seed gives the same noise as the per-layer path."""
