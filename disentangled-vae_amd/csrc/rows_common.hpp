@@ -72,6 +72,12 @@ struct RowsArgs {
     unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
     int stash_inputs;           // 0: the weight-gradient kernel reads x / y from the input matrices, no stash for them (8-wave kernel only)
+    // Label tiles that one bf16 plane holds exactly (binary VAD / IBM labels) have an all-zero lo plane: the 8-wave kernel then stores only
+    // the hi plane of the label stash (ylo_skip != 0) and raises *ylo_epoch to `launch_id` as soon as ANY tile of the launch does need its
+    // lo plane; the weight-gradient kernel reads the label lo plane (and issues the hi * lo products) only in that case.
+    // ylo_dirty[tile]: this tile slot's lo plane in the stash holds non-zero values from an earlier launch -- a tile that needs no lo plane
+    // now still rewrites it (with its zeros) once, so that a launch in which SOME tile is flagged never reads stale lo values of the others.
+    unsigned* ylo_epoch; unsigned launch_id; int ylo_skip; int* ylo_dirty;
 };
 
 #ifdef DVAE_FINE_STAMPS
@@ -94,7 +100,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
 
 template <typename P>
 __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr, int64_t spl,
-                                           int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30) {
+                                           int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30, int nplanes = P::NP) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
@@ -131,8 +137,8 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
 #pragma unroll
                     for (int j = 0; j < E; ++j) f[pl][j] = P::cvt(0.f);
             }
-#pragma unroll
-            for (int pl = 0; pl < P::NP; ++pl) *reinterpret_cast<Frag*>(dst + pl * spl + gq * 32 * E) = f[pl];
+            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f[0];
+            if constexpr (P::NP == 2) { if (nplanes == 2) *reinterpret_cast<Frag*>(dst + spl + gq * 32 * E) = f[1]; }      // wave-uniform
         }
     } else {
 #pragma unroll
@@ -153,12 +159,16 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
 // generic (edge tile / strided / unaligned input): global [32 frames][ncols] fp32 -> LDS as T, zero padded
 template <typename P, typename RowOf>
 __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, int ld, int ncols, int pcols, int64_t b0, int64_t B,
-                                                 typename P::T* U, int ldu, int tid, RowOf rowof, float* xf = nullptr) {
+                                                 typename P::T* U, int ldu, int tid, RowOf rowof, float* xf = nullptr,
+                                                 float* log2sum = nullptr, float eps = 0.f) {
     const int total = TB * pcols;
     for (int idx = tid; idx < total; idx += 256) {
         const int row = idx / pcols, col = idx - row * pcols;
         float v = 0.f;
-        if (col < ncols && b0 + row < B) v = src[rowof(row) * ld + col];
+        if (col < ncols && b0 + row < B) {
+            v = src[rowof(row) * ld + col];
+            if (log2sum && col < XD - 1) *log2sum += __builtin_amdgcn_logf(v + eps);      // live frames, bins 0 .. 511 (see tile513_log2sum)
+        }
         const typename P::T vh = P::cvt(v);
         U[row * ldu + col] = vh;
         if constexpr (P::NP == 2) U[Pl<P>::lds + row * ldu + col] = P::cvt(v - (float)vh);
@@ -172,22 +182,31 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
 // dwordx4 loads at dword alignment.  Column 512 of row (t & 31) rides in slot 16.
 constexpr int NQ513 = 17;
 struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
-template <typename RowOf>
-__device__ __forceinline__ void tile513_issue(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
+// chunks [I0, I1) of the tile (16 chunks of 4 columns per thread; slot 16 = column 512: tile513_issue_last)
+template <int I0, int I1, typename RowOf>
+__device__ __forceinline__ void tile513_issue_part(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = I0; i < I1; ++i) {
         const int c = tid + 256 * i;
         v[i] = reinterpret_cast<const F4U*>(base + rowof(c >> 7) * XD + 4 * (c & 127))->v;
     }
+}
+template <typename RowOf>
+__device__ __forceinline__ void tile513_issue_last(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
     v[16][0] = base[rowof(tid & 31) * XD + XD - 1];
+}
+template <typename RowOf>
+__device__ __forceinline__ void tile513_issue(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
+    tile513_issue_part<0, 16>(base, rowof, v, tid);
+    tile513_issue_last(base, rowof, v, tid);
     __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
 }
-template <typename P, int PCOLS>
-__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr, bool* any_lo = nullptr) {
+// chunks [I0, I1) -> (hi, lo) planes of the LDS image; lo_bits collects the OR of every lo-plane word written
+template <typename P, int I0, int I1>
+__device__ __forceinline__ void tile513_commit_part(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf, unsigned long long& lo_bits) {
     typedef typename P::Pack4 Pack4;
-    unsigned long long lo_bits = 0ull;                          // OR of every lo-plane word this thread writes (any_lo: is the lo plane needed at all?)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = I0; i < I1; ++i) {
         const int c = tid + 256 * i;
         const int row = c >> 7, col = 4 * (c & 127);
         if (xf) {                                              // dense [frame][513] fp32 copy (rows 4-byte aligned)
@@ -202,10 +221,14 @@ __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename
             pl[0] = P::cvt(v[i][0] - (float)pk[0]); pl[1] = P::cvt(v[i][1] - (float)pk[1]);
             pl[2] = P::cvt(v[i][2] - (float)pk[2]); pl[3] = P::cvt(v[i][3] - (float)pk[3]);
             *reinterpret_cast<Pack4*>(U + Pl<P>::lds + row * ldu + col) = pl;
-            if (any_lo) lo_bits |= __builtin_bit_cast(unsigned long long, pl) & 0x7fff7fff7fff7fffull;   // -0 is not "non-zero"
+            lo_bits |= __builtin_bit_cast(unsigned long long, pl) & 0x7fff7fff7fff7fffull;   // -0 is not "non-zero"
         }
     }
-    constexpr int PADC = PCOLS - XD;                            // column 512, then PADC zero columns
+}
+// column 512 (slot 16), then the PCOLS - 513 zero columns
+template <typename P, int PCOLS>
+__device__ __forceinline__ void tile513_commit_last(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf, unsigned long long& lo_bits) {
+    constexpr int PADC = PCOLS - XD;
     if (tid < TB) {
         if (xf) xf[tid * XD + XD - 1] = v[16][0];
         const typename P::T vh = P::cvt(v[16][0]);
@@ -213,29 +236,48 @@ __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename
         if constexpr (P::NP == 2) {
             const typename P::T vl = P::cvt(v[16][0] - (float)vh);
             U[Pl<P>::lds + tid * ldu + XD - 1] = vl;
-            if (any_lo && (float)vl != 0.f) lo_bits |= 1ull;
+            if ((float)vl != 0.f) lo_bits |= 1ull;
         }
     }
-    if (any_lo) *any_lo = lo_bits != 0ull;
     for (int idx = tid; idx < TB * PADC; idx += 256) {
         const int r = idx / PADC, c = XD + idx - r * PADC;
         U[r * ldu + c] = P::cvt(0.f);
         if constexpr (P::NP == 2) U[Pl<P>::lds + r * ldu + c] = P::cvt(0.f);
     }
 }
+template <typename P, int PCOLS>
+__device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr, bool* any_lo = nullptr) {
+    unsigned long long lo_bits = 0ull;                          // OR of every lo-plane word this thread writes (any_lo: is the lo plane needed at all?)
+    tile513_commit_part<P, 0, 16>(v, U, ldu, tid, xf, lo_bits);
+    tile513_commit_last<P, PCOLS>(v, U, ldu, tid, xf, lo_bits);
+    if (any_lo) *any_lo = lo_bits != 0ull;
+}
+// sum over this thread's share of a full dense tile of log2(x + eps), columns 0 .. 511 (hardware log2: the loss epilogue's log terms,
+// taken while the tile sits in registers; utils.py:74 -- the caller scales by ln 2).  Bin 512 is not included: the wave that owns the
+// 17th output tile computes that bin's whole term itself.
+__device__ __forceinline__ float tile513_log2sum(const f32x4 (&v)[NQ513], float eps, int tid) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        s0 += __builtin_amdgcn_logf(v[i][0] + eps) + __builtin_amdgcn_logf(v[i][1] + eps);
+        s1 += __builtin_amdgcn_logf(v[i][2] + eps) + __builtin_amdgcn_logf(v[i][3] + eps);
+    }
+    return s0 + s1;
+}
 
 // LDS U[frame][col] -> fragment-major stash (see put_tile), 16 bytes (E frames of one feature) per
 // store; feature rows up to `srows` (multiple of 32) are written, columns >= pcols as zeros
 template <typename P>
 __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, int pcols, int srows, typename P::T* stash, int64_t spl,
-                                               int64_t Bp, int64_t b0, int tid) {
+                                               int64_t Bp, int64_t b0, int tid, int ft0 = 0, int ft1 = 1 << 30, int nplanes = P::NP) {
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
     if constexpr (sizeof(typename P::T) == 2) {
-        // one wave per 32-feature tile (wave-uniform loop: EXEC stays all ones for the transposing reads)
+        // one wave per 32-feature tile (wave-uniform loop: EXEC stays all ones for the transposing reads); feature tiles [ft0, ft1)
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        for (int ft = wave; ft < srows / 32; ft += 4)
-            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, spl, b0, lane & 31, lane >> 5, 1.f, pcols);
+        const int fte = ft1 < srows / 32 ? ft1 : srows / 32;
+        for (int ft = ft0 + wave; ft < fte; ft += 4)
+            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, spl, b0, lane & 31, lane >> 5, 1.f, pcols, nplanes);
         return;
     }
     constexpr int groups = TB / E;

@@ -21,6 +21,7 @@
 // the frame axis cut into `ksplit` slabs that the apply kernel sums in a fixed order
 // (deterministic: no atomics anywhere).  Bias gradients ride along as one extra MFMA against a
 // constant-one fragment.
+#include <atomic>
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -927,7 +928,8 @@ template <typename P> struct Wg4 {
 // branch makes hipcc's wait-count pass fall back to vmcnt(0) in front of the first MFMA of every k-step (the ring then holds one).
 struct RawIn { const float* x; const float* y; int ldx, ldy; int64_t B; };
 
-template <typename P, int NA, int NB, int RAW>
+// BLO = false: the B tiles (labels) have no lo plane in this launch -- it is neither read nor multiplied
+template <typename P, int NA, int NB, int RAW, bool BLO = true>
 __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __restrict__ bdg, char* wsm, int slice, int64_t Bp, int64_t spl, int64_t kper,
                                             float* __restrict__ slabs, int64_t slab_stride, int lane, int wave, const RawIn& ri) {
     typedef typename P::T T;
@@ -1013,7 +1015,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 b[s][k][0] = *(gfrag)(bp[k] + o + loff);
-                if constexpr (NP == 2) b[s][k][1] = *(gfrag)(bp[k] + plb + o + loff);
+                if constexpr (NP == 2 && BLO) b[s][k][1] = *(gfrag)(bp[k] + plb + o + loff);
             }
         }
     };
@@ -1081,7 +1083,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j]);
+                for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j], BLO);
                 bs[i] += fsum(a[s][i][0]);                               // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
                 if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
             }
@@ -1204,7 +1206,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 template <typename P>
 __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
                                                         int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride,
-                                                        const RawIn ri, int use_raw) {
+                                                        const RawIn ri, int use_raw, const unsigned* __restrict__ ylo_epoch, unsigned launch_id) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1240,6 +1242,13 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
             else if (nb == 2) W4_GO(4, 2, 1);
             else W4_GO(4, 4, 1);
         }
+    } else if (sizeof(typename P::T) == 2 && P::NP == 2 && bd.raw == 2 && ylo_epoch != nullptr && *ylo_epoch != launch_id) {
+        // label-fed blocks of a launch whose label tiles all fit one bf16 plane (binary labels): hi plane only
+#define W4_GO1(NA_, NB_) wgrad4_body<P, NA_, NB_, 0, false>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave, ri)
+        if (nb == 1) W4_GO1(4, 1);
+        else if (nb == 2) W4_GO1(4, 2);
+        else W4_GO1(4, 4);
+#undef W4_GO1
     } else if (na == 1) {
         if (nb == 1) W4_GO(1, 1, 0);
         else if (nb == 2) W4_GO(1, 2, 0);
@@ -1418,7 +1427,7 @@ struct Layout {
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
-    int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_wcopy, o_stash, o_grads, total;
+    int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_flags, o_wcopy, o_stash, o_grads, total;
     int ntiles, nblocks, nblocks4;
 };
 
@@ -1476,6 +1485,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
+    L.o_flags = bytes(256 + 4 * (p.Bp / TB + 1));             // [0]: label-lo-plane epoch (RowsArgs::ylo_epoch); from byte 256: ylo_dirty[tile]
     L.o_wcopy = bytes(L.wcopy_elems * esz * np);              // PolX3: hi plane, then lo plane
     L.o_stash = bytes(L.stash_rows * p.Bp * esz * np);
     L.o_grads = bytes((int64_t)p.ksplit * p.n_params * sizeof(float));
@@ -1893,6 +1903,17 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
                             a.rows == nullptr && wgrad_form(getenv("DVAE_WGRAD")) == 4 && g_mode.mode != 1;
     a.stash_inputs = raw_inputs ? 0 : 1;
     a.mode = g_mode.mode;
+    {   // label lo plane on demand: 8-wave kernel + the workgroup k-split weight-gradient kernel, split-bf16 operands, labels from the stash
+        static std::atomic<unsigned> launch_counter{1};
+        const char* wk0 = getenv("DVAE_WGRAD");
+        const bool wg4 = wgrad_form(wk0) == 4 && (plan->Bp > 128 || raw_inputs || wk0 != nullptr);
+        a.ylo_epoch = (unsigned*)(w + L.o_flags);
+        a.ylo_dirty = (int*)(w + L.o_flags + 256);
+        a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);
+        if (a.launch_id == 0) a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of a fresh workspace
+        a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && wg4 && !raw_inputs &&
+                      getenv("DVAE_YLO_ALWAYS") == nullptr) ? 1 : 0;
+    }
     a.out_r = g_mode.out_r; a.out_mu = g_mode.out_mu; a.out_lv = g_mode.out_lv; a.out_z = g_mode.out_z; a.ld_r = g_mode.ld_r;
     a.g_r = g_mode.g_r; a.g_mu = g_mode.g_mu; a.g_lv = g_mode.g_lv; a.g_z = g_mode.g_z; a.ld_gr = g_mode.ld_gr;
     DVAE_CHECK_ARG(a.mode == 0 || plan->rows_kernel == 2, "rows-kernel modes 1 / 2 exist in the 8-wave kernel only (plan->rows_kernel == 2)");
@@ -1960,9 +1981,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             attr_done[dev][pi] = true;
         }
         const Block4* bl = (const Block4*)(w + L.o_blocks4);
-        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw);
-        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw);
-        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw);
+        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id);
+        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u);
+        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u);
         DVAE_LAUNCH_OK("wgrad4_kernel");
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);

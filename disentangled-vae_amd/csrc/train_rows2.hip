@@ -85,7 +85,13 @@ __device__ __forceinline__ void get_raw4(float (&v)[4], const typename P::T* lds
 }
 
 #define R2_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#ifdef R2_FINE      // diagnostic build: the helper's stamp slots 16 .. 29 carry chain-side sub-phase stamps of the output layer instead
+#define R2_HSTAMP(i) do { } while (0)
+#define R2_FSTAMP(i) do { if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#else
 #define R2_HSTAMP(i) do { if (g.dbg && ht == 0) g.dbg[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#define R2_FSTAMP(i) do { } while (0)
+#endif
 
 // MODE (RowsArgs::mode, compile time so the train-step instantiation carries none of the other modes' code or registers):
 // 0 fused train step, 1 forward outputs only, 2 backward from upstream gradients
@@ -106,7 +112,19 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #define R2_LATE_Y 1
 #endif
 #ifndef R2_EARLY_Y
-#define R2_EARLY_Y 0
+#define R2_EARLY_Y 1
+#endif
+#ifndef R2_DH
+#define R2_DH 6
+#endif
+#ifndef R2_HPRIO
+#define R2_HPRIO 0
+#endif
+#ifndef R2_YSPREAD
+#define R2_YSPREAD 8
+#endif
+#ifndef R2_YLOSEG
+#define R2_YLOSEG 0
 #endif
     constexpr bool OFFL = R2_OFFL && MODE == 0 && NP == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,6 +143,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     float* const keepz = reinterpret_cast<float*>(smem + Lds2<P>::o_keepz);
     constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
 
+    constexpr int DH = R2_DH;                                                    // ring depth of the helper waves' own weight stream
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -136,6 +155,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         const int cw = wave_u, fb = 32 * cw;
         constexpr int D = OFFL ? P::PDO : P::PD;
         typedef Sched<P, YP, YENC, D> SC;
+        typedef HSched<P, YP, YENC, DH> HS;
         typedef WStream<P, SC, D> WS;
         constexpr unsigned FBB = SC::FBB;
         WS ws;
@@ -206,7 +226,14 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 wg_barrier();                                           // BL1X: the x image of U has been consumed
                 wg_barrier();                                           // BY: the y image is in U (it stays there until the loss epilogue writes da)
                 ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
-                gemm_seg<P, SC, D, G_W1Y>(acc, ws, Ur, ylo);
+                // (two copies of the segment instead of a branch around the hi * lo MFMA of every k-step)
+                if (!R2_YLOSEG) gemm_seg<P, SC, D, G_W1Y>(acc, ws, Ur, ylo);
+                else if (ylo) gemm_seg<P, SC, D, G_W1Y>(acc, ws, Ur, true);
+                else gemm_seg<P, SC, D, G_W1Y>(acc, ws, Ur, false);
+            } else if constexpr (HS::n(H_W1X) > 0) wg_barrier();        // BL1X: the helpers' share of the x block is in `keep`
+            if constexpr (HS::n(H_W1X) > 0) {                           // the partner wave's partial tile (k-steps NX1 .. of the x block)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += keep[r * 256 + tid];
             }
             float hv[16], bv[16];
             R2_STAMP(3);
@@ -251,20 +278,25 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 }
             }
             // label block of decoder layer 1: independent of z (three of the four waves have nothing else to do in this phase)
+            // (513-label models: on the helper waves, during the L1 y GEMM -- SC::HELPY; they finish decoder layer 1 themselves)
             f32x16 accy;
-            if (YP > 0) {
+            if constexpr (YP > 0 && !SC::HELPY) {
                 zero_acc<P>(accy);
-                gemm_seg<P, SC, D, G_W3Y>(accy, ws, Ur, ylo);
+                if (!R2_YLOSEG) gemm_seg<P, SC, D, G_W3Y>(accy, ws, Ur, ylo);
+                else if (ylo) gemm_seg<P, SC, D, G_W3Y>(accy, ws, Ur, true);
+                else gemm_seg<P, SC, D, G_W3Y>(accy, ws, Ur, false);
             }
             wg_barrier();                                               // BZ
             R2_STAMP(6);
             // ---------------- decoder layer 1: [z | y] -> d1 ----------------
-            zero_acc<P>(acc);
-            gemm_seg<P, SC, D, G_W3Z>(acc, ws, Zbr);
-            bias16(Bias + OB3, fb, h, bv);
+            if constexpr (!SC::HELPY) {
+                zero_acc<P>(acc);
+                gemm_seg<P, SC, D, G_W3Z>(acc, ws, Zbr);
+                bias16(Bias + OB3, fb, h, bv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + (YP > 0 ? accy[r] : 0.f) + bv[r]);
-            put_lds<P>(hv, Ha, LDH, fb, l31, h);
+                for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(acc[r] + ((YP > 0) ? accy[r] : 0.f) + bv[r]);
+                put_lds<P>(hv, Ha, LDH, fb, l31, h);
+            }
             wg_barrier();                                               // BD1
             R2_STAMP(7);
             // ---------------- decoder layer 2 ----------------
@@ -304,13 +336,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     constexpr int I = decltype(ic)::value;
                     const int t = cw + 4 * I;
                     zero_acc<P>(acc);
+                    R2_FSTAMP(16 + 3 * I);
                     gemm_seg<P, SC, D, G_W5A + I>(acc, ws, Hbr);
+                    R2_FSTAMP(17 + 3 * I);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const f32x4 b5q = *reinterpret_cast<const f32x4*>(Bias + OB5 + 32 * t + 8 * gq + 4 * h);
                         const float a4[4] = {acc[4 * gq] + b5q[0], acc[4 * gq + 1] + b5q[1], acc[4 * gq + 2] + b5q[2], acc[4 * gq + 3] + b5q[3]};
                         put_raw4<P>(a4, U, LDU, 32 * t + 8 * gq + 4 * h, l31);
                     }
+                    R2_FSTAMP(18 + 3 * I);
                     wg_barrier();                                       // RB0 .. RB3: the round's four tiles go to the helpers
                 });
             } else
@@ -390,6 +425,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if constexpr (NP == 2) *reinterpret_cast<Frag*>(urow + Pl<P>::lds + c * E) = fl;
                 }
             }
+            R2_FSTAMP(28);
             wg_barrier();                                               // BDA
             R2_STAMP(9);
             if (mode == 1) {                                               // forward only: the helpers stage the next tile, then the stream restarts at position 0
@@ -474,7 +510,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             wg_barrier();                                               // BRED (the next tile's x image is in U)
             if (tid == 0) {
                 tot_rec += (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
-                if constexpr (OFFL) tot_rec += (double)red[8] + (double)red[9] + (double)red[10] + (double)red[11];   // the helpers' share
+                if constexpr (OFFL)                                        // the helpers' share: sum (x / r + a - 1), and ln 2 * sum log2(x + eps)
+                    tot_rec += (double)red[8] + (double)red[9] + (double)red[10] + (double)red[11]
+                             - 0.6931471805599453 * ((double)red[12] + (double)red[13] + (double)red[14] + (double)red[15]);
                 tot_kl += -0.5 * (double)red[4];
             }
         }
@@ -521,6 +559,27 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 rowsrc[half * TB + ht] = r;
             }
         };
+        // the helper waves' own weight stream (wstream.hpp: HSched): the rest of the x block of encoder layer 1 and, for 513-label
+        // models, decoder layer 1.  Row tile of helper wave hw = row tile of its partner chain wave.
+        typedef Sched<P, YP, YENC, (OFFL ? P::PDO : P::PD)> SCc;
+        typedef HSched<P, YP, YENC, DH> HS;
+        typedef WStream<P, HS, DH> HWS;
+        HWS hws;
+        if constexpr (HS::any) {
+            hws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
+            hws.voff = lane * 16;
+            hws.pl = g.wpl_bytes;
+            auto mo = [&](const void* Wp) { return (unsigned)((const char*)Wp - (const char*)g.wcopy); };
+            constexpr unsigned FBB = HS::FBB;
+            const unsigned tw = (unsigned)hw * FBB;
+            hws.sb[H_W1X] = mo(g.W1s) + tw + (unsigned)SCc::NX1 * 4u * FBB;
+            hws.sb[H_W3Y] = mo(g.W3s) + tw + (unsigned)(ZD / KS) * 4u * FBB;
+            hws.sb[H_W3Z] = mo(g.W3s) + tw;
+            hws.sb[H_PAD] = mo(g.W1s);
+        }
+        const T* const Urh = U + l31 * LDU + h * E;
+        const T* const Zbrh = Zb + l31 * LDZ + h * E;
+        float lsum2 = 0.f;            // sum of log2(x + eps) over this thread's share of the x tiles it committed (loss epilogue, OFFL)
         f32x4 xv[NQ513], yv[NQ513];
         bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
         bool y_in_regs = false;       // persistent loop: the NEXT tile's label tile is requested during this tile's backward phases too
@@ -544,33 +603,72 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 if (gather) { fill_rows(tile, 0); wg_barrier(); }       // BROW
                 if (g.fastx && full) {
                     tile513_issue(g.x, rowof, xv, tl);
-#if R2_EARLY_Y
-                    if (YP > 0 && Y513 && g.fasty) { tile513_issue(g.y, rowof, yv, tl); y_early = true; }
-#endif
 #pragma unroll
                     for (int q = 0; q < NB; ++q) {
                         const int i = ht + 256 * q;
                         if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
                     }
-                    tile513_commit<P, XP>(xv, U, LDU, tl);
+#if R2_EARLY_Y
+                    if (YP > 0 && Y513 && g.fasty) {
+                        // The label tile is requested BEHIND the x tile, a quarter at a time, each quarter followed by the commit of
+                        // the x quarter that has arrived by then.  (A CU pulls ~30 GB/s from HBM while every CU does the same: the
+                        // 17 label requests of a thread take ~2.5 us to ISSUE.  Issued in one go in front of the x commit they delay
+                        // it by that much; issued after the BX barrier -- the previous form -- they arrive 3 us after the L1 x GEMM
+                        // has finished.  Interleaved, x is committed as it lands and the labels land during the L1 x GEMM.)
+                        unsigned long long lb = 0ull;
+                        static_for<0, 4>([&](auto qc) {
+                            constexpr int Q = decltype(qc)::value;
+                            tile513_issue_part<4 * Q, 4 * Q + 4>(g.y, rowof, yv, tl);
+                            __builtin_amdgcn_sched_barrier(0);
+                            tile513_commit_part<P, 4 * Q, 4 * Q + 4>(xv, U, LDU, tl, nullptr, lb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                        tile513_issue_last(g.y, rowof, yv, tl);
+                        __builtin_amdgcn_sched_barrier(0);
+                        tile513_commit_last<P, XP>(xv, U, LDU, tl, nullptr, lb);
+                        y_early = true;
+                    } else
+#endif
+                    {
+                        tile513_commit<P, XP>(xv, U, LDU, tl);
+#pragma unroll
+                        for (int i = 0; i < NQ513; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // a full definition on every path (see xv below)
+                    }
                 } else {
 #pragma unroll
+                    for (int i = 0; i < NQ513; ++i) { xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; yv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
                     for (int q = 0; q < NB; ++q) {
                         const int i = ht + 256 * q;
                         if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
                     }
-                    load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof);
+                    load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
                 }
                 if (ht == 0) flags[0] = 0;
                 wg_barrier();                                           // BX
+                if constexpr (OFFL) { if (g.fastx && full) lsum2 += tile513_log2sum(xv, g.elbo_eps, tl); }   // the tile is still in registers
             }
-            // ---- chain: L1 x GEMM.  y loads in flight, x -> stash
+            // ---- chain: L1 x GEMM (its NX1 k-steps); here: the other k-steps of the same row tile, partial tile -> keep
+            if constexpr (HS::n(H_W1X) > 0) {
+                f32x16 hacc;
+                zero_acc<P>(hacc);
+                hws.fill();
+                gemm_seg<P, HS, DH, H_W1X>(hacc, hws, Urh + SCc::NX1 * 2 * E);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep[r * 256 + ht] = hacc[r];
+            }
+            f32x16 accy;                                                   // label block of decoder layer 1 (HS::HELPY)
+            int yplanes = NP;                                              // planes of the label stash this tile writes (RowsArgs::ylo_skip)
+            int ydirty = 0;                                                // the tile slot's lo plane holds an earlier launch's non-zero values
+            if constexpr (NP == 2 && YP > 0) { if (g.ylo_skip && st2) ydirty = g.ylo_dirty[tile]; }
+            // ---- y loads in flight, x -> stash
             if (YP > 0) {
                 if (Y513 && yfast && !y_early) tile513_issue(g.y, rowof, yv, tl);
                 R2_HSTAMP(16);
                 if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
                 R2_HSTAMP(17);
                 wg_barrier();                                           // BL1X
+                if constexpr (HS::HELPY && HS::n(H_W1X) == 0) hws.fill();  // decoder layer 1's first fragments arrive under the label commit
                 R2_HSTAMP(18);
                 bool any = false;                                          // does the label tile need its lo plane?  (found while committing)
                 if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl, nullptr, NP == 2 ? &any : nullptr);
@@ -586,22 +684,58 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 }
                 R2_HSTAMP(20);
                 wg_barrier();                                           // BY
+                if constexpr (NP == 2) {
+                    const bool ylo_t = __builtin_amdgcn_readfirstlane(flags[0]) != 0;
+                    if (g.ylo_skip && st2) {
+                        ydirty = __builtin_amdgcn_readfirstlane(ydirty);
+                        yplanes = (ylo_t || ydirty != 0) ? 2 : 1;
+                        if (ht == 0) {
+                            if (ylo_t) *g.ylo_epoch = g.launch_id;                           // every flagged tile stores the same value
+                            if ((ylo_t ? 1 : 0) != ydirty) g.ylo_dirty[tile] = ylo_t ? 1 : 0;
+                        }
+                    }
+                }
 #if !R2_LATE_Y
-                if (st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+                if (st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, 0, 1 << 30, yplanes);
 #endif
+                if constexpr (HS::HELPY) {
+                    // chain: L1 y GEMM (33 k-steps).  Here: the label block of decoder layer 1 (33 k-steps, independent of z), this
+                    // wave's row tile; it stays in registers until the z block joins it after BZ
+                    const bool ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
+                    zero_acc<P>(accy);
+                    if (!R2_YLOSEG) gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, ylo);
+                    else if (ylo) gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, true);
+                    else gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, false);
+                }
             } else {
                 if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if constexpr (HS::n(H_W1X) > 0) wg_barrier();            // BL1X (models without labels): the partial tile is in `keep`
             }
             wg_barrier();                                               // BH1
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+#if R2_LATE_Y
+            // the label tile stays in U until the output layer: its stash waits for these two phases, away from the window in which every
+            // CU reads x and y and writes the x stash (the first 10 us of the kernel move 68 MB: HBM-bound); split over the L2 and the
+            // heads phase (feature tiles below / from R2_YSPREAD) so that neither phase waits for it
+            if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, 0, R2_YSPREAD, yplanes);
+#endif
             wg_barrier();                                               // BH2
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
 #if R2_LATE_Y
-            // the label tile stays in U until the output layer: its stash waits for this phase, away from the window in which every CU
-            // reads x and y and writes the x stash (the first 10 us of the kernel move 68 MB: HBM-bound)
-            if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl);
+            if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, R2_YSPREAD, 1 << 30, yplanes);
 #endif
             wg_barrier();                                               // BZ
+            if constexpr (HS::HELPY) {
+                // decoder layer 1 on the helper waves: the z block (one k-step) joins the label block; d1 -> Ha
+                f32x16 az;
+                zero_acc<P>(az);
+                gemm_seg<P, HS, DH, H_W3Z>(az, hws, Zbrh);
+                float hv[16], bv[16];
+                bias16(Bias + OB3, 32 * hw, h, bv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(az[r] + accy[r] + bv[r]);
+                put_lds<P>(hv, Ha, LDH, 32 * hw, l31, h);
+            }
             if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
             if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
             wg_barrier();                                               // BD1
@@ -633,16 +767,22 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     R2_HSTAMP(21 + 2 * I);
                     wg_barrier();                                       // RB0 .. RB3
                     R2_HSTAMP(22 + 2 * I);
+#if R2_HPRIO
+                    __builtin_amdgcn_s_setprio(R2_HPRIO);
+#endif
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         float a4[4], da4[4];
                         get_raw4<P>(a4, U, LDU, 32 * t + 8 * gq + 4 * ho, l31o);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float xs = xo[gq][j];
-                            const float xe = xs * P::exp_(-a4[j]);               // x / r,  r = exp(a)  (models.py:122)
-                            rec_h += xe - P::log_(xs + g.elbo_eps) + a4[j] - 1.f;   // utils.py:74 (log r = a)
-                            da4[j] = (1.f - xe) * invB_l;                        // d recon / d a
+                            // recon term x / r - log(x + eps) + log r - 1 with r = exp(a) (models.py:122, utils.py:74): x e^{-a} + a is
+                            // summed here; the log(x + eps) terms were summed while the x tile sat in registers (lsum2) and the -1's are a
+                            // count -- 6 VALU instructions per element instead of 13 (this loop is what the output layer waits for)
+                            const float xe = xo[gq][j] * __builtin_amdgcn_exp2f(a4[j] * -1.44269504088896341f);
+                            rec_h += xe;
+                            rec_h += a4[j];
+                            da4[j] = fmaf(-xe, invB_l, invB_l);                  // d recon / d a = (1 - x / r) / B
                         }
                         typename P::Pack4 ph, pl;
 #pragma unroll
@@ -650,10 +790,13 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                         *reinterpret_cast<typename P::Pack4*>(U + l31o * LDU + 32 * t + 8 * gq + 4 * ho) = ph;
                         *reinterpret_cast<typename P::Pack4*>(U + Pl<P>::lds + l31o * LDU + 32 * t + 8 * gq + 4 * ho) = pl;
                     }
+#if R2_HPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) xo[gq] = xnx[gq];
                 }
-                if (!live) rec_h = 0.f;
+                rec_h = live ? rec_h - 64.f : 0.f;                          // the -1 of each of this lane's 64 elements; frames past B contribute nothing
             }
             wg_barrier();                                               // BDA
             for (int t = hw; t < NT_OUT; t += 4) if (st1) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
@@ -710,11 +853,17 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BDH1
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            if (more) {
-                if (x_in_regs) tile513_commit<P, XP>(xv, U, LDU, tl);
-                else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof);
+            if constexpr (OFFL) {                                          // log terms of the tile(s) whose x this thread has committed so far
+                const float rs = wave_sum(rec_h), ls = wave_sum(lsum2);
+                if (lane == 0) { red[8 + hw] = rs; red[12 + hw] = ls; }
+                lsum2 = 0.f;
             }
-            if constexpr (OFFL) { const float rs = wave_sum(rec_h); if (lane == 0) red[8 + hw] = rs; }
+            if (more) {
+                if (x_in_regs) {
+                    tile513_commit<P, XP>(xv, U, LDU, tl);
+                    if constexpr (OFFL) lsum2 = tile513_log2sum(xv, g.elbo_eps, tl);      // counted with the next tile's sums
+                } else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
+            }
             wg_barrier();                                               // BRED
         }
     }

@@ -15,6 +15,24 @@
 #ifndef R2_WAUX
 #define R2_WAUX 0
 #endif
+// Work the helper waves take off the chain (both waves of a SIMD then keep a weight ring in flight: the k-step of a GEMM phase is
+// latency-bound by loads in flight per SIMD, t = t0 + L / D):
+//   R2_NX1   : k-steps of the encoder's x block (33) the CHAIN computes; the partner helper wave computes the rest of the same row tile
+//              during the L1 x phase and hands its partial 32 x 32 tile over through LDS (the fp32 h1 slot, free until the epilogue).
+//              Default 33 = off: on a workgroup's FIRST tile the helper's label-tile requests are in flight in that phase and vmcnt
+//              retires in order, so a helper wave cannot wait for a weight fragment without waiting for the whole label tile.
+//   R2_HELPY : 513-label models: the label block of decoder layer 1 (33 k-steps, independent of z) runs on the helper waves during
+//              the chain's L1 y GEMM, and the helpers finish decoder layer 1 themselves (the z block is one k-step): no hand-over.
+//              Default 0 = off, measured (round 3, same box, alternating): the heads phase loses the 33 k-steps (4.3 -> 1.4 us) and the
+//              L1 y phase gains 2.5 us -- two GEMM streams on one SIMD finish 66 k-steps in 5.9 us, 89 ns per k-step against 100 ns
+//              for one stream: the k-step is not bound by loads in flight per SIMD but by what the CU's vector-memory path delivers
+//              beside the MFMAs (8 KB per k-step and CU) -- step 75.4 us with, 74.8 us without.
+#ifndef R2_NX1
+#define R2_NX1 33
+#endif
+#ifndef R2_HELPY
+#define R2_HELPY 0
+#endif
 
 namespace dvae {
 namespace fused {
@@ -24,19 +42,45 @@ enum { G_W1X, G_W1Y, G_W2, G_WMV, G_W3Y, G_W3Z, G_W4, G_W5A, G_W5B, G_W5C, G_W5D
 
 template <typename P, int YP, bool YENC, int D> struct Sched {
     static constexpr int KS = P::KSTEP;
+    static constexpr int NSEG = G_N;
     static constexpr unsigned FBB = 64u * P::E * sizeof(typename P::T);          // bytes of one (row tile, k-step) fragment block
+    static constexpr int NX1 = (R2_NX1 > 0 && R2_NX1 < XP / KS) ? R2_NX1 : XP / KS;   // the chain's share of the x block of layer 1
+    static constexpr bool HELPY = R2_HELPY && YP == XP;                            // decoder layer 1 lives on the helper waves
     static constexpr int raw(int s) {
-        return s == G_W1X ? XP / KS : s == G_W1Y ? (YENC ? YP / KS : 0) : s == G_W3Y ? YP / KS : s == G_W3Z ? ZD / KS
+        return s == G_W1X ? NX1 : s == G_W1Y ? (YENC ? YP / KS : 0) : s == G_W3Y ? (HELPY ? 0 : YP / KS) : s == G_W3Z ? (HELPY ? 0 : ZD / KS)
              : s == G_W5T ? NO / KS : s == G_WMVT ? 32 / KS : s == G_PAD ? 0 : HD / KS;
     }
     static constexpr int sum_raw() { int t = 0; for (int s = 0; s < G_PAD; ++s) t += raw(s); return t; }
     static constexpr int pad = (D - sum_raw() % D) % D;
     static constexpr int total = sum_raw() + pad;
+    static constexpr bool WRAP = true;
     static constexpr int n(int s) { return s == G_PAD ? pad : raw(s); }
     static constexpr int start(int s) { int t = 0; for (int i = 0; i < s; ++i) t += n(i); return t; }
     static constexpr int seg_of(int q) { int s = 0; while (q >= start(s) + n(s)) ++s; return s; }
     // k-step stride: 4-tile matrices are [k-step][4 tiles], the single-tile heads [k-step][1], the output layer [k-step][17]
     static constexpr unsigned stride(int s) { return (s == G_WMV || s == G_W3ZT) ? FBB : (s >= G_W5A && s <= G_W5D) ? NT_OUT * FBB : 4u * FBB; }
+};
+
+// the helper waves' stream: the rest of the x block of layer 1, then (513-label models) decoder layer 1
+enum { H_W1X, H_W3Y, H_W3Z, H_PAD, H_N };
+template <typename P, int YP, bool YENC, int D> struct HSched {
+    typedef Sched<P, YP, YENC, D> C;
+    static constexpr int KS = P::KSTEP;
+    static constexpr int NSEG = H_N;
+    static constexpr unsigned FBB = C::FBB;
+    static constexpr bool HELPY = C::HELPY;
+    static constexpr int raw(int s) { return s == H_W1X ? XP / KS - C::NX1 : s == H_W3Y ? (C::HELPY ? YP / KS : 0) : s == H_W3Z ? (C::HELPY ? ZD / KS : 0) : 0; }
+    static constexpr int sum_raw() { int t = 0; for (int s = 0; s < H_PAD; ++s) t += raw(s); return t; }
+    // the helpers' stream does not wrap: it is started (fill) when the tile's label image is about to be committed and requests nothing
+    // past its last position, so no fragment registers stay live through the rest of the tile
+    static constexpr int pad = 0;
+    static constexpr int total = sum_raw();
+    static constexpr bool any = sum_raw() > 0;
+    static constexpr bool WRAP = false;
+    static constexpr int n(int s) { return s == H_PAD ? pad : raw(s); }
+    static constexpr int start(int s) { int t = 0; for (int i = 0; i < s; ++i) t += n(i); return t; }
+    static constexpr int seg_of(int q) { int s = 0; while (q >= start(s) + n(s)) ++s; return s; }
+    static constexpr unsigned stride(int s) { return 4u * FBB; }
 };
 
 template <int I, int N, typename F>
@@ -49,20 +93,27 @@ template <typename P, typename SC, int D> struct WStream {
     __amdgpu_buffer_rsrc_t rs;
     int voff;                  // lane * 16
     unsigned pl;               // bytes between the hi and lo planes
-    unsigned sb[G_N];          // byte offset of k-step 0 of every segment for THIS wave
+    unsigned sb[SC::NSEG];     // byte offset of k-step 0 of every segment for THIS wave
+    unsigned cur;              // byte offset of the position requested last: positions are requested strictly in sequence
+    // The soffset of every request is ONE running SGPR: + stride inside a segment, = sb[segment] at its first k-step, opaque to the
+    // optimiser after each update.  (Written as sb[s] + constant, hipcc computes all ~430 offsets of the sequence once per kernel --
+    // they are invariant over the tile loop -- keeps them in VGPR lanes (529 "SGPR spills") and pays a v_readlane + s_nop 4 in front of
+    // EVERY weight load, on the chain's critical path.)
     template <int Q> __device__ __forceinline__ void req() {
         constexpr int s = SC::seg_of(Q);
-        constexpr unsigned off = (unsigned)(Q - SC::start(s)) * SC::stride(s);
+        if constexpr (Q == SC::start(s)) cur = sb[s];
+        else cur += SC::stride(s);
+        asm volatile("" : "+s"(cur));
         // R2_WAUX: cache-policy bits of the weight stream's loads (gfx950 buffer aux: 1 = sc0, 2 = nt, 16 = sc1)
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sb[s] + off, R2_WAUX);
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur, R2_WAUX);
         r[Q % D][0] = __builtin_bit_cast(typename P::Frag, v0);
         if constexpr (P::NP == 2) {
-            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, sb[s] + off + pl, R2_WAUX);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur + pl, R2_WAUX);
             r[Q % D][1] = __builtin_bit_cast(typename P::Frag, v1);
         }
     }
     __device__ __forceinline__ void fill() {
-        static_for<0, D>([&](auto ic) { this->template req<decltype(ic)::value>(); });
+        static_for<0, (D < SC::total ? D : SC::total)>([&](auto ic) { this->template req<decltype(ic)::value>(); });
         __builtin_amdgcn_sched_barrier(0);
     }
 };
@@ -93,7 +144,8 @@ __device__ __forceinline__ void gemm_seg(f32x16& acc, WS& w, const typename P::T
 #endif
             }
 #ifndef R2_NOWLOAD
-            w.template req<(Q0 + I + D) % SC::total>();
+            if constexpr (SC::WRAP) w.template req<(Q0 + I + D) % SC::total>();
+            else if constexpr (Q0 + I + D < SC::total) w.template req<Q0 + I + D>();
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });

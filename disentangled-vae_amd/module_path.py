@@ -186,7 +186,7 @@ def engine_for(module, model, x, y):
         return None
     if x.requires_grad or (y is not None and y.requires_grad):
         return None                                  # gradients with respect to the data are a layer-path feature
-    if not torch.is_grad_enabled():
+    if not torch.is_grad_enabled() or not any(p.requires_grad for p in module.parameters()):
         return None                                  # inference: the exact-fp32 per-layer kernels (module docstring)
     eng = module.__dict__.get("_dvae_engine")
     if eng is None:
@@ -204,7 +204,7 @@ def engine_for(module, model, x, y):
             return None
         eng = ModuleEngine(module, model, module.y_dim if model == "M2" else 0)
         object.__setattr__(module, "_dvae_engine", eng)
-    if not eng.usable(x) or not any(p.requires_grad for p in eng.params):
+    if not eng.usable(x):
         return None
     if model == "M2" and (y is None or y.dim() != 2 or y.shape != (x.shape[0], eng.y_dim) or y.dtype != torch.float32 or y.device != x.device):
         return None

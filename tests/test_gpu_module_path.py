@@ -42,7 +42,7 @@ def _step(m, model, x, y, e, opt, path, monkeypatch, do_step=True):
     return out, (loss.item(), recon.item(), kl.item()), grads
 
 
-@pytest.mark.parametrize("model,y_dim,B", [("M1", 0, 128), ("M2", 1, 300), ("M2", 513, 128), ("M2", 513, 8192)])
+@pytest.mark.parametrize("model,y_dim,B", [("M1", 0, 128), ("M2", 1, 300), ("M2", 513, 128), ("M2", 513, 8192), ("M2", 513, 20000), ("M1", 0, 9000)])
 def test_training_loop_matches_the_layer_path(model, y_dim, B, monkeypatch):
     dims, mf, ml = _models(model, y_dim, 3)
     of = torch.optim.Adam(mf.parameters(), lr=1e-4, betas=(0.9, 0.999))

@@ -40,6 +40,13 @@ if os.environ.get("DVAE_HSTAMPS"):
           "\n  out layer, helper (us since BD2): " + "  ".join(f"{'arrive' if i % 2 == 0 else 'pass'} RB{i // 2}={np.median(r[:, 21 + i] - r[:, 8]):.2f}" for i in range(8)) +
           f" BDA={np.median(r[:, 9] - r[:, 8]):.2f}" +
           f"  | chain: BX={np.median(r[:,1]-t0[:,0]):.2f} L1x done={np.median(r[:,2]-t0[:,0]):.2f} L1y done={np.median(r[:,3]-t0[:,0]):.2f}")
+if os.environ.get("DVAE_FSTAMPS"):       # -DR2_FINE build: chain-side sub-phase stamps of the output layer (slots 16 + 3 I: round start, GEMM done, a -> U done)
+    r = buf.cpu().numpy().reshape(-1, 32).astype(np.float64) * 0.01
+    med = lambda a: float(np.median(a))
+    parts = []
+    for I in range(4):
+        parts.append(f"round {I}: start@{med(r[:, 16 + 3 * I] - r[:, 8]):.2f} gemm={med(r[:, 17 + 3 * I] - r[:, 16 + 3 * I]):.2f} put={med(r[:, 18 + 3 * I] - r[:, 17 + 3 * I]):.2f}")
+    print("  out layer, chain (us; start since BD2): " + "  ".join(parts) + f"  tail(17th tile)={med(r[:, 28] - r[:, 27]):.2f} BDA wait={med(r[:, 9] - r[:, 28]):.2f}")
 raw = buf.cpu().numpy().reshape(-1, 32).astype(np.float64)
 cyc = raw[:, 31] - raw[:, 30]; us = (raw[:, 15] - raw[:, 0]) * 0.01
 print("  shader clock during the kernel: %.0f MHz (median over workgroups)" % np.median(cyc / us))
