@@ -169,6 +169,65 @@ def cpu_baseline(model, dims, B, seconds):
             "single_thread": {"value": v1, "unit": "frames/s", "cores": 1, "sample": f"{n1} steps of {B} frames {what}, {dt1:.1f} s"}}
 
 
+def side_kernels(device):
+    """The hot path's other kernels on this GPU, so that a driver run carries them: STFT / ISTFT of ten minutes of
+    float64 audio (HBM-bound: algorithmic bytes per frame = 256 new samples in + 513 complex64 out) and one batched MCEM
+    run (25 utterances of 300 frames side by side, fp32 parity policy: MFMA-bound decoder chains)."""
+    import numpy as np
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    M = importlib.import_module("disentangled-vae_amd.mcem")
+    synth = importlib.import_module("disentangled-vae_amd.synth")
+
+    def t_us(fn, n=20):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / n
+    out = {}
+    n = 16000 * 600
+    x = torch.randn(n, dtype=torch.float64, device=device)
+    T = H.frame_count(n, 1024, 256)
+    w = H.window_f64("hann", 1024, device)
+    S = H.stft_device(x, w, 1024, 256, T, 0)
+    for name, fn, byts in (("stft_complex", lambda: H.stft_device(x, w, 1024, 256, T, 0), T * (256 * 8 + 513 * 8)),
+                           ("stft_power_frames", lambda: H.stft_device(x, w, 1024, 256, T, 1), T * (256 * 8 + 513 * 4)),
+                           ("istft", lambda: H.istft_device(S, w, 1024, 256, T, 0, n), T * (513 * 8 + 256 * 4))):
+        us = t_us(fn)
+        out[name] = {"us": us, "frames": T, "Mframes_per_s": T / us, "algorithmic_GB_per_s": byts / us * 1e-3, "hbm_frac": byts / us * 1e-3 / 8000.0}
+    out["stft_note"] = "600 s of float64 audio at 16 kHz, nfft 1024, hop 256; bytes = new samples in + spectrogram out (float32 samples out for istft)"
+    # MCEM: scripts/evaluate_ntcd_M2.py settings (10 + 30 samples per E-step, rank 10), 25 utterances x 300 frames, 20 EM iterations
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    torch.manual_seed(0)
+    vae = synth.build_model("M2", dims).to(device).eval()
+    for p in vae.parameters():
+        p.requires_grad = False
+    rng = np.random.default_rng(5)
+    F, N, U, niter = 513, 300, 25, 20
+    env = np.exp(rng.standard_normal((F, 1)) * 0.7 - 1.0) * np.exp(rng.standard_normal((1, N)) * 0.5)
+    Sx = np.sqrt(env / 2) * (rng.standard_normal((F, N)) + 1j * rng.standard_normal((F, N)))
+    X = (Sx + 0.3 * (rng.standard_normal((F, N)) + 1j * rng.standard_normal((F, N)))).astype(np.complex64)
+    y = torch.from_numpy((rng.random((1, N)) > 0.4).astype(np.float32)).to(device)
+    mb = M.McemBatch(vae, niter=2, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, label_in_encoder=True,
+                     label_in_decoder=True, precision="fp32")
+    mb.init_parameters([X] * U, [y] * U); mb.run()
+    mb.niter = niter
+    mb.init_parameters([X] * U, [y] * U)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mb.run()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    # decoder frame passes the kernels execute: per EM iteration 40 chain steps + 10 kept-sample decodes (the reference's second decoder
+    # pass per step is replaced by the kept likelihood), plus the final Wiener chain of 100 steps + 25 decodes; frames padded to 32
+    Np = -(-N // 32) * 32
+    passes = U * Np * (niter * (40 + 10) + (100 + 25))
+    flops = passes * 2.0 * (17 * 128 + 128 * 128 + 128 * 513)
+    out["mcem_batched_fp32"] = {"utterances": U, "frames_each": N, "em_iterations": niter, "seconds": dt, "ms_per_em_iteration": 1e3 * dt / niter,
+                                "decoder_TFLOP_per_s": flops / dt * 1e-12, "fp32_mfma_frac": flops / dt * 1e-12 / 157.3,
+                                "note": "whole run incl. M-steps and the Wiener chain; flops = decoder MACs x 2 of the chain / decode passes the kernels execute"}
+    return out
+
+
 def timed_steps(impl, batches, first, steps, dist, device):
     """K steps bracketed by barrier + synchronize on both sides; max over ranks.  Returns (seconds, last loss tensor)."""
     nb = len(batches)
@@ -311,6 +370,11 @@ def main():
             g128 = other(a.precision, 128, 200)
             out["b128"] = {"frames_per_step": 128, "gpu_ms_per_step": g128, "gpu_frames_per_s": 128 / (g128 * 1e-3),
                            "note": "the batch size of scripts/training_M2.py:60"}
+        if world == 1 and extras and impl_name == "fused" and a.model == "M2" and B == 8192:
+            try:
+                out["side_kernels"] = side_kernels(device)
+            except Exception as exc:                                                # never lose the headline line to a side measurement
+                out["side_kernels"] = {"error": repr(exc)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model, dims, B, a.cpu_seconds)
             if "b128" in out:

@@ -45,7 +45,7 @@
 namespace dvae {
 namespace fused {
 
-template <typename P> struct Lds2 {
+template <typename P, bool INFO = false> struct Lds2 {
     typedef typename P::T T;
     static constexpr int nbias = Ld<T>::nbias;
     static constexpr size_t o_bias = (size_t)Ld<T>::act_elems * P::NP * sizeof(T);
@@ -54,8 +54,14 @@ template <typename P> struct Lds2 {
     static constexpr size_t o_rows = o_flags + 16 * sizeof(int);
     static constexpr size_t o_keep = o_rows + 2 * TB * sizeof(int64_t);                  // fp32 h1 | h2 of the chain waves: [2][16][256]
     static constexpr size_t o_keepz = o_keep + 2 * 16 * 256 * sizeof(float);             // fp32 mu | log_var of wave 0: [16][64]
-    static constexpr size_t bytes = o_keepz + 16 * 64 * sizeof(float);
-    static_assert(o_bias % 16 == 0 && o_rows % 8 == 0, "LDS carve alignment");
+    // M2_info: the classifier / auxiliary-net tables (bc1 bc2 wc3 ba1 ba2 wa3, then bc3, ba3), the partial output dot products of the
+    // four waves of a side net ([4][32]), and d BCE_aux / d z of wave 0's latent tile ([8][64], kept until the backward z phase)
+    static constexpr size_t o_info = o_keepz + 16 * 64 * sizeof(float);
+    static constexpr size_t o_red2 = o_info + (INFO ? (size_t)Ld<T>::ninfo * sizeof(float) : 0);
+    static constexpr size_t o_dzu = o_red2 + (INFO ? 144 * sizeof(float) : 0);      // [128], [129]: the tile's BCE sums (classifier, auxiliary)
+    static constexpr size_t bytes = o_dzu + (INFO ? 8 * 64 * sizeof(float) : 0);
+    static_assert(o_bias % 16 == 0 && o_rows % 8 == 0 && o_info % 16 == 0, "LDS carve alignment");
+    static_assert(bytes <= 160 * 1024, "LDS budget");
 };
 
 // Workgroup barrier that orders LDS only: waits for this wave's LDS operations, not for its global stores (the helpers'
@@ -95,8 +101,9 @@ __device__ __forceinline__ void get_raw4(float (&v)[4], const typename P::T* lds
 
 // MODE (RowsArgs::mode, compile time so the train-step instantiation carries none of the other modes' code or registers):
 // 0 fused train step, 1 forward outputs only, 2 backward from upstream gradients
-template <typename P, int YP, bool YENC, int MODE>
+template <typename P, int YP, bool YENC, int MODE, bool INFO = false>
 __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
+    static_assert(!INFO || (MODE == 0 && YP == 16 && !YENC), "M2_info: train step, 1-dim label, encoder on x only");
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
@@ -132,15 +139,24 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     T* const Ha = U + TB * LDU;
     T* const Hb = Ha + TB * LDH;
     T* const Zb = Hb + TB * LDH;
-    float* const Bias = reinterpret_cast<float*>(smem + Lds2<P>::o_bias);
-    float* const red = reinterpret_cast<float*>(smem + Lds2<P>::o_red);
-    int* const flags = reinterpret_cast<int*>(smem + Lds2<P>::o_flags);          // [0]: the label tile has a non-zero lo plane
-    int64_t* const rowsrc = reinterpret_cast<int64_t*>(smem + Lds2<P>::o_rows);  // [2][TB] gather table, double buffered
+    typedef Lds2<P, INFO> LD2;
+    float* const Bias = reinterpret_cast<float*>(smem + LD2::o_bias);
+    float* const red = reinterpret_cast<float*>(smem + LD2::o_red);
+    int* const flags = reinterpret_cast<int*>(smem + LD2::o_flags);          // [0]: the label tile has a non-zero lo plane
+    int64_t* const rowsrc = reinterpret_cast<int64_t*>(smem + LD2::o_rows);  // [2][TB] gather table, double buffered
+    // M2_info (DeepGenerativeModel_v5, models.py:390-444; loop body scripts/training_M2_info_vad.py:159-198): the classifier on x runs on
+    // the HELPER waves beside the chain's encoder (its layer images live in columns 32 .. 415 of U, which are free between the x image
+    // and the output layer when the label is one column wide); the auxiliary net on z is four extra chain phases after the heads.
+    float* const Binfo = reinterpret_cast<float*>(smem + LD2::o_info);
+    float* const red2 = reinterpret_cast<float*>(smem + LD2::o_red2);
+    float* const dzs = reinterpret_cast<float*>(smem + LD2::o_dzu);
+    constexpr int OBC1 = 0, OBC2 = HD, OWC3 = 2 * HD, OBA1 = 3 * HD, OBA2 = 4 * HD, OWA3 = 5 * HD, OS3 = 6 * HD;
+    constexpr int IMA = 32, IMB = 160, IMC = 288;                            // classifier layer images: first column in U
     // Two waves per SIMD leave 256 registers per wave: the tanh outputs the backward pass needs again do not stay in
     // registers.  h1 / h2 (needed ten phases later) wait in private fp32 LDS slots; d1 / d2 are re-read from their own
     // operand planes (hi + lo), which the backward tiles then overwrite in place (same lane, same elements).
-    float* const keep = reinterpret_cast<float*>(smem + Lds2<P>::o_keep);
-    float* const keepz = reinterpret_cast<float*>(smem + Lds2<P>::o_keepz);
+    float* const keep = reinterpret_cast<float*>(smem + LD2::o_keep);
+    float* const keepz = reinterpret_cast<float*>(smem + LD2::o_keepz);
     constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
 
     constexpr int DH = R2_DH;                                                    // ring depth of the helper waves' own weight stream
@@ -154,8 +170,8 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         // =========================================================== chain waves ===========================================================
         const int cw = wave_u, fb = 32 * cw;
         constexpr int D = OFFL ? P::PDO : P::PD;
-        typedef Sched<P, YP, YENC, D> SC;
-        typedef HSched<P, YP, YENC, DH> HS;
+        typedef Sched<P, YP, YENC, D, INFO> SC;
+        typedef HSched<P, YP, YENC, DH, INFO> HS;
         typedef WStream<P, SC, D> WS;
         constexpr unsigned FBB = SC::FBB;
         WS ws;
@@ -178,6 +194,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             ws.sb[G_W5C] = mo(g.W5s) + (unsigned)(cw + 8) * FBB;  ws.sb[G_W5D] = mo(g.W5s) + (unsigned)(cw + 12) * FBB;
             ws.sb[G_W5T] = mo(g.W5t) + tw;  ws.sb[G_W4T] = mo(g.W4t) + tw;  ws.sb[G_W3ZT] = mo(g.W3zt);
             ws.sb[G_WMVT] = mo(g.Wmvt) + tw;  ws.sb[G_W2T] = mo(g.W2t) + tw;  ws.sb[G_PAD] = mo(g.W1s);
+            if constexpr (INFO) {
+                ws.sb[G_A1] = mo(g.Wa1s) + tw;  ws.sb[G_A2] = mo(g.Wa2s) + tw;  ws.sb[G_A2T] = mo(g.Wa2t) + tw;  ws.sb[G_A1T] = mo(g.Wa1t);
+            } else { ws.sb[G_A1] = ws.sb[G_A2] = ws.sb[G_A2T] = ws.sb[G_A1T] = 0; }
         }
         ws.fill();                                                         // the first D k-steps of the stream, in flight under the x tile load
         const T* const Ur = U + l31 * LDU + h * E;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         const T* const Zbr = Zb + l31 * LDZ + h * E;
         const bool w0 = cw == 0;
         constexpr int mode = MODE;
-        double tot_rec = 0.0, tot_kl = 0.0;
+        double tot_rec = 0.0, tot_kl = 0.0, tot_bc = 0.0, tot_ba = 0.0;
 
         for (int it = 0; it < ntl; ++it) {
             const int tile = (int)blockIdx.x + it * (int)gridDim.x;
@@ -288,6 +307,61 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             }
             wg_barrier();                                               // BZ
             R2_STAMP(6);
+            float bce_a = 0.f;
+            if constexpr (INFO) {
+                // ---------------- auxiliary classifier on z (models.py:41-63, 419-420): forward, BCE against the frame label, backward down to
+                // d BCE / d z.  Unit scale on chip; the stashed pre-activation gradients carry (gamma - beta) (quirk Q4: the -beta * dBCE that
+                // enc_loss.backward() leaves in the auxiliary net's .grad is never zeroed before aux_loss.backward() adds gamma * dBCE).
+                float a1r[16], a2r[16], w3v[16];
+                zero_acc<P>(acc);
+                gemm_seg<P, SC, D, G_A1>(acc, ws, Zbr);
+                bias16(Binfo + OBA1, fb, h, bv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1r[r] = fmaxf(acc[r] + bv[r], 0.f);
+                put_lds<P>(a1r, Ha, LDH, fb, l31, h);
+                wg_barrier();                                           // BA1
+                zero_acc<P>(acc);
+                gemm_seg<P, SC, D, G_A2>(acc, ws, Har);
+                bias16(Binfo + OBA2, fb, h, bv);
+                bias16(Binfo + OWA3, fb, h, w3v);
+                float pd = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a2r[r] = fmaxf(acc[r] + bv[r], 0.f); pd = fmaf(w3v[r], a2r[r], pd); }
+                put_lds<P>(a2r, Hb, LDH, fb, l31, h);
+                pd += __shfl_xor(pd, 32, 64);
+                if (h == 0) red2[cw * 32 + l31] = pd;
+                wg_barrier();                                           // BA2
+                {
+                    int64_t rowy = gather ? rsrc[l31] : (b0 + l31 < g.B ? b0 + l31 : g.B - 1);
+                    const float y_l = g.y[rowy * g.ldy];
+                    const float logit = red2[l31] + red2[32 + l31] + red2[64 + l31] + red2[96 + l31] + Binfo[OS3 + 1];
+                    const float p = 1.f / (1.f + P::exp_(-logit));
+                    const float lp = P::log_(p + g.elbo_eps), lq = P::log_(1.f - p + g.elbo_eps);
+                    bce_a = (live && h == 0 && w0) ? -(y_l * lp + (1.f - y_l) * lq) : 0.f;                        // utils.py:55-56, this frame's term
+                    const float u = live ? -g.invB * (y_l / (p + g.elbo_eps) - (1.f - y_l) / (1.f - p + g.elbo_eps)) : 0.f;
+                    const float dpre3 = u * p * (1.f - p);
+                    float dv2[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dv2[r] = a2r[r] > 0.f ? w3v[r] * dpre3 : 0.f;                     // dpre2 (unit scale)
+                    put_lds<P>(dv2, Ha, LDH, fb, l31, h);
+                }
+                wg_barrier();                                           // BA3
+                zero_acc<P>(acc);
+                gemm_seg<P, SC, D, G_A2T>(acc, ws, Har);
+                {
+                    float dv1[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dv1[r] = a1r[r] > 0.f ? acc[r] : 0.f;                              // dpre1 (unit scale)
+                    put_lds<P>(dv1, Hb, LDH, fb, l31, h);
+                }
+                wg_barrier();                                           // BA4
+                zero_acc<P>(acc);
+                gemm_seg<P, SC, D, G_A1T>(acc, ws, Hbr, true, w0);     // d BCE_aux / d z: the latent tile belongs to wave 0
+                if (w0) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) dzs[r * 64 + lane] = acc[r];
+                }
+            }
             // ---------------- decoder layer 1: [z | y] -> d1 ----------------
             if constexpr (!SC::HELPY) {
                 zero_acc<P>(acc);
@@ -475,7 +549,8 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float mu = keepz[r * 64 + lane], lv = keepz[(8 + r) * 64 + lane];
-                    const float dz = acc[r] + gu[r];
+                    float dz = acc[r] + gu[r];
+                    if constexpr (INFO) dz -= g.beta * dzs[r * 64 + lane];                                          // enc_loss = ELBO + alpha clf - beta BCE(aux(z), y)
                     const float kmu = mode == 0 ? mu * g.invB : gu[8 + r];                                         // KL term of the fused step / upstream d mu
                     const float klv = mode == 0 ? -0.5f * g.invB * (1.f - P::exp_(lv)) : gu[16 + r];
                     dml[r] = live ? dz + kmu : 0.f;                                                                 // dmu
@@ -507,8 +582,10 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (!live) rec_lane = 0.f;
             const float rs = wave_sum(rec_lane), ks = wave_sum(kl_lane);
             if (lane == 0) { red[cw] = rs; red[4 + cw] = ks; }
+            if constexpr (INFO) { if (w0) { const float bas = wave_sum(bce_a); if (lane == 0) red2[129] = bas; } }
             wg_barrier();                                               // BRED (the next tile's x image is in U)
             if (tid == 0) {
+                if constexpr (INFO) { tot_bc += (double)red2[128]; tot_ba += (double)red2[129]; }
                 tot_rec += (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
                 if constexpr (OFFL)                                        // the helpers' share: sum (x / r + a - 1), and ln 2 * sum log2(x + eps)
                     tot_rec += (double)red[8] + (double)red[9] + (double)red[10] + (double)red[11]
@@ -521,8 +598,8 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         if (tid == 0) {
             g.partials[4 * blockIdx.x] = tot_rec;
             g.partials[4 * blockIdx.x + 1] = tot_kl;
-            g.partials[4 * blockIdx.x + 2] = 0.0;
-            g.partials[4 * blockIdx.x + 3] = 0.0;
+            g.partials[4 * blockIdx.x + 2] = tot_bc;
+            g.partials[4 * blockIdx.x + 3] = tot_ba;
         }
     } else {
         // =========================================================== helper waves ===========================================================
@@ -561,8 +638,8 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         };
         // the helper waves' own weight stream (wstream.hpp: HSched): the rest of the x block of encoder layer 1 and, for 513-label
         // models, decoder layer 1.  Row tile of helper wave hw = row tile of its partner chain wave.
-        typedef Sched<P, YP, YENC, (OFFL ? P::PDO : P::PD)> SCc;
-        typedef HSched<P, YP, YENC, DH> HS;
+        typedef Sched<P, YP, YENC, (OFFL ? P::PDO : P::PD), INFO> SCc;
+        typedef HSched<P, YP, YENC, DH, INFO> HS;
         typedef WStream<P, HS, DH> HWS;
         HWS hws;
         if constexpr (HS::any) {
@@ -576,6 +653,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             hws.sb[H_W3Y] = mo(g.W3s) + tw + (unsigned)(ZD / KS) * 4u * FBB;
             hws.sb[H_W3Z] = mo(g.W3s) + tw;
             hws.sb[H_PAD] = mo(g.W1s);
+            if constexpr (INFO) { hws.sb[H_C1] = mo(g.Wc1s) + tw;  hws.sb[H_C2] = mo(g.Wc2s) + tw;  hws.sb[H_C2T] = mo(g.Wc2t) + tw; }
+            else { hws.sb[H_C1] = hws.sb[H_C2] = hws.sb[H_C2T] = 0; }
+            if constexpr (INFO) hws.fill();                               // the classifier's first fragments: requested BEFORE the x tile (vmcnt retires in order)
         }
         const T* const Urh = U + l31 * LDU + h * E;
         const T* const Zbrh = Zb + l31 * LDZ + h * E;
@@ -644,6 +724,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     }
                     load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
                 }
+                if constexpr (INFO) {
+                    for (int i = ht; i < 6 * HD + 2; i += 256) {
+                        const int q = i / HD, k = i - q * HD;
+                        float v;
+                        if (q == 0) v = g.bc1[k]; else if (q == 1) v = g.bc2[k]; else if (q == 2) v = g.wc3[k];
+                        else if (q == 3) v = g.ba1[k]; else if (q == 4) v = g.ba2[k]; else if (q == 5) v = g.wa3[k];
+                        else v = k == 0 ? g.bc3[0] : g.ba3[0];
+                        Binfo[i] = v;
+                    }
+                }
                 if (ht == 0) flags[0] = 0;
                 wg_barrier();                                           // BX
                 if constexpr (OFFL) { if (g.fastx && full) lsum2 += tile513_log2sum(xv, g.elbo_eps, tl); }   // the tile is still in registers
@@ -656,6 +746,21 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 gemm_seg<P, HS, DH, H_W1X>(hacc, hws, Urh + SCc::NX1 * 2 * E);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) keep[r * 256 + ht] = hacc[r];
+            }
+            // ---- M2_info: the classifier on x (models.py:41-63, 418), on the helper waves beside the chain's encoder.  Wave hw owns hidden
+            // features 32 hw .. + 31 of both 128-wide layers; the layer images sit in columns IMA / IMB / IMC of U.
+            float c1r[16], c2r[16], w3c[16];
+            float bce_c = 0.f, ylab = 0.f;
+            if constexpr (INFO) {
+                ylab = g.y[rowof(l31) * g.ldy];
+                if (it > 0) hws.fill();                                    // (first tile: requested in front of the x tile)
+                f32x16 cacc;
+                zero_acc<P>(cacc);
+                gemm_seg<P, HS, DH, H_C1>(cacc, hws, Urh);
+                float bvc[16];
+                bias16(Binfo + OBC1, 32 * hw, h, bvc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c1r[r] = fmaxf(cacc[r] + bvc[r], 0.f);
             }
             f32x16 accy;                                                   // label block of decoder layer 1 (HS::HELPY)
             int yplanes = NP;                                              // planes of the label stash this tile writes (RowsArgs::ylo_skip)
@@ -683,6 +788,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
                 }
                 R2_HSTAMP(20);
+                if constexpr (INFO) put_lds<P>(c1r, U + IMA, LDU, 32 * hw, l31, h);      // the x image is dead (BL1X)
                 wg_barrier();                                           // BY
                 if constexpr (NP == 2) {
                     const bool ylo_t = __builtin_amdgcn_readfirstlane(flags[0]) != 0;
@@ -707,11 +813,50 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     else if (ylo) gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, true);
                     else gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, false);
                 }
+                if constexpr (INFO) {                                   // classifier layer 2 + this wave's share of the output dot product
+                    f32x16 a2c;
+                    zero_acc<P>(a2c);
+                    gemm_seg<P, HS, DH, H_C2>(a2c, hws, Urh + IMA);
+                    float bvc[16];
+                    bias16(Binfo + OBC2, 32 * hw, h, bvc);
+                    bias16(Binfo + OWC3, 32 * hw, h, w3c);
+                    float pd = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { c2r[r] = fmaxf(a2c[r] + bvc[r], 0.f); pd = fmaf(w3c[r], c2r[r], pd); }
+                    put_lds<P>(c2r, U + IMB, LDU, 32 * hw, l31, h);
+                    pd += __shfl_xor(pd, 32, 64);
+                    if (h == 0) red2[hw * 32 + l31] = pd;
+                }
             } else {
                 if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
                 if constexpr (HS::n(H_W1X) > 0) wg_barrier();            // BL1X (models without labels): the partial tile is in `keep`
             }
             wg_barrier();                                               // BH1
+            if constexpr (INFO) {
+                // sigmoid output, binary_cross_entropy against the frame label (utils.py:55-56) and the unit-scale backward to dpre2; the
+                // stashed pre-activation gradients carry alpha (classif_loss = alpha * BCE, training_M2_info_vad.py:165)
+                const bool live_h = (b0 + l31) < g.B;
+                const float logit = red2[l31] + red2[32 + l31] + red2[64 + l31] + red2[96 + l31] + Binfo[OS3];
+                const float p = 1.f / (1.f + P::exp_(-logit));
+                const float lp = P::log_(p + g.elbo_eps), lq = P::log_(1.f - p + g.elbo_eps);
+                bce_c = (live_h && h == 0 && hw == 0) ? -(ylab * lp + (1.f - ylab) * lq) : 0.f;
+                const float u = live_h ? -g.invB * (ylab / (p + g.elbo_eps) - (1.f - ylab) / (1.f - p + g.elbo_eps)) : 0.f;   // d BCE / d p
+                const float dpre3 = u * p * (1.f - p);
+                float dv2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv2[r] = c2r[r] > 0.f ? w3c[r] * dpre3 : 0.f;                 // dpre2 (unit scale)
+                put_lds<P>(dv2, U + IMC, LDU, 32 * hw, l31, h);
+                if (st1) {
+                    stash_tile<P>(U + IMA, LDU, 32 * hw, (T*)g.c1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+                    stash_tile<P>(U + IMB, LDU, 32 * hw, (T*)g.c2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+                    if (hw == 0 && h == 0) {                               // output pre-activation gradient: feature row 0 of a 32-row stash tile
+                        T* d3 = (T*)g.dc3T + (b0 / KS) * (64 * E) + (l31 / E) * 32 * E + (l31 % E);
+                        const T d3h = P::cvt(dpre3 * g.alpha);
+                        *d3 = d3h;
+                        if constexpr (NP == 2) d3[g.spl] = P::cvt(dpre3 * g.alpha - (float)d3h);
+                    }
+                }
+            }
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
 #if R2_LATE_Y
             // the label tile stays in U until the output layer: its stash waits for these two phases, away from the window in which every
@@ -720,6 +865,16 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, 0, R2_YSPREAD, yplanes);
 #endif
             wg_barrier();                                               // BH2
+            if constexpr (INFO) {                                          // classifier: backward through layer 2, dpre1 -> image A (c1 is stashed)
+                f32x16 a3c;
+                zero_acc<P>(a3c);
+                gemm_seg<P, HS, DH, H_C2T>(a3c, hws, Urh + IMC);
+                float dv1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv1[r] = c1r[r] > 0.f ? a3c[r] : 0.f;                          // dpre1 (unit scale)
+                put_lds<P>(dv1, U + IMA, LDU, 32 * hw, l31, h);
+                if (st1) stash_tile<P>(U + IMC, LDU, 32 * hw, (T*)g.dc2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, g.alpha);
+            }
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
 #if R2_LATE_Y
             if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, R2_YSPREAD, 1 << 30, yplanes);
@@ -738,25 +893,57 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             }
             if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
             if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
+            if constexpr (INFO) {
+                if (st1) stash_tile<P>(U + IMA, LDU, 32 * hw, (T*)g.dc1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, g.alpha);
+                // the auxiliary net on the chain (four extra phases): its layer tiles go to the stash from here; pre-activation gradients
+                // carry gamma - beta (quirk Q4)
+                const float sa = g.gamma - g.beta;
+                wg_barrier();                                           // BA1: a1 is in Ha
+                if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.a1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+                wg_barrier();                                           // BA2: a2 is in Hb, the output partials in red2
+                if (st1) {
+                    stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.a2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+                    if (hw == 0 && h == 0) {
+                        const bool live_h = (b0 + l31) < g.B;
+                        const float logit = red2[l31] + red2[32 + l31] + red2[64 + l31] + red2[96 + l31] + Binfo[OS3 + 1];
+                        const float p = 1.f / (1.f + P::exp_(-logit));
+                        const float u = live_h ? -g.invB * (ylab / (p + g.elbo_eps) - (1.f - ylab) / (1.f - p + g.elbo_eps)) : 0.f;
+                        const float dpre3 = u * p * (1.f - p);
+                        T* d3 = (T*)g.da3T + (b0 / KS) * (64 * E) + (l31 / E) * 32 * E + (l31 % E);
+                        const T d3h = P::cvt(dpre3 * sa);
+                        *d3 = d3h;
+                        if constexpr (NP == 2) d3[g.spl] = P::cvt(dpre3 * sa - (float)d3h);
+                    }
+                }
+                wg_barrier();                                           // BA3: dpre2 is in Ha
+                if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.da2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, sa);
+                wg_barrier();                                           // BA4: dpre1 is in Hb
+                if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.da1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, sa);
+            }
             wg_barrier();                                               // BD1
+            // loss epilogue of the output layer (OFFL): x of the first round's tile is requested HERE, a phase early.  Requested at BD2
+            // by every CU at once (the tile has long left the L2: 16.8 MB from the Infinity Cache / HBM within a microsecond) the burst
+            // doubled the time of the first epilogue round AND of the chain's GEMM beside it (its weight loads queue behind the misses).
+            // per-iteration opaque copy of the lane id: keeps this block's 40-odd LDS / global addresses out of loop-invariant hoisting
+            // (hoisted to the tile loop's preheader they stay live across every phase and spill)
+            int lo_ = lane;
+            asm volatile("" : "+v"(lo_));
+            const int l31o = lo_ & 31, ho = lo_ >> 5;
+            const float* const xrow_o = g.x + rowof(l31o) * g.ldx + 4 * ho;
+            f32x4 xo[4], xnx[4];                                            // this round's x, the next round's (requested a round ahead)
+            if constexpr (OFFL) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) xo[gq] = reinterpret_cast<const F4U*>(xrow_o + 32 * hw + 8 * gq)->v;
+            }
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             wg_barrier();                                               // BD2
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
             float rec_h = 0.f;
             if constexpr (OFFL) {
-                // loss epilogue of the output layer: tile hw + 4 I of round I (x of all four tiles requested up front: the tile was read a
-                // few microseconds ago, L2 / MALL)
-                // per-iteration opaque copy of the lane id: keeps this block's 40-odd LDS / global addresses out of loop-invariant hoisting
-                // (hoisted to the tile loop's preheader they stay live across every phase and spill)
-                int lo_ = lane;
-                asm volatile("" : "+v"(lo_));
-                const int l31o = lo_ & 31, ho = lo_ >> 5;
+                // tile hw + 4 I of round I
                 const bool live = (b0 + l31o) < g.B;
                 const float invB_l = live ? g.invB : 0.f;                  // frames past B contribute nothing
-                const float* const xrow = g.x + rowof(l31o) * g.ldx + 4 * ho;
-                f32x4 xo[4], xnx[4];                                        // this round's x, the next round's (requested a round ahead)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) xo[gq] = reinterpret_cast<const F4U*>(xrow + 32 * hw + 8 * gq)->v;
+                const float* const xrow = xrow_o;
 #pragma unroll 1
                 for (int I = 0; I < 4; ++I) {                               // rolled: unrolled, the scheduler interleaves the rounds and the block spills
                     const int t = hw + 4 * I;
@@ -858,6 +1045,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 if (lane == 0) { red[8 + hw] = rs; red[12 + hw] = ls; }
                 lsum2 = 0.f;
             }
+            if constexpr (INFO) { if (hw == 0) { const float bcs = wave_sum(bce_c); if (lane == 0) red2[128] = bcs; } }
             if (more) {
                 if (x_in_regs) {
                     tile513_commit<P, XP>(xv, U, LDU, tl);
@@ -869,19 +1057,19 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     }
 }
 
-template <typename P, int YP, bool YENC, int MODE>
+template <typename P, int YP, bool YENC, int MODE, bool INFO = false>
 static int launch_rows2_m(const RowsArgs& a, int grid, hipStream_t s) {
-    const size_t lds = Lds2<P>::bytes;
+    const size_t lds = Lds2<P, INFO>::bytes;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC, MODE, INFO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(rows2 kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC, MODE>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC, MODE, INFO>), dim3(grid), dim3(512), lds, s, a);
     DVAE_LAUNCH_OK("vae_rows2_kernel");
     return 0;
 }
@@ -893,9 +1081,14 @@ static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
     return launch_rows2_m<P, YP, YENC, 0>(a, grid, s);
 }
 
-// model: DVAE_MODEL_M1 / DVAE_MODEL_M2 (M2_info stays on the 4-wave kernel); precision: DVAE_PREC_BF16 / DVAE_PREC_BF16X3
+// model: DVAE_MODEL_M1 / DVAE_MODEL_M2 / DVAE_MODEL_M2_INFO (train step only); precision: DVAE_PREC_BF16 / DVAE_PREC_BF16X3
 int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s) {
     const bool m2 = model == DVAE_MODEL_M2;
+    if (model == DVAE_MODEL_M2_INFO) {
+        if (a.mode != 0) { set_error("rows2 kernel: M2_info runs the fused train step only (mode %d)", a.mode); return DVAE_E_UNSUPPORTED; }
+        if (precision == DVAE_PREC_BF16X3) return launch_rows2_m<PolX3v2, 16, false, 0, true>(a, grid, s);
+        if (precision == DVAE_PREC_BF16) return launch_rows2_m<PolBF16v2, 16, false, 0, true>(a, grid, s);
+    }
     if (precision == DVAE_PREC_BF16X3) {
         if (!m2) return launch_rows2_t<PolX3v2, 0, false>(a, grid, s);
         if (y_dim == 1) return launch_rows2_t<PolX3v2, 16, true>(a, grid, s);
@@ -911,7 +1104,7 @@ int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int gri
 }
 
 bool rows2_supported(int precision, int model) {
-    return (precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3) && (model == DVAE_MODEL_M1 || model == DVAE_MODEL_M2);
+    return (precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3) && (model == DVAE_MODEL_M1 || model == DVAE_MODEL_M2 || model == DVAE_MODEL_M2_INFO);
 }
 
 }  // namespace fused

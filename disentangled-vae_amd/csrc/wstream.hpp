@@ -38,9 +38,10 @@ namespace dvae {
 namespace fused {
 
 // segments in consumption order (G_W5A..D: the four output-layer tiles of a wave; G_PAD: dummy positions)
-enum { G_W1X, G_W1Y, G_W2, G_WMV, G_W3Y, G_W3Z, G_W4, G_W5A, G_W5B, G_W5C, G_W5D, G_W5T, G_W4T, G_W3ZT, G_WMVT, G_W2T, G_PAD, G_N };
+// G_A1 .. G_A1T: M2_info's auxiliary classifier on z (16-128-128-1), forward and backward, between the heads and decoder layer 1
+enum { G_W1X, G_W1Y, G_W2, G_WMV, G_W3Y, G_A1, G_A2, G_A2T, G_A1T, G_W3Z, G_W4, G_W5A, G_W5B, G_W5C, G_W5D, G_W5T, G_W4T, G_W3ZT, G_WMVT, G_W2T, G_PAD, G_N };
 
-template <typename P, int YP, bool YENC, int D> struct Sched {
+template <typename P, int YP, bool YENC, int D, bool INFO = false> struct Sched {
     static constexpr int KS = P::KSTEP;
     static constexpr int NSEG = G_N;
     static constexpr unsigned FBB = 64u * P::E * sizeof(typename P::T);          // bytes of one (row tile, k-step) fragment block
@@ -48,6 +49,7 @@ template <typename P, int YP, bool YENC, int D> struct Sched {
     static constexpr bool HELPY = R2_HELPY && YP == XP;                            // decoder layer 1 lives on the helper waves
     static constexpr int raw(int s) {
         return s == G_W1X ? NX1 : s == G_W1Y ? (YENC ? YP / KS : 0) : s == G_W3Y ? (HELPY ? 0 : YP / KS) : s == G_W3Z ? (HELPY ? 0 : ZD / KS)
+             : s == G_A1 ? (INFO ? ZD / KS : 0) : (s == G_A2 || s == G_A2T || s == G_A1T) ? (INFO ? HD / KS : 0)
              : s == G_W5T ? NO / KS : s == G_WMVT ? 32 / KS : s == G_PAD ? 0 : HD / KS;
     }
     static constexpr int sum_raw() { int t = 0; for (int s = 0; s < G_PAD; ++s) t += raw(s); return t; }
@@ -58,18 +60,22 @@ template <typename P, int YP, bool YENC, int D> struct Sched {
     static constexpr int start(int s) { int t = 0; for (int i = 0; i < s; ++i) t += n(i); return t; }
     static constexpr int seg_of(int q) { int s = 0; while (q >= start(s) + n(s)) ++s; return s; }
     // k-step stride: 4-tile matrices are [k-step][4 tiles], the single-tile heads [k-step][1], the output layer [k-step][17]
-    static constexpr unsigned stride(int s) { return (s == G_WMV || s == G_W3ZT) ? FBB : (s >= G_W5A && s <= G_W5D) ? NT_OUT * FBB : 4u * FBB; }
+    static constexpr unsigned stride(int s) { return (s == G_WMV || s == G_W3ZT || s == G_A1T) ? FBB : (s >= G_W5A && s <= G_W5D) ? NT_OUT * FBB : 4u * FBB; }
 };
 
-// the helper waves' stream: the rest of the x block of layer 1, then (513-label models) decoder layer 1
-enum { H_W1X, H_W3Y, H_W3Z, H_PAD, H_N };
-template <typename P, int YP, bool YENC, int D> struct HSched {
-    typedef Sched<P, YP, YENC, D> C;
+// the helper waves' stream: the rest of the x block of layer 1, then (513-label models) decoder layer 1; M2_info: the classifier on x
+// (513-128-128-1: layer 1, layer 2, backward through layer 2), which runs beside the chain's encoder
+enum { H_W1X, H_W3Y, H_W3Z, H_C1, H_C2, H_C2T, H_PAD, H_N };
+template <typename P, int YP, bool YENC, int D, bool INFO = false> struct HSched {
+    typedef Sched<P, YP, YENC, D, INFO> C;
     static constexpr int KS = P::KSTEP;
     static constexpr int NSEG = H_N;
     static constexpr unsigned FBB = C::FBB;
     static constexpr bool HELPY = C::HELPY;
-    static constexpr int raw(int s) { return s == H_W1X ? XP / KS - C::NX1 : s == H_W3Y ? (C::HELPY ? YP / KS : 0) : s == H_W3Z ? (C::HELPY ? ZD / KS : 0) : 0; }
+    static constexpr int raw(int s) {
+        return s == H_W1X ? XP / KS - C::NX1 : s == H_W3Y ? (C::HELPY ? YP / KS : 0) : s == H_W3Z ? (C::HELPY ? ZD / KS : 0)
+             : s == H_C1 ? (INFO ? XP / KS : 0) : (s == H_C2 || s == H_C2T) ? (INFO ? HD / KS : 0) : 0;
+    }
     static constexpr int sum_raw() { int t = 0; for (int s = 0; s < H_PAD; ++s) t += raw(s); return t; }
     // the helpers' stream does not wrap: it is started (fill) when the tile's label image is about to be committed and requests nothing
     // past its last position, so no fragment registers stay live through the rest of the tile
