@@ -348,6 +348,8 @@ def main():
     }
     if world > 1:
         out["multi_gpu"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(),
+                            "exchange": os.environ.get("DVAE_ALLREDUCE", "rccl") + (" (dvae_allreduce_flat: peer pointers, one launch per rank)"
+                                                                                    if os.environ.get("DVAE_ALLREDUCE") == "direct" else " (torch.distributed all_reduce)"),
                             "allreduce_us": None if prof is None else prof.get("allreduce_us"),
                             "allreduce_bytes": None if impl_name != "fused" else 4 * int(impl.tr.plan.n_params),
                             "note": "allreduce_us = mean device time of the flat-gradient all-reduce per step (events on the launch stream, rank 0)"}

@@ -71,7 +71,7 @@ struct RowsArgs {
     double* partials;
     unsigned long long* dbg;    // diagnostic stamps (100 MHz wall clock), null in production
     int ablate;                 // diagnostic ablation mask (env DVAE_ABLATE), 0 in production
-    int stash_inputs;           // 0: the weight-gradient kernel reads x / y from the input matrices, no stash for them (8-wave kernel only)
+    int stash_inputs;           // bit 0: stash the x tile, bit 1: stash the label tile; a cleared bit = the weight-gradient kernel reads that input from its fp32 matrix (8-wave kernel only)
     // Label tiles that one bf16 plane holds exactly (binary VAD / IBM labels) have an all-zero lo plane: the 8-wave kernel then stores only
     // the hi plane of the label stash (ylo_skip != 0) and raises *ylo_epoch to `launch_id` as soon as ANY tile of the launch does need its
     // lo plane; the weight-gradient kernel reads the label lo plane (and issues the hi * lo products) only in that case.

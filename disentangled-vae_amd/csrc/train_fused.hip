@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
     for (int k = 0; k < 4; ++k) { if (bd.At[k] != nullptr) na = k + 1; if (bd.Bt[k] != nullptr) nb = k + 1; }
 #define W4_GO(NA_, NB_, RAW_) wgrad4_body<P, NA_, NB_, RAW_>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave, ri)
     bool raw = false;
-    if constexpr (sizeof(typename P::T) == 2) raw = use_raw && bd.raw != 0;       // input-matrix B tiles (16-bit operand policies only)
+    if constexpr (sizeof(typename P::T) == 2) raw = (use_raw & bd.raw) != 0;      // input-matrix B tiles (16-bit operand policies only); use_raw bit 0: x, bit 1: labels
     if (raw) {
         if constexpr (sizeof(typename P::T) == 2) {
             if (nb == 4 && bd.rcol[0] + 128 <= bd.rncols) W4_GO(4, 4, 2);      // four full tiles: through the LDS staging rows
@@ -1901,7 +1901,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     // transpose 8 KB per k-step and wave through LDS behind a two-deep ring -- so the stash stays the default (step 78.6 vs 81.8 us).
     const bool raw_inputs = getenv("DVAE_RAW_INPUTS") != nullptr && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) &&
                             a.rows == nullptr && wgrad_form(getenv("DVAE_WGRAD")) == 4 && g_mode.mode != 1;
-    a.stash_inputs = raw_inputs ? 0 : 1;
+    // DVAE_RAW_INPUTS=x: only the x tile is read raw (the label stash stays: one plane for binary labels); any other value: x and labels
+    const int raw_mask = !raw_inputs ? 0 : (strcmp(getenv("DVAE_RAW_INPUTS"), "x") == 0 ? 1 : 3);
+    a.stash_inputs = 3 & ~raw_mask;
     a.mode = g_mode.mode;
     {   // label lo plane on demand: 8-wave kernel + the workgroup k-split weight-gradient kernel, split-bf16 operands, labels from the stash
         static std::atomic<unsigned> launch_counter{1};
@@ -1911,7 +1913,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         a.ylo_dirty = (int*)(w + L.o_flags + 256);
         a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);
         if (a.launch_id == 0) a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of a fresh workspace
-        a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && wg4 && !raw_inputs &&
+        a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && wg4 && !(raw_mask & 2) &&
                       getenv("DVAE_YLO_ALWAYS") == nullptr) ? 1 : 0;
     }
     a.out_r = g_mode.out_r; a.out_mu = g_mode.out_mu; a.out_lv = g_mode.out_lv; a.out_z = g_mode.out_z; a.ld_r = g_mode.ld_r;
@@ -1968,7 +1970,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         const dim3 g3((unsigned)(8 * ((ks >> 3) * L.nblocks4 + (((ks & 7) * L.nblocks4 + 7) >> 3))));   // see the index map at the top of wgrad4_kernel
         RawIn ri;
         ri.x = x; ri.y = y; ri.ldx = ldx; ri.ldy = plan->y_dim ? ldy : 0; ri.B = plan->B;
-        const int use_raw = raw_inputs ? 1 : 0;
+        const int use_raw = raw_mask;
         static bool attr_done[64][3] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);

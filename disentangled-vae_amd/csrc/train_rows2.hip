@@ -663,7 +663,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         f32x4 xv[NQ513], yv[NQ513];
         bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
         bool y_in_regs = false;       // persistent loop: the NEXT tile's label tile is requested during this tile's backward phases too
-        const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2) && g.stash_inputs;   // forward-only launches stash nothing
+        // forward-only launches stash nothing; stash_inputs: bit 0 = the x tile, bit 1 = the label tile (a cleared bit: the weight-gradient
+        // kernel reads that input from its fp32 matrix)
+        const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2) && (g.stash_inputs & 2), st2x = MODE != 1 && !(g.ablate & 2) && (g.stash_inputs & 1);
         for (int it = 0; it < ntl; ++it) {
             const int tile = (int)blockIdx.x + it * (int)gridDim.x;
             const int64_t b0 = (int64_t)tile * TB;
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (YP > 0) {
                 if (Y513 && yfast && !y_early) tile513_issue(g.y, rowof, yv, tl);
                 R2_HSTAMP(16);
-                if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (st2x) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
                 R2_HSTAMP(17);
                 wg_barrier();                                           // BL1X
                 if constexpr (HS::HELPY && HS::n(H_W1X) == 0) hws.fill();  // decoder layer 1's first fragments arrive under the label commit
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if (h == 0) red2[hw * 32 + l31] = pd;
                 }
             } else {
-                if (st2) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (st2x) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
                 if constexpr (HS::n(H_W1X) > 0) wg_barrier();            // BL1X (models without labels): the partial tile is in `keep`
             }
             wg_barrier();                                               // BH1

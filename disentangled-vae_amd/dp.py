@@ -3,7 +3,12 @@ so rank k takes rows [k*B, (k+1)*B) of the global batch, every rank holds a full
 0.17-0.30 M parameters, and the only exchange per step is ONE all-reduce (sum) of the flat fp32
 gradient buffer, scaled by 1/world before an identical Adam step on every rank.  On the GPU node the
 process group is RCCL over xGMI (backend "nccl"); the same code runs on gloo for CPU tests."""
+import ctypes
+import os
+
 import torch.distributed as dist
+
+IPC_HANDLE_BYTES = 64          # include/dvae_train.h: DVAE_IPC_HANDLE_BYTES
 
 
 def shard_rows(global_rows, rank, world):
@@ -33,3 +38,52 @@ def mean_scalars_(t, world, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     t.div_(world)
     return t
+
+
+def exchange_mode():
+    """DVAE_ALLREDUCE=rccl (default: torch.distributed all_reduce on the process group's backend) | direct (dvae_allreduce_flat: the
+    library's own reduce-scatter / all-gather over hipIpc-mapped peer buffers, stream-ordered, fused with the slab sum)."""
+    m = os.environ.get("DVAE_ALLREDUCE", "rccl")
+    if m not in ("rccl", "direct"):
+        raise ValueError("DVAE_ALLREDUCE must be rccl or direct")
+    return m
+
+
+class DirectExchange:
+    """dvae_comm_* / dvae_allreduce_flat (include/dvae_train.h, csrc/allreduce.hip) for one flat gradient of n floats.
+
+    The process group is used ONCE, on the host, to pass the hipIpc handles of the ranks' exchange buffers around; after that a step's
+    exchange is one kernel launch per rank on the step's own stream.  Every rank must call allreduce() the same number of times.
+    UNMEASURED on multi-GPU hardware (the build box has one GPU); bit-identical to the process-group path at world 2 (tests)."""
+
+    def __init__(self, n_floats, group=None):
+        from . import native as N
+        self.N, self.lib = N, N.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n = int(n_floats)
+        self.handle = ctypes.c_void_p()
+        mine = (ctypes.c_ubyte * IPC_HANDLE_BYTES)()
+        N.check(self.lib.dvae_comm_create(self.rank, self.world, self.n, ctypes.byref(self.handle), mine), "dvae_comm_create")
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, bytes(mine), group=group)
+        blob = (ctypes.c_ubyte * (IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(gathered))
+        N.check(self.lib.dvae_comm_connect(self.handle, blob), "dvae_comm_connect")
+        dist.barrier(group=group)                      # every rank has mapped every buffer before the first launch
+
+    def allreduce(self, slabs, n_slabs, slab_stride, out):
+        """out[i] = sum over ranks of sum_k slabs[k * slab_stride + i]  (fp32 CUDA tensors; `out` may be slab 0); enqueued on the
+        current stream, returns at once."""
+        N = self.N
+        N.check(self.lib.dvae_allreduce_flat(self.handle, N.ptr(slabs), int(n_slabs), int(slab_stride), N.ptr(out), N.stream()),
+                "dvae_allreduce_flat")
+
+    def failed(self):
+        """Synchronises; True when a bounded wait for a peer expired (the exchanged values are then undefined)."""
+        f = ctypes.c_int(0)
+        self.N.check(self.lib.dvae_comm_status(self.handle, ctypes.byref(f)), "dvae_comm_status")
+        return bool(f.value)
+
+    def close(self):
+        if self.handle:
+            self.lib.dvae_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()

@@ -63,6 +63,11 @@ SIGNATURES = {
     "dvae_train_profile": (c_i, [c_i]),
     "dvae_train_debug_stamps": (c_i, [c_vp]),
     "dvae_train_profile_read": (c_i, [c_vp, c_vp]),
+    "dvae_comm_create": (c_i, [c_i, c_i, c_i64, c_vp, c_vp]),
+    "dvae_comm_connect": (c_i, [c_vp, c_vp]),
+    "dvae_allreduce_flat": (c_i, [c_vp, c_vp, c_i, c_i64, c_vp, c_vp]),
+    "dvae_comm_status": (c_i, [c_vp, c_vp]),
+    "dvae_comm_destroy": (c_i, [c_vp]),
     # include/dvae_mcem.h
     "dvae_mcem_plan": (c_i, [c_i, c_i, c_vp]),
     "dvae_mcem_pack": (c_i, [c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp]),

@@ -101,6 +101,12 @@ class Trainer:
         self.plan.bad_row_counter = self.bad_rows.data_ptr()
         go = self.plan.grad_offset_bytes
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
+        # gradient exchange of the data-parallel step: the process group's all-reduce (RCCL over xGMI), or the library's own
+        # stream-ordered exchange over peer pointers (DVAE_ALLREDUCE=direct; dp.DirectExchange) -- unmeasured on multi-GPU hardware
+        self.direct = share.direct if share is not None else None
+        if self.world > 1 and share is None and dp.exchange_mode() == "direct":
+            with torch.cuda.device(self.device):
+                self.direct = dp.DirectExchange(P, process_group)
         self._copy_version = self._shared["version"]
         rank = torch.distributed.get_rank(process_group) if (process_group is not None and torch.distributed.is_initialized()) else 0
         base = int(seed) if seed is not None else (share.plan.rng_seed if share is not None else int(torch.initial_seed()))
@@ -258,13 +264,17 @@ class Trainer:
                                              self.betas[1], self.adam_eps, N.ptr(self.losses), s), "dvae_train_step")
             self._reduced = False
         else:
+            direct = self.direct
             N.check(self.lib.dvae_train_grads(plan, N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
-                                              self.elbo_eps, 1, s), "dvae_train_grads")
+                                              self.elbo_eps, 0 if direct is not None else 1, s), "dvae_train_grads")
             ev = None
             if self._ar_events is not None:                           # profiling: device time of the exchange, on the launch stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            dp.allreduce_flat_(self.flat_grad, self.pg)              # RCCL over xGMI: one flat fp32 buffer per step
+            if direct is not None:                                    # slab sum + reduce-scatter + all-gather in one launch on this stream
+                direct.allreduce(self.flat_grad, self._used_slabs(), self.plan.n_params, self.flat_grad)
+            else:
+                dp.allreduce_flat_(self.flat_grad, self.pg)          # RCCL over xGMI: one flat fp32 buffer per step
             if ev is not None:
                 ev[1].record()
                 self._ar_events.append(ev)

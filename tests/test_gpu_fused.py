@@ -185,8 +185,9 @@ def test_state_dict_round_trip_and_repack():
         trainer.Trainer("M2", dict(x_dim=513, y_dim=7, z_dim=16, h_dim=(128, 128)), None, batch=8)
 
 
-def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32"):
+def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32", exchange="rccl"):
     import os, sys
+    os.environ["DVAE_ALLREDUCE"] = exchange
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
     import importlib, numpy as np, torch, torch.distributed as dist
@@ -204,7 +205,11 @@ def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32"):
         x, y, e = gu.make_batch(dims, Bg, 30 + step)
         t = lambda a: torch.from_numpy(a[lo:hi].copy()).cuda()
         losses = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
-    q.put((rank, tr.state_dict_numpy(), losses))
+    failed = tr.direct.failed() if tr.direct is not None else False
+    q.put((rank, tr.state_dict_numpy(), losses, failed, tr.direct is not None))
+    if tr.direct is not None:
+        dist.barrier()
+        tr.direct.close()
     dist.destroy_process_group()
 
 
@@ -239,6 +244,34 @@ def test_two_rank_data_parallel_equals_single_process(model, y_dim, precision):
         assert d.max() <= (2e-6 if (model, precision) == ("M2", "fp32") else 4.1e-4), (k, d.max())
         assert np.mean(d > 2e-6) < (0.0 if (model, precision) == ("M2", "fp32") else 0.02) + 1e-12, (k, float(np.mean(d > 2e-6)))
     np.testing.assert_allclose(0.5 * (res[0][2] + res[1][2]), losses, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "bf16x3"), ("M2_info", 1, "bf16x3")])
+def test_direct_exchange_equals_the_process_group_exchange(model, y_dim, precision):
+    """DVAE_ALLREDUCE=direct (dvae_allreduce_flat: slab sum + reduce-scatter by pull + all-gather by push over hipIpc-mapped peer buffers,
+    one launch per rank on the step's stream) against the process-group all-reduce, two ranks sharing the one GPU: the parameters after
+    two steps are bit-identical (at world 2 both paths add the two ranks' slab sums once), no bounded wait expired."""
+    import torch.multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    got = {}
+    for exchange in ("direct", "rccl"):
+        q = ctx.Queue()
+        port = 31000 + (os.getpid() + 13 * len(model) + y_dim + (7 if exchange == "direct" else 0)) % 2000
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, model, y_dim, precision, exchange)) for r in range(2)]
+        for pr in procs:
+            pr.start()
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+        got[exchange] = res
+    for r in range(2):
+        assert got["direct"][r][4] and not got["rccl"][r][4]                       # the direct path really ran
+        assert not got["direct"][r][3], "a bounded wait for the peer expired"
+        np.testing.assert_array_equal(got["direct"][r][2], got["rccl"][r][2])
+        for k in got["rccl"][r][1]:
+            np.testing.assert_array_equal(got["direct"][r][1][k], got["rccl"][r][1][k], err_msg=k)
 
 
 class FusedInfoImpl(FusedImpl):
