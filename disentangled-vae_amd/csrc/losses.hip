@@ -171,6 +171,142 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+
+// ---- loss zoo of packages/models/utils.py beyond elbo / BCE (reference :65-118): per-frame Itakura-Saito + KL rows (L_loss,
+// ikatura_saito_divergence), the two-class BCE and the squared-error mask / signal / magnitude-spectrum-approximation losses.
+// Same structure as above: one wave per frame or a flat grid-stride sum, double partials, one-block final pass, no atomics.
+__global__ __launch_bounds__(256) void isrows_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r, int ldr,
+                                                          const float* __restrict__ mu, const float* __restrict__ lv, float eps,
+                                                          int64_t B, int F, int Z, float* __restrict__ rec_b, float* __restrict__ kl_b) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += nw) {
+        const float* xr = x + b * ldx;
+        const float* rr = r + b * ldr;
+        float acc = 0.f;
+        for (int f = lane; f < F; f += 64) {
+            const float xv = xr[f], rv = rr[f];
+            acc += xv / rv - logf(xv + eps) + logf(rv) - 1.f;     // utils.py:71, 79
+        }
+        acc = wave_sum(acc);
+        float k = 0.f;
+        if (kl_b) {
+            for (int j = lane; j < Z; j += 64) {
+                const float m = mu[b * Z + j], l = lv[b * Z + j];
+                k += l - m * m - expf(l);                         // utils.py:80
+            }
+            k = -0.5f * wave_sum(k);
+        }
+        if (lane == 0) { rec_b[b] = acc; if (kl_b) kl_b[b] = k; }
+    }
+}
+
+__global__ __launch_bounds__(256) void isrows_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r, int ldr,
+                                                          const float* __restrict__ mu, const float* __restrict__ lv,
+                                                          const float* __restrict__ g_rec, const float* __restrict__ g_kl,
+                                                          int64_t B, int F, int Z, float* __restrict__ dr, int lddr,
+                                                          float* __restrict__ dmu, float* __restrict__ dlv) {
+    const int64_t total = B * (int64_t)F, nz = B * (int64_t)Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        if (dr) {
+            const float gr = g_rec ? g_rec[b] : 0.f;
+            const float xv = x[b * ldx + f], rv = r[b * ldr + f];
+            dr[b * lddr + f] = gr / rv - gr * ((xv / rv) / rv);    // d/dr [x/r + log r]
+        }
+        if (i < nz && (dmu || dlv)) {
+            const float gk = g_kl ? g_kl[i / Z] : 0.f;
+            if (dmu) dmu[i] = gk * mu[i];
+            if (dlv) dlv[i] = -0.5f * gk * (1.f - expf(lv[i]));
+        }
+    }
+}
+
+// two-class BCE (utils.py:65-66): sum of t log(r1 + eps) + (1 - t) log(r2 + eps)
+__global__ __launch_bounds__(256) void bce2_sum_kernel(const float* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ t,
+                                                        float eps, int64_t n, double* __restrict__ partials) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += (double)(t[i] * logf(r1[i] + eps) + (1.f - t[i]) * logf(r2[i] + eps));
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void bce2_bwd_kernel(const float* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ t,
+                                                        float eps, const float* __restrict__ g, int64_t B, int64_t n,
+                                                        float* __restrict__ dr1, float* __restrict__ dr2, float* __restrict__ dt) {
+    const float s = -g[0] / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float tv = t[i];
+        if (dr1) dr1[i] = s * tv / (r1[i] + eps);
+        if (dr2) dr2[i] = s * (1.f - tv) / (r2[i] + eps);
+        if (dt) dt[i] = s * (logf(r1[i] + eps) - logf(r2[i] + eps));
+    }
+}
+
+// squared-error family (utils.py:107-118), mean over frames of the row sums of |d|^2:
+//   mode 0 (mean_square_error_signal): d = (y - yhat) * x       mode 1 (mean_square_error_mask): d = y - yhat
+//   mode 2 (magnitude_spectrum_approxiamation_loss): d = s - yhat * x with complex64 s, x (float2) and a real mask yhat
+__global__ __launch_bounds__(256) void sqerr_sum_kernel(int mode, const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ yhat, int64_t n, double* __restrict__ partials) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mode == 2) {
+            const float2 xc = reinterpret_cast<const float2*>(x)[i], sc = reinterpret_cast<const float2*>(y)[i];
+            const float m = yhat[i];
+            const float dr_ = sc.x - m * xc.x, di = sc.y - m * xc.y;
+            s += (double)(dr_ * dr_ + di * di);
+        } else {
+            float d = y[i] - yhat[i];
+            if (mode == 0) d *= x[i];
+            s += (double)(d * d);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void mean_final_kernel(const double* __restrict__ partials, int nblocks, int64_t B, float sign, float* __restrict__ out1) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) a += partials[i];
+    a = wave_sum(a);
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out1[0] = (float)((double)sign * (red[0] + red[1] + red[2] + red[3]) / (double)B);
+}
+
+__global__ __launch_bounds__(256) void sqerr_bwd_kernel(int mode, const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ yhat, const float* __restrict__ g, int64_t B, int64_t n,
+                                                         float* __restrict__ dyhat, float* __restrict__ dy, float* __restrict__ dx) {
+    const float s = 2.f * g[0] / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (mode == 2) {
+            const float2 xc = reinterpret_cast<const float2*>(x)[i], sc = reinterpret_cast<const float2*>(y)[i];
+            const float m = yhat[i];
+            const float dr_ = sc.x - m * xc.x, di = sc.y - m * xc.y;
+            if (dyhat) dyhat[i] = -s * (dr_ * xc.x + di * xc.y);        // d |s - m x|^2 / d m = -2 Re(d conj(x))
+        } else {
+            const float e = y[i] - yhat[i];
+            const float xv = mode == 0 ? x[i] : 1.f;
+            const float ge = s * e * xv * xv;
+            if (dyhat) dyhat[i] = -ge;
+            if (dy) dy[i] = ge;
+            if (dx && mode == 0) dx[i] = s * e * e * xv;
+        }
+    }
+}
+
 static inline int ew_blocks(int64_t n) {
     int64_t b = cdiv(n, 256);
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -252,6 +388,70 @@ extern "C" int dvae_bce_bwd(const float* r, const float* t, float eps, const flo
     const int64_t n = B * (int64_t)Y;
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, r, t, eps, g, B, n, variant, dr, dt);
     DVAE_LAUNCH_OK("bce_bwd");
+    return 0;
+}
+
+
+/* ---- remaining losses of packages/models/utils.py (reference :65-118) ---- */
+extern "C" int dvae_isrows_fwd(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar, float eps,
+                               int64_t B, int F, int Z, float* recon_rows, float* kl_rows, void* stream) {
+    DVAE_CHECK_ARG(x && r && recon_rows && B > 0 && F > 0 && ldx >= F && ldr >= F && (!kl_rows || (mu && logvar && Z > 0)), "isrows_fwd: bad argument");
+    const int nb = (int)(cdiv(B, 4) < 2048 ? cdiv(B, 4) : 2048);
+    hipLaunchKernelGGL(isrows_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, ldx, r, ldr, mu, logvar, eps, B, F, Z, recon_rows, kl_rows);
+    DVAE_LAUNCH_OK("isrows_fwd");
+    return 0;
+}
+
+extern "C" int dvae_isrows_bwd(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar,
+                               const float* g_recon_rows, const float* g_kl_rows, int64_t B, int F, int Z,
+                               float* dr, int lddr, float* dmu, float* dlogvar, void* stream) {
+    DVAE_CHECK_ARG(x && r && B > 0 && F > 0 && ldx >= F && ldr >= F && (!dr || lddr >= F) && ((!dmu && !dlogvar) || (mu && logvar && Z > 0 && Z <= F)),
+                   "isrows_bwd: bad argument");
+    hipLaunchKernelGGL(isrows_bwd_kernel, dim3(ew_blocks(B * (int64_t)F)), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, r, ldr, mu, logvar, g_recon_rows, g_kl_rows, B, F, Z, dr, lddr, dmu, dlogvar);
+    DVAE_LAUNCH_OK("isrows_bwd");
+    return 0;
+}
+
+extern "C" int dvae_bce2_fwd(const float* r1, const float* r2, const float* t, float eps, int64_t B, int Y, float* out1, void* ws, void* stream) {
+    DVAE_CHECK_ARG(r1 && r2 && t && out1 && ws && B > 0 && Y > 0, "bce2_fwd: bad argument");
+    const int64_t n = B * (int64_t)Y;
+    const int nb = (int)(cdiv(n, 256) < kMaxPartials ? cdiv(n, 256) : kMaxPartials);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce2_sum_kernel, dim3(nb), dim3(256), 0, s, r1, r2, t, eps, n, (double*)ws);
+    DVAE_LAUNCH_OK("bce2_sum");
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, nb, B, -1.f, out1);
+    DVAE_LAUNCH_OK("bce2_final");
+    return 0;
+}
+
+extern "C" int dvae_bce2_bwd(const float* r1, const float* r2, const float* t, float eps, const float* g, int64_t B, int Y,
+                             float* dr1, float* dr2, float* dt, void* stream) {
+    DVAE_CHECK_ARG(r1 && r2 && t && g && B > 0 && Y > 0, "bce2_bwd: bad argument");
+    const int64_t n = B * (int64_t)Y;
+    hipLaunchKernelGGL(bce2_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, r1, r2, t, eps, g, B, n, dr1, dr2, dt);
+    DVAE_LAUNCH_OK("bce2_bwd");
+    return 0;
+}
+
+extern "C" int dvae_sqerr_fwd(int mode, const void* x, const void* y, const float* yhat, int64_t B, int F, float* out1, void* ws, void* stream) {
+    DVAE_CHECK_ARG(mode >= 0 && mode <= 2 && y && yhat && out1 && ws && B > 0 && F > 0 && (mode == 1 || x), "sqerr_fwd: bad argument");
+    const int64_t n = B * (int64_t)F;
+    const int nb = (int)(cdiv(n, 256) < kMaxPartials ? cdiv(n, 256) : kMaxPartials);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sqerr_sum_kernel, dim3(nb), dim3(256), 0, s, mode, (const float*)x, (const float*)y, yhat, n, (double*)ws);
+    DVAE_LAUNCH_OK("sqerr_sum");
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, nb, B, 1.f, out1);
+    DVAE_LAUNCH_OK("sqerr_final");
+    return 0;
+}
+
+extern "C" int dvae_sqerr_bwd(int mode, const void* x, const void* y, const float* yhat, const float* g, int64_t B, int F,
+                              float* dyhat, float* dy, float* dx, void* stream) {
+    DVAE_CHECK_ARG(mode >= 0 && mode <= 2 && y && yhat && g && B > 0 && F > 0 && (mode == 1 || x) && (mode != 2 || (!dy && !dx)), "sqerr_bwd: bad argument");
+    const int64_t n = B * (int64_t)F;
+    hipLaunchKernelGGL(sqerr_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, mode, (const float*)x, (const float*)y, yhat, g, B, n, dyhat, dy, dx);
+    DVAE_LAUNCH_OK("sqerr_bwd");
     return 0;
 }
 

@@ -38,6 +38,12 @@ SIGNATURES = {
     "dvae_elbo_bwd3": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_vp, c_i, c_vp, c_vp, c_vp]),
     "dvae_bce_fwd": (c_i, [c_vp, c_vp, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp]),
     "dvae_bce_bwd": (c_i, [c_vp, c_vp, c_f, c_vp, c_i64, c_i, c_i, c_vp, c_vp, c_vp]),
+    "dvae_isrows_fwd": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp]),
+    "dvae_isrows_bwd": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_vp, c_i, c_vp, c_vp, c_vp]),
+    "dvae_bce2_fwd": (c_i, [c_vp, c_vp, c_vp, c_f, c_i64, c_i, c_vp, c_vp, c_vp]),
+    "dvae_bce2_bwd": (c_i, [c_vp, c_vp, c_vp, c_f, c_vp, c_i64, c_i, c_vp, c_vp, c_vp, c_vp]),
+    "dvae_sqerr_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp]),
+    "dvae_sqerr_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp, c_vp]),
     "dvae_adam_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i64, c_d, c_d, c_d, c_d, c_i, c_d, c_vp]),
     "dvae_stft": (c_i, [c_vp, c_i, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i, c_vp]),
     "dvae_istft_workspace_bytes": (c_sz, [c_i64, c_i]),

@@ -207,6 +207,140 @@ class Bce(torch.autograd.Function):
         return dr.reshape(ctx.rshape), (dt.reshape(ctx.tshape) if need_t else None), None, None
 
 
+class IsRows(torch.autograd.Function):
+    """Per-frame (recon, KL) rows of packages/models/utils.py:68-71, 78-81 (L_loss, ikatura_saito_divergence): [B] vectors.
+    mu / logvar may be None (recon rows only)."""
+
+    @staticmethod
+    def forward(ctx, x, r, mu, logvar, eps):
+        lib = N.load()
+        x_ = N.as_f32_2d(x, "is rows: x")
+        r_ = N.as_f32_2d(r, "is rows: r")
+        if r_.shape != x_.shape:
+            raise RuntimeError("is rows: shape mismatch")
+        B, F = x_.shape
+        has_kl = mu is not None
+        mu_ = N.as_f32_2d(mu, "is rows: mu").contiguous() if has_kl else None
+        lv_ = N.as_f32_2d(logvar, "is rows: logvar").contiguous() if has_kl else None
+        Z = mu_.shape[1] if has_kl else 0
+        rec = _new((B,), x_)
+        kl = _new((B,), x_) if has_kl else None
+        N.check(lib.dvae_isrows_fwd(N.ptr(x_), N.ld(x_), N.ptr(r_), N.ld(r_), N.ptr(mu_), N.ptr(lv_), float(eps), B, F, Z, N.ptr(rec), N.ptr(kl),
+                                    N.stream()), "dvae_isrows_fwd")
+        ctx.save_for_backward(x_, r_, *( (mu_, lv_) if has_kl else ()))
+        ctx.has_kl = has_kl
+        ctx.lead = x.shape[:-1]
+        ctx.shapes = (r.shape, None if mu is None else mu.shape, None if logvar is None else logvar.shape)
+        ctx.set_materialize_grads(False)
+        if has_kl:
+            return rec.reshape(ctx.lead), kl.reshape(ctx.lead)
+        return rec.reshape(ctx.lead)
+
+    @staticmethod
+    def backward(ctx, g_rec, g_kl=None):
+        lib = N.load()
+        saved = ctx.saved_tensors
+        x_, r_ = saved[0], saved[1]
+        mu_, lv_ = (saved[2], saved[3]) if ctx.has_kl else (None, None)
+        B, F = x_.shape
+        Z = mu_.shape[1] if ctx.has_kl else 0
+        c = lambda g: None if g is None else g.to(torch.float32).reshape(B).contiguous()
+        g_rec, g_kl = c(g_rec), c(g_kl)
+        need_r = ctx.needs_input_grad[1] and g_rec is not None
+        need_mu = ctx.has_kl and ctx.needs_input_grad[2] and g_kl is not None
+        need_lv = ctx.has_kl and ctx.needs_input_grad[3] and g_kl is not None
+        dr = _new((B, F), x_) if need_r else None
+        dmu = torch.empty_like(mu_) if need_mu else None
+        dlv = torch.empty_like(lv_) if need_lv else None
+        if need_r or need_mu or need_lv:
+            N.check(lib.dvae_isrows_bwd(N.ptr(x_), N.ld(x_), N.ptr(r_), N.ld(r_), N.ptr(mu_), N.ptr(lv_), N.ptr(g_rec), N.ptr(g_kl), B, F, Z,
+                                        N.ptr(dr), F, N.ptr(dmu), N.ptr(dlv), N.stream()), "dvae_isrows_bwd")
+        rs, ms, ls = ctx.shapes
+        return (None, None if dr is None else dr.reshape(rs), None if dmu is None else dmu.reshape(ms),
+                None if dlv is None else dlv.reshape(ls), None)
+
+
+class Bce2(torch.autograd.Function):
+    """binary_cross_entropy_2classes of packages/models/utils.py:65-66."""
+
+    @staticmethod
+    def forward(ctx, r1, r2, t, eps):
+        lib = N.load()
+        a = N.as_f32_2d(r1, "bce2: r1").contiguous()
+        b = N.as_f32_2d(r2, "bce2: r2").contiguous()
+        t_ = N.as_f32_2d(t, "bce2: target").contiguous()
+        if a.shape != b.shape or a.shape != t_.shape:
+            raise RuntimeError("bce2: shape mismatch")
+        B, Y = a.shape
+        out1 = _new((1,), a)
+        ws = torch.empty(lib.dvae_elbo_workspace_bytes(B), dtype=torch.uint8, device=a.device)
+        N.check(lib.dvae_bce2_fwd(N.ptr(a), N.ptr(b), N.ptr(t_), float(eps), B, Y, N.ptr(out1), N.ptr(ws), N.stream()), "dvae_bce2_fwd")
+        ctx.save_for_backward(a, b, t_)
+        ctx.eps, ctx.shapes = float(eps), (r1.shape, r2.shape, t.shape)
+        return out1.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = N.load()
+        a, b, t_ = ctx.saved_tensors
+        B, Y = a.shape
+        g_ = g.to(torch.float32).reshape(1).contiguous()
+        d1 = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        d2 = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        dt = torch.empty_like(a) if ctx.needs_input_grad[2] else None
+        N.check(lib.dvae_bce2_bwd(N.ptr(a), N.ptr(b), N.ptr(t_), ctx.eps, N.ptr(g_), B, Y, N.ptr(d1), N.ptr(d2), N.ptr(dt), N.stream()), "dvae_bce2_bwd")
+        s1, s2, st = ctx.shapes
+        return (None if d1 is None else d1.reshape(s1), None if d2 is None else d2.reshape(s2), None if dt is None else dt.reshape(st), None)
+
+
+class SqErr(torch.autograd.Function):
+    """mean_b sum_f |d|^2 of packages/models/utils.py:107-118.  mode 0: d = (y - yhat) x; 1: d = y - yhat; 2: d = s - yhat x with complex64
+    x, s (= y) and a real mask yhat (gradient with respect to the mask only: x and s are STFT data)."""
+
+    @staticmethod
+    def forward(ctx, mode, x, y, yhat):
+        lib = N.load()
+        if mode == 2:
+            if x.dtype != torch.complex64 or y.dtype != torch.complex64:
+                raise TypeError("magnitude spectrum approximation: x and s must be complex64")
+            xs = torch.view_as_real(x.reshape(-1, x.shape[-1]).contiguous())
+            ys = torch.view_as_real(y.reshape(-1, y.shape[-1]).contiguous())
+            B, F = xs.shape[0], xs.shape[1]
+        else:
+            ys = N.as_f32_2d(y, "squared error: y").contiguous()
+            xs = N.as_f32_2d(x, "squared error: x").contiguous() if mode == 0 else None
+            B, F = ys.shape
+        h = N.as_f32_2d(yhat, "squared error: yhat").contiguous()
+        if h.shape != (B, F) or (xs is not None and xs.shape[:2] != (B, F)):
+            raise RuntimeError("squared error: shape mismatch")
+        out1 = _new((1,), h)
+        ws = torch.empty(lib.dvae_elbo_workspace_bytes(B), dtype=torch.uint8, device=h.device)
+        N.check(lib.dvae_sqerr_fwd(mode, N.ptr(xs), N.ptr(ys), N.ptr(h), B, F, N.ptr(out1), N.ptr(ws), N.stream()), "dvae_sqerr_fwd")
+        ctx.save_for_backward(*(t for t in (xs, ys, h) if t is not None))
+        ctx.mode = mode
+        ctx.shapes = (None if x is None else x.shape, y.shape, yhat.shape)
+        return out1.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = N.load()
+        mode = ctx.mode
+        saved = ctx.saved_tensors
+        xs, ys, h = (saved if mode != 1 else (None, saved[0], saved[1]))
+        B, F = h.shape
+        g_ = g.to(torch.float32).reshape(1).contiguous()
+        need_x, need_y, need_h = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if mode == 2 and (need_x or need_y):
+            raise NotImplementedError("magnitude_spectrum_approxiamation_loss: gradients with respect to the complex spectra are not provided "
+                                      "(they are STFT data in every caller); detach them")
+        dh = torch.empty_like(h) if need_h else None
+        dy = torch.empty_like(h) if (need_y and mode != 2) else None
+        dx = torch.empty_like(h) if (need_x and mode == 0) else None
+        N.check(lib.dvae_sqerr_bwd(mode, N.ptr(xs), N.ptr(ys), N.ptr(h), N.ptr(g_), B, F, N.ptr(dh), N.ptr(dy), N.ptr(dx), N.stream()), "dvae_sqerr_bwd")
+        sx, sy, sh = ctx.shapes
+        return (None, None if dx is None else dx.reshape(sx), None if dy is None else dy.reshape(sy), None if dh is None else dh.reshape(sh))
+
+
 def adam_step_(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     """In-place torch.optim.Adam update on flat fp32 CUDA buffers (scripts/training_M2.py:122)."""
     lib = N.load()

@@ -107,6 +107,29 @@ int dvae_bce_bwd(const float* r, const float* t, float eps, const float* g, int6
                  int variant, float* dr, float* dt, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * The rest of the loss zoo of packages/models/utils.py (reference :65-118; the earlier M2v3 / M2v4 experiments train on them).
+ * Row layout [B, F] with leading dimensions like elbo; partial sums in double, no atomics; `ws` as for elbo.
+ * ------------------------------------------------------------------------- */
+/* per-frame Itakura-Saito rows recon_rows[b] = sum_f (x/r - log(x+eps) + log r - 1) (utils.py:68-71, 79) and, when kl_rows != NULL,
+ * kl_rows[b] = -0.5 sum_k (logvar - mu^2 - exp(logvar)) (utils.py:80): L_loss / ikatura_saito_divergence */
+int dvae_isrows_fwd(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar, float eps,
+                    int64_t B, int F, int Z, float* recon_rows, float* kl_rows, void* stream);
+/* gradients from per-frame upstream gradients g_recon_rows / g_kl_rows ([B], either may be NULL = zeros); outputs may be NULL */
+int dvae_isrows_bwd(const float* x, int ldx, const float* r, int ldr, const float* mu, const float* logvar,
+                    const float* g_recon_rows, const float* g_kl_rows, int64_t B, int F, int Z,
+                    float* dr, int lddr, float* dmu, float* dlogvar, void* stream);
+/* binary_cross_entropy_2classes (utils.py:65-66): -mean_b sum_j [t log(r1+eps) + (1-t) log(r2+eps)] */
+int dvae_bce2_fwd(const float* r1, const float* r2, const float* t, float eps, int64_t B, int Y, float* out1, void* ws, void* stream);
+int dvae_bce2_bwd(const float* r1, const float* r2, const float* t, float eps, const float* g, int64_t B, int Y,
+                  float* dr1, float* dr2, float* dt, void* stream);
+/* squared-error losses (utils.py:107-118), mean_b sum_f |d|^2.  mode 0 mean_square_error_signal: d = (y - yhat) x;
+ * mode 1 mean_square_error_mask: d = y - yhat (x unused); mode 2 magnitude_spectrum_approxiamation_loss: d = s - yhat x with
+ * x, y (= s) complex64 [B, F] and a real mask yhat.  Backward: dyhat always; dy, dx for the real modes (NULL = not wanted). */
+int dvae_sqerr_fwd(int mode, const void* x, const void* y, const float* yhat, int64_t B, int F, float* out1, void* ws, void* stream);
+int dvae_sqerr_bwd(int mode, const void* x, const void* y, const float* yhat, const float* g, int64_t B, int F,
+                   float* dyhat, float* dy, float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Optimiser: torch.optim.Adam(lr, betas) as the scripts construct it
  * (scripts/training_M2.py:122); op order of torch's single-tensor Adam.
  * ------------------------------------------------------------------------- */

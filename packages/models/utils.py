@@ -1,10 +1,10 @@
 """Drop-in replacement for the reference's packages/models/utils.py (loss zoo).
 
-Hot-path losses -- `elbo` (reference utils.py:73-76) and the `binary_cross_entropy`
-family (:55-63) -- run as HIP reduction kernels with hand-written backward when
-their inputs are CUDA tensors (disentangled-vae_amd/ops.py: Elbo, Bce); host tensors
-take the reference's own ATen expression.  The remaining helpers are not on the hot
-path and stay plain tensor code with the reference's signatures.
+Every loss -- `elbo` (reference utils.py:73-76), the `binary_cross_entropy` family (:55-66), `L_loss` / `U_loss` /
+`ikatura_saito_divergence` (:68-105) and the squared-error mask / signal / magnitude-spectrum losses (:107-118) -- runs as HIP
+reduction kernels with hand-written backward when its inputs are CUDA tensors (disentangled-vae_amd/ops.py: Elbo, Bce, Bce2,
+IsRows, SqErr; csrc/losses.hip); host tensors take the reference's own ATen expression (its CPU mode).  The label helpers
+(`enumerate_discrete`, `onehot`, `log_sum_exp`, `f1_loss`) are bookkeeping, not losses, and stay plain tensor code.
 """
 import torch
 from torch.autograd import Variable
@@ -63,6 +63,8 @@ def binary_cross_entropy_v3(r, eps):
 
 
 def binary_cross_entropy_2classes(r1, r2, x, eps):
+    if _on_gpu(r1, r2, x):
+        return _native.ops().Bce2.apply(r1, r2, x, eps)
     return -torch.mean(torch.sum(x * torch.log(r1 + eps) + (1 - x) * torch.log(r2 + eps), dim=-1))
 
 
@@ -77,6 +79,8 @@ def _kl_rows(mu, logvar):
 
 
 def ikatura_saito_divergence(r, x, eps):
+    if _on_gpu(r, x):
+        return _native.ops().IsRows.apply(x, r, None, None, eps)
     return _is_rows(x, r, eps)
 
 
@@ -90,6 +94,9 @@ def elbo(x, r, mu, logvar, eps):
 
 
 def L_loss(x, r, mu, logvar, eps):
+    if _on_gpu(x, r, mu, logvar):
+        recon, KL = _native.ops().IsRows.apply(x, r, mu, logvar, eps)
+        return recon + KL, recon, KL
     recon = _is_rows(x, r, eps)
     KL = _kl_rows(mu, logvar)
     return recon + KL, recon, KL
@@ -97,6 +104,11 @@ def L_loss(x, r, mu, logvar, eps):
 
 def U_loss(x, r, mu, logvar, y_hat_soft, eps):
     """Unlabelled objective of the M2v3/v4 experiments (reference :83-105)."""
+    if _on_gpu(x, r, mu, logvar, y_hat_soft):
+        # L_soft = sum_c [y L + (1 - y) L] is C * L whatever y is (its gradient with respect to y_hat_soft is zero term by term), and the
+        # entropy term is binary_cross_entropy_v3: U = C * mean(L) + bce_v3(y_hat_soft) on the elbo and BCE kernels
+        L, recon, KL = elbo(x, r, mu, logvar, eps)
+        return y_hat_soft.shape[-1] * L + binary_cross_entropy_v3(y_hat_soft, eps), L, recon, KL
     recon = _is_rows(x, r, eps)
     KL = _kl_rows(mu, logvar)
     L = (recon + KL)[..., None]
@@ -107,14 +119,20 @@ def U_loss(x, r, mu, logvar, y_hat_soft, eps):
 
 
 def mean_square_error_signal(x, y, y_hat):
+    if _on_gpu(x, y, y_hat):
+        return _native.ops().SqErr.apply(0, x, y, y_hat)
     return torch.mean(torch.sum(torch.square(torch.mul(y - y_hat, x)), axis=-1))
 
 
 def mean_square_error_mask(y, y_hat):
+    if _on_gpu(y, y_hat):
+        return _native.ops().SqErr.apply(1, None, y, y_hat)
     return torch.mean(torch.sum(torch.square(y - y_hat), axis=-1))
 
 
 def magnitude_spectrum_approxiamation_loss(x, s, y_hat):
+    if _on_gpu(x, s, y_hat):
+        return _native.ops().SqErr.apply(2, x, s, y_hat)
     d = s - y_hat * x
     return torch.mean(torch.sum(torch.real(d * d.conj()), axis=-1))
 
