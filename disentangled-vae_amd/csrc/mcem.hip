@@ -70,8 +70,15 @@ struct PolF32Deep : PolF32 {
 
 struct PolF32Lean : PolF32Deep { static constexpr int PD = 6; static constexpr int PRE = 2; };
 
+// Workgroups per CU the fp32 chain kernel is compiled for.  3 caps it at 168 registers (29 - 37 of them spill to scratch); 2 gives it 256
+// and no spill.  Measured (round 3, same box, alternating; tools/bench_mcem.py): E-step of one utterance 1027 us either way, 25 utterances
+// side by side 161 - 162 (3) against 154 - 161 (2) utterances / s: the spilled values are touched once per chain step, the third
+// workgroup hides more latency than they cost.
+#ifndef MCEM_OCC
+#define MCEM_OCC 3
+#endif
 template <typename P, int YP, int RES>
-__global__ __launch_bounds__(256, RES == 0 ? 3 : 1) void mcem_mh_kernel(const MhArgs g) {
+__global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(const MhArgs g) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP;

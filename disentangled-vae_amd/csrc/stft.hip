@@ -434,16 +434,8 @@ __global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __re
             if (idx < F * IF_FR) L.stage[f][q] = pre[u];
         }
     };
-    // Chunk order: workgroup b runs on XCD b % 8 (round-robin dispatch; speed only, never correctness).  The S runs of neighbouring
-    // chunks share their first / last 128-byte line (a chunk starts at frame 29 c - 3: no alignment), and each XCD has its own L2: with
-    // chunk = workgroup index, every such line crossed the fabric twice (FETCH_SIZE 306 MB for a 154 MB matrix).  So XCD x takes the
-    // CONSECUTIVE chunks [x * per, (x + 1) * per), dealt out to its workgroups in order: neighbours run side by side on one L2.
-    const int64_t per = (nchunks + 7) / 8, nwx = ((int64_t)gridDim.x + 7 - (blockIdx.x & 7)) / 8;      // chunks per XCD, workgroups of this XCD
-    const int64_t cx0 = (int64_t)(blockIdx.x & 7) * per;
-    int64_t cx1 = cx0 + per; if (cx1 > nchunks) cx1 = nchunks;
-    const int64_t cfirst = cx0 + (blockIdx.x >> 3);
-    if (cfirst < cx1) request(cfirst * IF_K - IF_H);
-    for (int64_t c = cfirst; c < cx1; c += nwx) {
+    if ((int64_t)blockIdx.x < nchunks) request((int64_t)blockIdx.x * IF_K - IF_H);
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int64_t t0 = c * IF_K, tb = t0 - IF_H;              // first own frame, first computed frame (may be < 0)
         __syncthreads();                                          // the previous chunk's output pass is done with acc
         for (int i = tid; i < IF_ACC; i += 256) L.acc[i] = 0.f;
@@ -453,7 +445,7 @@ __global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __re
             __syncthreads();
             // next pass (of this chunk or of this workgroup's next chunk): in flight during the FFT rounds
             if (pass + 1 < NPASS) request(ts + IF_FR);
-            else if (c + nwx < cx1) request((c + nwx) * IF_K - IF_H);
+            else if (c + gridDim.x < nchunks) request((c + gridDim.x) * IF_K - IF_H);
             for (int rr = 0; rr < IF_FR / 4; ++rr) {
                 const int q = 4 * rr + wave;
                 const int64_t t = ts + q;
