@@ -98,6 +98,28 @@ __device__ __forceinline__ s16x4 lds_tr16(const __bf16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+// Stash stores go out as buffer stores with selectable cache-policy bits (R2_STASH_AUX: gfx950 buffer aux, 0 = plain, 1 = sc0, 2 = nt,
+// 16 = sc1 = write-through, the line is not kept in the writing XCD's L2 -- the stash is read by ANOTHER kernel, on other XCDs).  They
+// are compiler-visible stores (hazards, wait counts); a first attempt with inline-asm `global_store_dwordx4 ... sc1` corrupted 0.7 % of
+// the stash bytes (no wait state behind a 128-bit store whose data registers the next VALU instruction rewrites: the compiler's hazard
+// recogniser does not see into inline asm) and still 0.06 % with an s_nop behind it.
+// Measured (round 3, M2 y513, 8192 frames, bf16x3, same box, alternating; us per step): plain stash and slab stores 74.7, sc1 stash
+// stores 73.1, sc1 stash and slab stores 72.9.  With plain stores the 80 MB of stash sit dirty in the L2s until evicted or until the
+// kernel ends.
+#ifndef R2_STASH_AUX
+#define R2_STASH_AUX 16
+#endif
+template <typename Frag>
+__device__ __forceinline__ void stash_store16(void* base_uniform, int voff_bytes, const Frag& f) {
+#if R2_STASH_AUX == 0
+    *reinterpret_cast<Frag*>((char*)base_uniform + voff_bytes) = f;
+#else
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, f), rs, voff_bytes, 0, R2_STASH_AUX);
+#endif
+}
+
 template <typename P>
 __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr, int64_t spl,
                                            int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30, int nplanes = P::NP) {
@@ -105,7 +127,7 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
     typedef typename P::Frag Frag;
     constexpr int E = P::E;
     if (stash_tile_ptr == nullptr) return;
-    T* dst = stash_tile_ptr + (b0 / P::KSTEP) * (64 * E) + l31 * E;
+    T* const dbase = stash_tile_ptr + (b0 / P::KSTEP) * (64 * E);              // wave-uniform: the tile's first fragment block
     if constexpr (sizeof(T) == 2) {
         const int i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
         const T* blk = lds + q * ldl + fbase + 16 * cg + 4 * pp;
@@ -137,8 +159,8 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
 #pragma unroll
                     for (int j = 0; j < E; ++j) f[pl][j] = P::cvt(0.f);
             }
-            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f[0];
-            if constexpr (P::NP == 2) { if (nplanes == 2) *reinterpret_cast<Frag*>(dst + spl + gq * 32 * E) = f[1]; }      // wave-uniform
+            stash_store16(dbase, (l31 * E + gq * 32 * E) * (int)sizeof(T), f[0]);
+            if constexpr (P::NP == 2) { if (nplanes == 2) stash_store16(dbase + spl, (l31 * E + gq * 32 * E) * (int)sizeof(T), f[1]); }      // wave-uniform
         }
     } else {
 #pragma unroll
@@ -151,7 +173,7 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
                 f[j] = scale == 1.f ? v : P::cvt((float)v * scale);
                 if (fbase + l31 >= col_limit) f[j] = P::cvt(0.f);
             }
-            *reinterpret_cast<Frag*>(dst + gq * 32 * E) = f;
+            stash_store16(dbase, (l31 * E + gq * 32 * E) * (int)sizeof(T), f);
         }
     }
 }

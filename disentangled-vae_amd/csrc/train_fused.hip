@@ -912,6 +912,12 @@ __device__ __forceinline__ void static_for_w(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_w<I + 1, N>(f); }
 }
 
+// gradient-slab stores of the workgroup k-split kernel as buffer stores with cache-policy bits (W4_SLAB_AUX: gfx950 buffer aux, 0 = plain,
+// 16 = sc1 = write-through -- the slabs are read by the apply kernel: 73.1 -> 72.9 us per step, same box, alternating; non-temporal
+// loads of the once-read B fragments, also tried: 26.8 -> 31.6 us for the kernel)
+#ifndef W4_SLAB_AUX
+#define W4_SLAB_AUX 16
+#endif
 template <typename P> struct Wg4 {
 #ifndef DVAE_W4RING_X3
 #define DVAE_W4RING_X3 3
@@ -1172,15 +1178,23 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
         // tile turned through this wave's LDS slot so that a lane holds four consecutive columns, 4 stores of 1 KB per tile instead of
         // 16 of 256 B: 28.1 us against 27.2 us for the kernel, same box, alternating.  The dword form stays.)
         const unsigned lo = (unsigned)(4 * h * ldo + l31);
+#if W4_SLAB_AUX
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(slab + a_off, 0, 0x7fffffff, 0x00020000);   // this A row's 32 tensor rows
+#endif
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (l31 < bd.nvalid[j]) {
                 float* const t0 = slab + a_off + bd.bcol[j];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#if W4_SLAB_AUX
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c[0][j][r]), srs, (int)(4u * lo), (int)(4u * (unsigned)(bd.bcol[j] + ((r & 3) + 8 * (r >> 2)) * ldo)), W4_SLAB_AUX);
+#else
                     float* const rowp = t0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ldo;     // wave-uniform
                     rowp[lo] = c[0][j][r];
+#endif
                 }
+                (void)t0;
             }
         }
     } else {

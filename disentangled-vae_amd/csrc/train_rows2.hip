@@ -133,6 +133,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #ifndef R2_YLOSEG
 #define R2_YLOSEG 0
 #endif
+#ifndef R2_STAGGER
+#define R2_STAGGER 0
+#endif
     constexpr bool OFFL = R2_OFFL && MODE == 0 && NP == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const U = reinterpret_cast<T*>(smem);
@@ -235,6 +238,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 wg_barrier();                                           // BX
             }
             R2_STAMP(1);
+#if R2_STAGGER
+            // diagnostic: workgroups of one XCD (b, b + 8, b + 16, ...) start their GEMM chain R2_STAGGER x 64 clocks apart (is the k-step
+            // slowed by every CU of an XCD asking its L2 for the same weight lines at the same moment?)
+            if (it == 0) { for (int q = 0; q < (int)((blockIdx.x >> 3) & 7); ++q) __builtin_amdgcn_s_sleep(R2_STAGGER); }
+#endif
             // ---------------- encoder layer 1: [x | y] -> h1 ----------------
             f32x16 acc;
             zero_acc<P>(acc);
