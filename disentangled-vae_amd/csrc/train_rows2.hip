@@ -167,7 +167,17 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const bool gather = g.rows != nullptr;
-    const int ntl = (g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1: grid <= ntiles)
+#ifndef R2_XCDMAP
+#define R2_XCDMAP 0
+#endif
+    // first tile of this workgroup.  R2_XCDMAP (diagnostic): workgroup b runs on XCD b % 8; with the map, XCD x takes the CONSECUTIVE
+    // tiles [x * grid / 8, (x + 1) * grid / 8) of a round, i.e. the frames of one slice of the weight-gradient kernel (which keeps slice
+    // s on XCD s % 8), so that a stash line is written and read through the same L2
+    int tile0 = (int)blockIdx.x;
+#if R2_XCDMAP
+    if ((gridDim.x & 7) == 0 && (g.ntiles % (int)gridDim.x) == 0) tile0 = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+#endif
+    const int ntl = (g.ntiles - tile0 + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1: grid <= ntiles)
 
     if (wave_u < 4) {
         // =========================================================== chain waves ===========================================================
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         double tot_rec = 0.0, tot_kl = 0.0, tot_bc = 0.0, tot_ba = 0.0;
 
         for (int it = 0; it < ntl; ++it) {
-            const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+            const int tile = tile0 + it * (int)gridDim.x;
             const int64_t b0 = (int64_t)tile * TB;
             const bool live = (b0 + l31) < g.B;
             const int64_t* const rsrc = rowsrc + (it & 1) * TB;
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         // kernel reads that input from its fp32 matrix)
         const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2) && (g.stash_inputs & 2), st2x = MODE != 1 && !(g.ablate & 2) && (g.stash_inputs & 1);
         for (int it = 0; it < ntl; ++it) {
-            const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+            const int tile = tile0 + it * (int)gridDim.x;
             const int64_t b0 = (int64_t)tile * TB;
             const bool full = (b0 + TB) <= g.B;
             const int64_t* const rsrc = rowsrc + (it & 1) * TB;
