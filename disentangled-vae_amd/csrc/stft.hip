@@ -54,6 +54,9 @@ __device__ __forceinline__ void store_bin(void* out, int layout, int64_t T, int 
     if (layout == 0) {            // complex64 [F][T]  (column = frame)
         o[(f * T + t) * 2] = re;
         o[(f * T + t) * 2 + 1] = im;
+    } else if (layout == 2) {     // complex64 [T][F]  (row = frame: the memory order of librosa's Fortran-ordered result)
+        o[(t * F + f) * 2] = re;
+        o[(t * F + f) * 2 + 1] = im;
     } else {                      // power [T][F] float32: np.abs(complex64)**2
         const float a = hypotf(re, im);
         o[t * F + f] = a * a;
@@ -241,7 +244,19 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
     };
 
     TIN2 cur[8], nxt[8];
-    if (LAYOUT == 1) {
+    if (LAYOUT == 2) {
+        // complex frames, frame-major: the walk of the power layout, each bin leaving as its complex64 value (512-byte runs per wave)
+        float2* o = (float2*)out;
+        const int64_t tb = ((int64_t)blockIdx.x * 4 + wave) * chunk;
+        const int64_t te = tb + chunk < T ? tb + chunk : T;
+        if (tb < te) fetch(tb, cur);
+        for (int64_t t = tb; t < te; ++t) {
+            if (t + 1 < te) { if (hop == 256) advance(t + 1, cur, nxt); else fetch(t + 1, nxt); }
+            one_frame(t, cur, [&](int f, cd X) { o[t * F + f] = float2{(float)X.x, (float)X.y}; });
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
+        }
+    } else if (LAYOUT == 1) {
         float* o = (float*)out;
         // each wave walks `chunk` consecutive frames (chunk chosen by the host so that the launch still fills the chip)
         const int64_t tb = ((int64_t)blockIdx.x * 4 + wave) * chunk;
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void stft_dft_kernel(const TIN* __restrict__ x
 // conjugate: ifft(Z) = conj(fft(conj Z)) / M).  S is [bin][T]: a workgroup stages 16 consecutive frames through LDS
 // (one 128-byte run per bin) and its four waves take four frames each.
 constexpr int ISTFT_FR = 8;       // frames staged per workgroup pass: 37 KB + 37 KB of exchange buffers = two workgroups per CU
-__global__ __launch_bounds__(256) void istft1024_frames_kernel(const float2* __restrict__ S, int64_t T, int64_t ldT,
+__global__ __launch_bounds__(256) void istft1024_frames_kernel(const float2* __restrict__ S, int64_t T, int64_t sf, int64_t st,
                                                                const double* __restrict__ window, double* __restrict__ frames) {
     constexpr int M = 512, F = 513, PW = ISTFT_FR / 4;
     __shared__ double lre[4][M + 64], lim[4][M + 64];
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(256) void istft1024_frames_kernel(const float2* __r
         __syncthreads();                                          // the previous block's readers are done with `stage`
         for (int idx = threadIdx.x; idx < F * ISTFT_FR; idx += 256) {
             const int f = idx / ISTFT_FR, q = idx - f * ISTFT_FR;
-            if (q < nq) stage[f * (ISTFT_FR + 1) + q] = S[(int64_t)f * ldT + t0 + q];
+            if (q < nq) stage[f * (ISTFT_FR + 1) + q] = S[(int64_t)f * sf + (t0 + q) * st];
         }
         __syncthreads();
         for (int q = wave * PW; q < (wave + 1) * PW && q < nq; ++q) {
@@ -384,12 +399,13 @@ template <int IF_FR, int NPASS> struct IstftFusedLds {
     static constexpr int R = NPASS * IF_FR, K = R - IF_H;   // frames computed / owned per chunk
     static constexpr int ACC = R * 256 + 768;                  // floats of the output image: frame R - 1 ends at (R - 1) * 256 + 1023
     double ex[4][1152];                                        // per wave: FFT exchange buffers (re: 576, im: 576), then its windowed frame (1024)
-    float2 stage[513][IF_FR + 1];                           // IF_FR frames of S, one (8 * IF_FR)-byte run per bin
+    float2 stage[513 * (IF_FR + 1)];                        // IF_FR frames of S: [bin][IF_FR + 1] (S bin-major, one (8 * IF_FR)-byte run per bin)
+                                                               // or [frame][516] (S frame-major: whole 4104-byte frames, conflict-free readers)
     float acc[ACC];
     float wss4[256];                                           // window sum of squares of a sample covered by four frames, by src mod hop
 };
-template <int IF_FR, int NPASS>
-__global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __restrict__ S, int64_t T, int64_t ldT,
+template <int IF_FR, int NPASS, bool TF>
+__global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __restrict__ S, int64_t T, int64_t ld,
                                                               const double* __restrict__ window, int64_t start,
                                                               float* __restrict__ y, int64_t out_len) {
     typedef IstftFusedLds<IF_FR, NPASS> LT;
@@ -417,21 +433,29 @@ __global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __re
         L.wss4[tid] = w4;
     }
     float2 pre[NPRE];
-    auto request = [&](int64_t ts) __attribute__((always_inline)) {   // eight frames starting at ts (frames outside [0, T): zeros)
+    // staged value idx of a pass -> (bin, frame of the pass): consecutive threads take consecutive frames of a bin when S is
+    // [bin][ld] and consecutive bins of a frame when S is [frame][ld]; `slot`: where (bin, frame) lives in L.stage
+    auto split = [&](int idx, int& f, int& q) __attribute__((always_inline)) {
+        if (TF) { q = idx / F; f = idx - q * F; } else { f = idx / IF_FR; q = idx - f * IF_FR; }
+    };
+    auto slot = [&](int f, int q) __attribute__((always_inline)) { return TF ? q * 516 + f : f * (IF_FR + 1) + q; };
+    auto request = [&](int64_t ts) __attribute__((always_inline)) {   // IF_FR frames starting at ts (frames outside [0, T): zeros)
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int idx = tid + 256 * u;
-            const int f = idx / IF_FR, q = idx - f * IF_FR;
+            int f, q;
+            split(idx, f, q);
             const int64_t t = ts + q;
-            pre[u] = (idx < F * IF_FR && t >= 0 && t < T) ? S[(int64_t)f * ldT + t] : float2{0.f, 0.f};
+            pre[u] = (idx < F * IF_FR && t >= 0 && t < T) ? (TF ? S[t * ld + f] : S[(int64_t)f * ld + t]) : float2{0.f, 0.f};
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) {
             const int idx = tid + 256 * u;
-            const int f = idx / IF_FR, q = idx - f * IF_FR;
-            if (idx < F * IF_FR) L.stage[f][q] = pre[u];
+            int f, q;
+            split(idx, f, q);
+            if (idx < F * IF_FR) L.stage[slot(f, q)] = pre[u];
         }
     };
     if ((int64_t)blockIdx.x < nchunks) request((int64_t)blockIdx.x * IF_K - IF_H);
@@ -455,7 +479,7 @@ __global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __re
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         const int k = lane + 64 * r;
-                        const float2 a = L.stage[k][q], b = L.stage[M - k][q];
+                        const float2 a = L.stage[slot(k, q)], b = L.stage[slot(M - k, q)];
                         cd xk = cd{(double)a.x, (double)a.y}, xc = cd{(double)b.x, -(double)b.y};   // X[k], conj(X[M-k])
                         if (k == 0) { xk.y = 0.0; xc.y = 0.0; }                                      // C2R ignores imag of DC / Nyquist
                         const cd e = cd{0.5 * (xk.x + xc.x), 0.5 * (xk.y + xc.y)};
@@ -516,27 +540,156 @@ __global__ __launch_bounds__(256) void istft1024_fused_kernel(const float2* __re
     }
 }
 
-template <int IF_FR, int NPASS>
-static int launch_istft_fused(const float2* S, int64_t T, int64_t ldT, const double* window, int64_t start, float* y, int64_t out_len, hipStream_t s) {
+// nfft = 1024, hop = 256, S FRAME-major ([T][ld], row t = frame t): the mirror image of the forward kernel's walk.  A frame is one
+// contiguous 4104-byte row, so a wave reads its frame straight into registers (two 512-byte runs per instruction: bins
+// lane + 64 r ascending and 512 - lane - 64 r descending) -- no staging through LDS, no workgroup barrier.  Each wave walks
+// `chunk` consecutive frames plus the three in front of them and keeps the overlap-add IN REGISTERS: after the inverse FFT lane l
+// holds samples 2 l + 128 r + {0, 1} of the frame (r = 0..7), the running float image of the next 1024 output samples lives in
+// the same lanes, and advancing one hop (256 samples) is a shift by two registers.  After frame t has been added, samples
+// [256 t, 256 t + 256) have received all their frames in frame order with one float rounding per addition -- the arithmetic of
+// librosa's `y[...] += ytmp`, of istft_ola_kernel and of the fused kernel above (bit-identical results) -- and leave as 512-byte runs.
+// LDS: the FFT exchange buffers only (9 KB per wave).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void istft1024_walk_kernel(const float2* __restrict__ S, int64_t T, int64_t ld,
+                                                             const double* __restrict__ window, int64_t start,
+                                                             float* __restrict__ y, int64_t out_len, int chunk) {
+    constexpr int M = 512, HOP = 256, NF = 1024;
+    __shared__ double lre[4][M + 64], lim[4][M + 64];
+    // per-bin constants of the whole workgroup in LDS (two waves per SIMD need the kernel under 256 registers):
+    // tw[k] = exp(+2 pi i k / 1024); wn[k] = (window[2 k], -window[2 k + 1]) / M  (conj and 1/M folded into the window)
+    __shared__ double2 tw[M], wn[M];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* re = lre[wave];
+    double* im = lim[wave];
+    for (int k = threadIdx.x; k < M; k += 256) {
+        double sn, cs;
+        sincospi(2.0 * (double)k / 1024.0, &sn, &cs);
+        tw[k] = double2{cs, sn};
+        wn[k] = double2{window[2 * k] * (1.0 / M), -(window[2 * k + 1] * (1.0 / M))};
+    }
+    __syncthreads();                                              // the only workgroup barrier
+    const int64_t nchunks = (T + chunk - 1) / chunk;
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    if (c >= nchunks) return;
+    Fft512 fft;
+    fft.init(lane);
+    // window sum of squares of a sample covered by four frames, at the positions this lane emits (p = 2 lane + 128 j + e within the
+    // hop): frames in ascending order see window positions p + 768, + 512, + 256, + 0; float rounding after every addition
+    float w4[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float w = 0.f;
+#pragma unroll
+            for (int f = 3; f >= 0; --f) { const double ww = window[2 * lane + 128 * j + e + f * HOP]; w = (float)((double)w + ww * ww); }
+            w4[j][e] = w;
+        }
+    const int64_t ntot = (int64_t)NF + (int64_t)HOP * (T - 1);
+    const int64_t t0 = c * chunk;
+    const int64_t te = t0 + chunk < T ? t0 + chunk : T;
+    const bool last = c == nchunks - 1;
+    const int64_t t_emit_end = last ? T + 3 : te;                 // the last chunk also flushes the three hops behind frame T - 1
+    float2 ra[8], rb[8], na[8], nb[8];                            // X[k] and X[512 - k] of the current / the next frame
+    auto fetch = [&](int64_t t, float2 (&a)[8], float2 (&b)[8]) __attribute__((always_inline)) {
+        const float2* row = S + t * ld;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a[r] = row[lane + 64 * r]; b[r] = row[M - lane - 64 * r]; }
+    };
+    float acc[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; }
+    int64_t t = t0 - 3 < 0 ? 0 : t0 - 3;                          // frames in front of the signal do not exist (nothing to add, nothing to emit)
+    if (t < T) fetch(t, ra, rb);
+    for (; t < t_emit_end; ++t) {
+        if (t < T) {
+            if (t + 1 < te) fetch(t + 1, na, nb);                 // in flight under this frame's transform
+            cd v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                cd xk = cd{(double)ra[r].x, (double)ra[r].y}, xc = cd{(double)rb[r].x, -(double)rb[r].y};   // X[k], conj(X[M-k])
+                if (k == 0) { xk.y = 0.0; xc.y = 0.0; }                                                      // C2R ignores imag of DC / Nyquist
+                const cd e = cd{0.5 * (xk.x + xc.x), 0.5 * (xk.y + xc.y)};
+                const double2 w = tw[k];
+                const cd o = cmulc(cd{0.5 * (xk.x - xc.x), 0.5 * (xk.y - xc.y)}, w.x, w.y);
+                v[r] = cd{e.x - o.y, -(e.y + o.x)};               // conj(E + i O)
+            }
+            fft.run(v, re, im, lane);
+            __builtin_amdgcn_wave_barrier();                      // the next frame's first exchange writes come after every lane's last reads
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                // windowed frame values (conj, 1/M folded into the window) as the doubles the other kernels store, then one
+                // float rounding per addition; __dmul_rn / __dadd_rn: never contracted into an fma
+                const double2 w = wn[lane + 64 * r];
+                acc[r][0] = (float)__dadd_rn((double)acc[r][0], __dmul_rn(w.x, v[r].x));
+                acc[r][1] = (float)__dadd_rn((double)acc[r][1], __dmul_rn(w.y, v[r].y));
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ra[r] = na[r]; rb[r] = nb[r]; }
+        }
+        if (t >= t0) {
+            // samples [256 t, 256 t + 256) are complete
+            const bool inner = t >= 3 && t <= T - 1;              // covered by four frames: the window sum depends on the position in the hop only
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float o[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int64_t src = t * HOP + 2 * lane + 128 * j + e;
+                    float a = acc[j][e], wss = 0.f;
+                    if (inner) wss = w4[j][e];
+                    else {
+                        int64_t tlo = (src - NF + HOP) / HOP;
+                        if (src < NF) tlo = 0;
+                        int64_t thi = src / HOP;
+                        if (thi > T - 1) thi = T - 1;
+                        for (int64_t tt = tlo; tt <= thi; ++tt) {
+                            const int m = (int)(src - tt * HOP);
+                            wss = (float)((double)wss + window[m] * window[m]);
+                        }
+                    }
+                    if (wss > FLT_MIN) a = a / wss;
+                    o[e] = a;
+                }
+                const int64_t i = t * HOP + 2 * lane + 128 * j - start;
+                if (i >= 0 && i + 1 < out_len && ((start & 1) == 0)) *reinterpret_cast<float2*>(y + i) = float2{o[0], o[1]};
+                else {
+                    if (i >= 0 && i < out_len) y[i] = o[0];
+                    if (i + 1 >= 0 && i + 1 < out_len) y[i + 1] = o[1];
+                }
+            }
+        }
+        // advance one hop: two registers down, zeros in behind
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { acc[r][0] = acc[r + 2][0]; acc[r][1] = acc[r + 2][1]; }
+        acc[6][0] = acc[6][1] = acc[7][0] = acc[7][1] = 0.f;
+    }
+    if (last)                                                      // behind the signal: zeros up to out_len
+        for (int64_t src = ntot + lane; src < start + out_len; src += 64)
+            if (src >= start) y[src - start] = 0.f;
+}
+
+template <int IF_FR, int NPASS, bool TF>
+static int launch_istft_fused(const float2* S, int64_t T, int64_t ld, const double* window, int64_t start, float* y, int64_t out_len, hipStream_t s) {
     typedef IstftFusedLds<IF_FR, NPASS> LT;
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        DVAE_HIP(hipFuncSetAttribute((const void*)(istft1024_fused_kernel<IF_FR, NPASS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LT)));
+        DVAE_HIP(hipFuncSetAttribute((const void*)(istft1024_fused_kernel<IF_FR, NPASS, TF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LT)));
         attr_done[dev] = true;
     }
     const int64_t nchunks = cdiv(T, LT::K);
     const int per_cu = sizeof(LT) <= 80 * 1024 ? 2 : 1;           // workgroups resident per CU (LDS)
     const int wb = (int)(nchunks < 256 * per_cu ? nchunks : 256 * per_cu);
-    hipLaunchKernelGGL((istft1024_fused_kernel<IF_FR, NPASS>), dim3(wb), dim3(256), sizeof(LT), s, S, T, ldT, window, start, y, out_len);
+    hipLaunchKernelGGL((istft1024_fused_kernel<IF_FR, NPASS, TF>), dim3(wb), dim3(256), sizeof(LT), s, S, T, ld, window, start, y, out_len);
     DVAE_LAUNCH_OK("istft1024_fused_kernel");
     return 0;
 }
 
 // frames[t][m] = window[m] * irfft(S[:, t])[m]   (double scratch)
-__global__ __launch_bounds__(256) void istft_frames_pow2_kernel(const float* __restrict__ S, int64_t T, int64_t ldT,
+__global__ __launch_bounds__(256) void istft_frames_pow2_kernel(const float* __restrict__ S, int64_t T, int64_t sf, int64_t st,
                                                                  const double* __restrict__ window, int nfft, int logM,
                                                                  double* __restrict__ frames) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,8 +702,8 @@ __global__ __launch_bounds__(256) void istft_frames_pow2_kernel(const float* __r
     const double scale = 1.0 / (double)M;
     for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
         for (int k = threadIdx.x; k <= (M >> 1); k += blockDim.x) {
-            cd xk = cd{(double)S[(k * ldT + t) * 2], (double)S[(k * ldT + t) * 2 + 1]};
-            cd xm = cd{(double)S[((int64_t)(M - k) * ldT + t) * 2], (double)S[((int64_t)(M - k) * ldT + t) * 2 + 1]};
+            cd xk = cd{(double)S[(k * sf + t * st) * 2], (double)S[(k * sf + t * st) * 2 + 1]};
+            cd xm = cd{(double)S[((int64_t)(M - k) * sf + t * st) * 2], (double)S[((int64_t)(M - k) * sf + t * st) * 2 + 1]};
             if (k == 0) { xk.y = 0.0; xm.y = 0.0; }              // C2R ignores imag of DC / Nyquist
             const cd xc = cconj(xm);
             const cd e = cd{0.5 * (xk.x + xc.x), 0.5 * (xk.y + xc.y)};
@@ -572,7 +725,7 @@ __global__ __launch_bounds__(256) void istft_frames_pow2_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void istft_frames_dft_kernel(const float* __restrict__ S, int64_t T, int64_t ldT,
+__global__ __launch_bounds__(256) void istft_frames_dft_kernel(const float* __restrict__ S, int64_t T, int64_t sf, int64_t st,
                                                                 const double* __restrict__ window, int nfft,
                                                                 double* __restrict__ frames) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -587,7 +740,7 @@ __global__ __launch_bounds__(256) void istft_frames_dft_kernel(const float* __re
     for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
         __syncthreads();
         for (int f = threadIdx.x; f < F; f += blockDim.x) {
-            cd v = cd{(double)S[(f * ldT + t) * 2], (double)S[(f * ldT + t) * 2 + 1]};
+            cd v = cd{(double)S[(f * sf + t * st) * 2], (double)S[(f * sf + t * st) * 2 + 1]};
             if (f == 0 || (2 * f == nfft)) v.y = 0.0;
             X[f] = v;
         }
@@ -641,7 +794,7 @@ using namespace dvae;
 extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* window, int nfft, int hop,
                          int64_t T, void* out, int layout, void* stream) {
     DVAE_CHECK_ARG(x && window && out && n > 0 && nfft >= 4 && (nfft % 2) == 0 && hop > 0 && T >= 0, "stft: bad argument");
-    DVAE_CHECK_ARG(layout == 0 || layout == 1, "stft: unknown output layout %d", layout);
+    DVAE_CHECK_ARG(layout >= 0 && layout <= 2, "stft: unknown output layout %d", layout);
     DVAE_CHECK_ARG(T == 0 || (T - 1) * (int64_t)hop + nfft <= n, "stft: %lld frames do not fit in %lld samples", (long long)T, (long long)n);
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -649,13 +802,18 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
     const int lg = ilog2_exact(nfft);
     static const bool legacy = getenv("DVAE_STFT_LEGACY") != nullptr;       // A/B switch for the workgroup-per-frame kernel
     if (nfft == 1024 && !legacy) {
-        if (layout == 1) {
+        if (layout != 0) {
             // one round of waves: 256 CUs x 4 SIMDs x 2 resident waves = 2048 slots; a wave takes ceil(T / 2048) frames
             int chunk = (int)cdiv(T, 2048);
             chunk = chunk < 1 ? 1 : chunk;
             const int wb = (int)cdiv(T, (int64_t)4 * chunk);
-            if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, chunk, out);
-            else hipLaunchKernelGGL((stft1024_kernel<float, 1>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, chunk, out);
+            if (layout == 1) {
+                if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, chunk, out);
+                else hipLaunchKernelGGL((stft1024_kernel<float, 1>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, chunk, out);
+            } else {
+                if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 2>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, chunk, out);
+                else hipLaunchKernelGGL((stft1024_kernel<float, 2>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, chunk, out);
+            }
         } else {
             const int wb = (int)(cdiv(T, STFT_FR) < 2048 ? cdiv(T, STFT_FR) : 2048);
             const size_t lds = (size_t)513 * (STFT_FR + 1) * sizeof(float2);
@@ -696,12 +854,15 @@ extern "C" size_t dvae_istft_workspace_bytes_hop(int64_t T, int nfft, int hop) {
     return dvae_istft_workspace_bytes(T, nfft);
 }
 
-extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,
-                          int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
-    DVAE_CHECK_ARG(S && window && y && ws && T > 0 && ldT >= T && nfft >= 4 && (nfft % 2) == 0 && hop > 0 && start >= 0 && out_len >= 0,
+// S(bin f, frame t) = S[f * ld + t] (tf = false: bin-major, ld >= T) or S[t * ld + f] (tf = true: frame-major, ld >= nfft / 2 + 1)
+static int istft_run(const void* S, int64_t T, int64_t ld, bool tf, const double* window, int nfft, int hop,
+                     int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
+    DVAE_CHECK_ARG(S && window && y && ws && T > 0 && nfft >= 4 && (nfft % 2) == 0 && hop > 0 && start >= 0 && out_len >= 0,
                    "istft: bad argument");
+    DVAE_CHECK_ARG(ld >= (tf ? (int64_t)(nfft / 2 + 1) : T), "istft: leading dimension %lld too small", (long long)ld);
     DVAE_CHECK_ARG(nfft <= 2048, "istft: window length %d not supported (max 2048)", nfft);
     hipStream_t s = (hipStream_t)stream;
+    const int64_t sf = tf ? 1 : ld, st = tf ? ld : 1;
     const int blocks = (int)(T < 2048 ? T : 2048);
     const int lg = ilog2_exact(nfft);
     static const bool legacy = getenv("DVAE_STFT_LEGACY") != nullptr;
@@ -710,9 +871,24 @@ extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* w
         if (out_len == 0) return 0;
         // chunk size by length: enough chunks to cover the CUs first, then the least halo work (3 of 8 / 16 / 32 frames)
         // chunk size by length: enough chunks to cover the CUs first, then wider runs per bin and less halo work (3 of 8 / 16 / 32 frames)
-        if (T <= 5 * 512) return launch_istft_fused<8, 1>((const float2*)S, T, ldT, window, start, y, out_len, s);
-        if (T <= 13 * 512) return launch_istft_fused<16, 1>((const float2*)S, T, ldT, window, start, y, out_len, s);
-        return launch_istft_fused<16, 2>((const float2*)S, T, ldT, window, start, y, out_len, s);
+        if (tf && getenv("DVAE_ISTFT_STAGED") == nullptr) {                  // A/B switch (read per call): frame-major input through the staged kernel
+            // one round of waves (2048 slots, as the forward transform): the shortest walk per wave, ceil(T / 2048) own frames + 3 halo
+            // frames (short utterances: 4 transforms for 1 own frame, all waves side by side -- 12 us at 309 frames against 19 us with 4 own)
+            int chunk = (int)cdiv(T, 2048);
+            chunk = chunk < 1 ? 1 : chunk;
+            const int wb = (int)cdiv(cdiv(T, chunk), 4);
+            hipLaunchKernelGGL(istft1024_walk_kernel, dim3(wb), dim3(256), 0, s, (const float2*)S, T, ld, window, start, y, out_len, chunk);
+            DVAE_LAUNCH_OK("istft1024_walk_kernel");
+            return 0;
+        }
+        if (tf) {
+            if (T <= 5 * 512) return launch_istft_fused<8, 1, true>((const float2*)S, T, ld, window, start, y, out_len, s);
+            if (T <= 13 * 512) return launch_istft_fused<16, 1, true>((const float2*)S, T, ld, window, start, y, out_len, s);
+            return launch_istft_fused<16, 2, true>((const float2*)S, T, ld, window, start, y, out_len, s);
+        }
+        if (T <= 5 * 512) return launch_istft_fused<8, 1, false>((const float2*)S, T, ld, window, start, y, out_len, s);
+        if (T <= 13 * 512) return launch_istft_fused<16, 1, false>((const float2*)S, T, ld, window, start, y, out_len, s);
+        return launch_istft_fused<16, 2, false>((const float2*)S, T, ld, window, start, y, out_len, s);
     }
     if (nfft == 1024 && !legacy) {
         const size_t lds = (size_t)513 * (ISTFT_FR + 1) * sizeof(float2);
@@ -722,13 +898,13 @@ extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* w
             attr_done = true;
         }
         const int wb = (int)(cdiv(T, ISTFT_FR) < 4096 ? cdiv(T, ISTFT_FR) : 4096);
-        hipLaunchKernelGGL(istft1024_frames_kernel, dim3(wb), dim3(256), lds, s, (const float2*)S, T, ldT, window, (double*)ws);
+        hipLaunchKernelGGL(istft1024_frames_kernel, dim3(wb), dim3(256), lds, s, (const float2*)S, T, sf, st, window, (double*)ws);
     } else if (lg >= 3) {
         const size_t lds = (size_t)(nfft / 2) * 2 * sizeof(cd) + (size_t)nfft * sizeof(double);
-        hipLaunchKernelGGL(istft_frames_pow2_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, ldT, window, nfft, lg - 1, (double*)ws);
+        hipLaunchKernelGGL(istft_frames_pow2_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, sf, st, window, nfft, lg - 1, (double*)ws);
     } else {
         const size_t lds = (size_t)nfft * sizeof(cd) + (size_t)(nfft / 2 + 1) * sizeof(cd);
-        hipLaunchKernelGGL(istft_frames_dft_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, ldT, window, nfft, (double*)ws);
+        hipLaunchKernelGGL(istft_frames_dft_kernel, dim3(blocks), dim3(256), lds, s, (const float*)S, T, sf, st, window, nfft, (double*)ws);
     }
     DVAE_LAUNCH_OK("istft_frames");
     if (out_len == 0) return 0;
@@ -736,4 +912,14 @@ extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* w
     hipLaunchKernelGGL(istft_ola_kernel, dim3(ob), dim3(256), 0, s, (const double*)ws, window, T, nfft, hop, start, y, out_len);
     DVAE_LAUNCH_OK("istft_ola");
     return 0;
+}
+
+extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,
+                          int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
+    return istft_run(S, T, ldT, false, window, nfft, hop, start, y, out_len, ws, stream);
+}
+
+extern "C" int dvae_istft_frames(const void* S, int64_t T, int64_t ldF, const double* window, int nfft, int hop,
+                                 int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
+    return istft_run(S, T, ldF, true, window, nfft, hop, start, y, out_len, ws, stream);
 }

@@ -57,7 +57,8 @@ def _device():
 
 def stft_device(x_dev, window, nfft, hop, T, layout=0):
     """x_dev: 1-D float32/float64 CUDA tensor already padded.  layout 0 -> complex64 [F, T];
-    layout 1 -> float32 power frames [T, F]."""
+    layout 1 -> float32 power frames [T, F]; layout 2 -> complex64 [T, F] (frame-major: the values of layout 0 in the memory
+    order of librosa's Fortran-ordered result; `.T` of it is the reference's array, strides included)."""
     lib = N.load()
     if not x_dev.is_cuda or x_dev.dim() != 1 or x_dev.dtype not in (torch.float32, torch.float64):
         raise TypeError("stft_device: 1-D float32/float64 CUDA tensor required")
@@ -65,6 +66,8 @@ def stft_device(x_dev, window, nfft, hop, T, layout=0):
     F = nfft // 2 + 1
     if layout == 0:
         out = torch.empty((F, T), dtype=torch.complex64, device=x_dev.device)
+    elif layout == 2:
+        out = torch.empty((T, F), dtype=torch.complex64, device=x_dev.device)
     else:
         out = torch.empty((T, F), dtype=torch.float32, device=x_dev.device)
     N.check(lib.dvae_stft(N.ptr(x_dev), 1 if x_dev.dtype == torch.float64 else 0, x_dev.numel(), N.ptr(window), nfft, hop, T,
@@ -73,13 +76,19 @@ def stft_device(x_dev, window, nfft, hop, T, layout=0):
 
 
 def istft_device(S_dev, window, nfft, hop, n_frames, start, out_len):
-    """S_dev: complex64 [F, >= n_frames] CUDA tensor -> float32 [out_len]."""
+    """S_dev: complex64 [F, >= n_frames] CUDA tensor -> float32 [out_len].  A tensor whose memory is frame-major (the `.T` view of
+    a contiguous [T, F] tensor, e.g. of stft_device(..., layout=2)) is read in place by the frame-major kernel; anything else is
+    made row-contiguous first."""
     lib = N.load()
     if not S_dev.is_cuda or S_dev.dtype != torch.complex64 or S_dev.dim() != 2 or S_dev.shape[0] != nfft // 2 + 1:
         raise TypeError("istft_device: complex64 [nfft/2+1, T] CUDA tensor required")
-    S_dev = S_dev.contiguous()
     y = torch.empty((out_len,), dtype=torch.float32, device=S_dev.device)
     ws = torch.empty(max(lib.dvae_istft_workspace_bytes_hop(n_frames, nfft, hop), 16), dtype=torch.uint8, device=S_dev.device)
+    if S_dev.shape[1] > 1 and S_dev.stride(0) == 1 and S_dev.stride(1) >= S_dev.shape[0]:
+        N.check(lib.dvae_istft_frames(N.ptr(S_dev), n_frames, S_dev.stride(1), N.ptr(window), nfft, hop, start, N.ptr(y), out_len,
+                                      N.ptr(ws), N.stream()), "dvae_istft_frames")
+        return y
+    S_dev = S_dev.contiguous()
     N.check(lib.dvae_istft(N.ptr(S_dev), n_frames, S_dev.shape[1], N.ptr(window), nfft, hop, start, N.ptr(y), out_len,
                            N.ptr(ws), N.stream()), "dvae_istft")
     return y
@@ -100,10 +109,14 @@ def stft_numpy(x, fs, wlen_sec, win, hop_percent, center, pad_mode, pad_at_end, 
     T = frame_count(len(x_), nfft, hop)
     dev = _device()
     xin = np.ascontiguousarray(x_, dtype=np.float64 if x_.dtype != np.float32 else np.float32)
-    out = stft_device(torch.from_numpy(xin).to(dev), window_f64(win, nfft, dev), nfft, hop, T, layout)
+    # the complex result is computed frame-major (whole frames leave the kernel as contiguous rows) and returned as the
+    # transpose view: a Fortran-ordered [F, T] array, which is also what librosa.stft hands the reference
+    out = stft_device(torch.from_numpy(xin).to(dev), window_f64(win, nfft, dev), nfft, hop, T, 2 if layout == 0 else layout)
     res = out.cpu().numpy()
-    if layout == 0 and np.dtype(dtype) != res.dtype:
-        res = res.astype(dtype)
+    if layout == 0:
+        res = res.T
+        if np.dtype(dtype) != res.dtype:
+            res = res.astype(dtype)
     return res
 
 
@@ -124,7 +137,9 @@ def istft_numpy(Sxx, fs, wlen_sec, win, hop_percent, center, dtype, max_len):
     else:
         out_len = int(max_len)
     dev = _device()
-    S_dev = torch.from_numpy(np.ascontiguousarray(S, dtype=np.complex64)).to(dev)
+    # frame-major on the device (each frame one contiguous row): free for a Fortran-ordered S (what stft() returns), one host
+    # transpose for a C-ordered one
+    S_dev = torch.from_numpy(np.ascontiguousarray(S.T, dtype=np.complex64)).to(dev).T
     y = istft_device(S_dev, window_f64(win, nfft, dev), nfft, hop, n_frames, start, out_len).cpu().numpy()
     if np.dtype(dtype) != y.dtype:
         y = y.astype(dtype)

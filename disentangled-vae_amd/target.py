@@ -65,10 +65,8 @@ def utterance_to_frames(speech, labels="vad_labels", fs=16000, wlen_sec=64e-3, h
     if labels == "vad_labels":
         Y = vad_labels(x, nfft, hop, T, vad_threshold)[:, None]
     elif labels == "ibm_labels":
-        S = H.stft_device(x, w, nfft, hop, T, 0)                         # complex (F, T)
-        m = ibm_labels(S, eps, ibm_threshold)
-        Y = torch.empty((T, m.shape[0]), dtype=torch.float32, device=x.device)
-        N.check(lib.dvae_transpose(N.ptr(m), m.shape[0], T, T, N.ptr(Y), m.shape[0], N.stream()), "dvae_transpose")
+        # the mask is elementwise against the global peak: computed on the frame-major complex frames it IS the [T, 513] label rows
+        Y = ibm_labels(H.stft_device(x, w, nfft, hop, T, 2), eps, ibm_threshold)
     else:
         raise ValueError(labels)
     return X, Y

@@ -147,7 +147,10 @@ int dvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doub
  *      same bytes are the legacy torch.stft real view [nfft/2+1, T, 2] of stft_pytorch,
  *      packages/processing/stft.py:145-151);
  *      layout 1 = [T, nfft/2+1] float32 power |.|^2 (one training frame per row,
- *      scripts/create_train_set.py:152 / scripts/reconstruct_M2.py:153).
+ *      scripts/create_train_set.py:152 / scripts/reconstruct_M2.py:153);
+ *      layout 2 = [T, nfft/2+1] interleaved complex64 (row = frame): the values of layout 0 in the MEMORY order of
+ *      librosa's result (librosa.stft fills a Fortran-ordered [nfft/2+1, T] array, packages/processing/stft.py:50-57);
+ *      the host returns its transpose view, so the caller sees the reference's shape and strides.
  * window: nfft doubles (device).  Power-of-two nfft in [8, 2048] runs the LDS FFT; any other
  * even nfft <= 2048 (e.g. the wrapper's never-used 800-sample default) runs a plain DFT. */
 int dvae_stft(const void* x, int in_f64, int64_t n, const double* window, int nfft, int hop,
@@ -163,6 +166,11 @@ size_t dvae_istft_workspace_bytes(int64_t T, int nfft);
 size_t dvae_istft_workspace_bytes_hop(int64_t T, int nfft, int hop);
 int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,
                int64_t start, float* y, int64_t out_len, void* ws, void* stream);
+/* The same transform of a FRAME-major spectrogram: S complex64 [T, ldF], row t = frame t (its first nfft/2+1 entries) -- the
+ * memory order of a Fortran-ordered [nfft/2+1, T] array such as librosa.stft / dvae_stft layout 2 return.  Results are
+ * bit-identical to dvae_istft on the transposed array (packages/processing/stft.py:63-99). */
+int dvae_istft_frames(const void* S, int64_t T, int64_t ldF, const double* window, int nfft, int hop,
+                      int64_t start, float* y, int64_t out_len, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused train step (the build's own harness; mirrors scripts/training_M1.py:134-139,

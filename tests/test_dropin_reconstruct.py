@@ -102,11 +102,12 @@ def test_reconstruct_M2_runs_unchanged(tmp_path, monkeypatch):
     def stft_cpu(x_dev, window, nfft, hop, T, layout=0):
         calls["stft"] += 1
         x = x_dev.numpy().astype(np.float64)
-        assert x.ndim == 1 and layout == 0 and window.dtype == torch.float64 and window.numel() == nfft
+        assert x.ndim == 1 and layout in (0, 2) and window.dtype == torch.float64 and window.numel() == nfft
         idx = np.arange(nfft)[:, None] + hop * np.arange(T)[None, :]
         S = np.fft.rfft(window.numpy()[:, None] * x[idx], axis=0)
         assert 1 + (x.size - nfft) // hop == T
-        return torch.from_numpy(S.astype(np.complex64))
+        S = S.astype(np.complex64)
+        return torch.from_numpy(np.ascontiguousarray(S.T if layout == 2 else S))   # layout 2: frame-major [T, F]
     monkeypatch.setattr(H, "stft_device", stft_cpu)
 
     def istft_cpu(S_dev, window, nfft, hop, n_frames, start, out_len):

@@ -168,3 +168,68 @@ def test_istft_fused_overlap_add_equals_two_pass_bitwise(n, center):
             del os.environ["DVAE_ISTFT_2PASS"]
         assert fused.shape == two.shape and fused.dtype == two.dtype == np.float32
         assert np.array_equal(fused.view(np.uint32), two.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,dtype,wlen", [(1024, np.float64, 64e-3), (73045, np.float32, 64e-3), (16000 * 140 + 11, np.float64, 64e-3),
+                                          (20000, np.float64, 32e-3), (20000, np.float32, 50e-3)])
+def test_frame_major_complex_layout_is_the_bin_major_one_transposed(n, dtype, wlen):
+    """dvae_stft layout 2 ([T, F] complex64, what stft() now computes) holds the very values of layout 0 ([F, T]); stft() returns
+    its transpose view: the reference's shape with the memory order of librosa's Fortran-ordered result
+    (packages/processing/stft.py:50-57).  Covers the one-wave-per-frame kernel (1024) with one and several frames per wave and
+    the generic power-of-two (512) and plain-DFT (800) kernels."""
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(dtype)
+    nfft, hop = H.sizes(16000, wlen, 0.25)
+    pad = hop if H.needs_end_pad(n, 16000, wlen, 0.25) else 0
+    xd = torch.from_numpy(np.pad(x, (0, pad))).cuda()
+    T = H.frame_count(n + pad, nfft, hop)
+    w = H.window_f64("hann", nfft, xd.device)
+    a = H.stft_device(xd, w, nfft, hop, T, 0)
+    b = H.stft_device(xd, w, nfft, hop, T, 2)
+    assert a.shape == (nfft // 2 + 1, T) and b.shape == (T, nfft // 2 + 1)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b.T.contiguous()))
+    got = ps.stft(x, fs=16000, wlen_sec=wlen, hop_percent=0.25, center=False)
+    assert got.shape == a.shape and got.dtype == np.complex64 and got.flags.f_contiguous
+    assert np.array_equal(np.ascontiguousarray(got).view(np.float32), a.cpu().numpy().view(np.float32))
+
+
+@pytest.mark.parametrize("T", [1, 5, 300, 2560, 2561, 6656, 6657, 9000])
+def test_istft_of_frame_major_input_equals_bin_major_bitwise(T):
+    """dvae_istft_frames (S as [T, ld] rows, whole frames staged per load) against dvae_istft (S as [513, T]) on the same values:
+    identical bits for every chunk size the host picks (T <= 2560: 8-frame passes, <= 6656: 16, above: 2 x 16), a padded row
+    stride, and through the numpy wrapper for C- and Fortran-ordered spectrograms."""
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    rng = np.random.default_rng(T)
+    S = (rng.standard_normal((513, T)) + 1j * rng.standard_normal((513, T))).astype(np.complex64)
+    w = H.window_f64("hann", 1024, torch.device("cuda", 0))
+    ntot = 1024 + 256 * (T - 1)
+    S_ft = torch.from_numpy(S).cuda()                                       # [513, T] row-contiguous: the bin-major kernel
+    assert S_ft.stride(1) == 1 or T == 1
+    ref = H.istft_device(S_ft, w, 1024, 256, T, 0, ntot + 300)
+    rows = torch.from_numpy(np.ascontiguousarray(S.T)).cuda()              # [T, 513]
+    got = H.istft_device(rows.T, w, 1024, 256, T, 0, ntot + 300)                  # register-resident walk (one wave per run of frames)
+    os.environ["DVAE_ISTFT_STAGED"] = "1"
+    try:
+        got_staged = H.istft_device(rows.T, w, 1024, 256, T, 0, ntot + 300)       # the LDS-staged kernel reading frame-major rows
+    finally:
+        del os.environ["DVAE_ISTFT_STAGED"]
+    wide = torch.zeros((T, 520), dtype=torch.complex64, device="cuda")
+    wide[:, :513] = rows
+    got_wide = H.istft_device(wide[:, :513].T, w, 1024, 256, T, 0, ntot + 300)
+    if T > 1:
+        assert rows.T.stride(0) == 1 and wide[:, :513].T.stride(1) == 520
+        assert torch.equal(ref.view(torch.int32), got.view(torch.int32))
+        assert torch.equal(ref.view(torch.int32), got_wide.view(torch.int32))
+        assert torch.equal(ref.view(torch.int32), got_staged.view(torch.int32))
+        for st, ln in ((512, ntot - 1024), (512, 777), (0, 1), (300, ntot)):     # centre trim, odd lengths, a start inside the first hop
+            r2 = H.istft_device(S_ft, w, 1024, 256, T, st, ln)
+            g2 = H.istft_device(rows.T, w, 1024, 256, T, st, ln)
+            assert torch.equal(r2.view(torch.int32), g2.view(torch.int32))
+    kw = dict(fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=False)
+    y_c = ps.istft(S, **kw)
+    y_f = ps.istft(np.asfortranarray(S), **kw)
+    assert np.array_equal(y_c.view(np.uint32), y_f.view(np.uint32))
+    assert np.array_equal(y_c.view(np.uint32), ref[:ntot].cpu().numpy().view(np.uint32))

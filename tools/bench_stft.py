@@ -20,12 +20,16 @@ def main():
         x = torch.randn(n, dtype=dt, device=dev)
         T = H.frame_count(n, 1024, 256)
         w = H.window_f64("hann", 1024, dev)
-        t_c = timeit(lambda: H.stft_device(x, w, 1024, 256, T, 0))
+        t_c = timeit(lambda: H.stft_device(x, w, 1024, 256, T, 2))           # frame-major complex (the drop-in's stft())
+        t_c0 = timeit(lambda: H.stft_device(x, w, 1024, 256, T, 0))          # bin-major complex (stft_pytorch)
         t_p = timeit(lambda: H.stft_device(x, w, 1024, 256, T, 1))
         S = H.stft_device(x, w, 1024, 256, T, 0)
-        t_i = timeit(lambda: H.istft_device(S, w, 1024, 256, T, 0, n))
+        Sr = H.stft_device(x, w, 1024, 256, T, 2).T
+        t_i = timeit(lambda: H.istft_device(Sr, w, 1024, 256, T, 0, n))
+        t_i0 = timeit(lambda: H.istft_device(S, w, 1024, 256, T, 0, n))
         inb = 256 * x.element_size()
-        res[f"{secs}s_{str(dt).split('.')[-1]}"] = dict(frames=T, stft_us=t_c * 1e6, stft_power_us=t_p * 1e6, istft_us=t_i * 1e6,
+        res[f"{secs}s_{str(dt).split('.')[-1]}"] = dict(frames=T, stft_us=t_c * 1e6, stft_bin_major_us=t_c0 * 1e6, stft_power_us=t_p * 1e6,
+            istft_us=t_i * 1e6, istft_bin_major_us=t_i0 * 1e6,
             stft_Mframes_s=T / t_c / 1e6, stft_GBs=T * (inb + 4104) / t_c / 1e9, istft_Mframes_s=T / t_i / 1e6,
             istft_GBs=T * (4104 + 1024) / t_i / 1e9)
     xs = np.random.default_rng(0).standard_normal(16000 * 60)
