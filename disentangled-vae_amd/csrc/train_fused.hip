@@ -22,6 +22,8 @@
 // (deterministic: no atomics anywhere).  Bias gradients ride along as one extra MFMA against a
 // constant-one fragment.
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -905,6 +907,7 @@ struct Block4 {
     // input matrix (the rows kernel then writes no stash for them); blocks never mix input tiles with stash tiles
     int32_t raw, rncols;     // rncols: columns of the input matrix (513 / y_dim)
     int32_t rcol[4];         // first column of B tile j in the input matrix
+    int32_t wt[4], bt[4], wt_hi, bt_hi;   // tensor numbers of A tile i's weight / bias rows (and of the rows >= 16 of a split tile): fold_tail
 };
 
 template <int I, int N, typename F>
@@ -918,6 +921,15 @@ __device__ __forceinline__ void static_for_w(F&& f) {
 #ifndef W4_SLAB_AUX
 #define W4_SLAB_AUX 16
 #endif
+// the ragged-tile and bias stores of the slabs: write-through like the full-tile buffer stores (the folded optimizer tail reads the
+// slabs of other workgroups of the same launch and relies on every slab store being one)
+__device__ __forceinline__ void slab_store(float* p, float v) {
+#if W4_SLAB_AUX
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
 template <typename P> struct Wg4 {
 #ifndef DVAE_W4RING_X3
 #define DVAE_W4RING_X3 3
@@ -1207,7 +1219,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
                     const bool hi = split && row >= 16;
                     const int rr = hi ? row - 16 : row;
                     const int ld = hi ? bd.ldo_hi : ldo;
-                    slab[(hi ? bd.a_off_hi : a_off) + (int64_t)rr * ld + bd.bcol[j] + l31] = c[0][j][r];
+                    slab_store(&slab[(hi ? bd.a_off_hi : a_off) + (int64_t)rr * ld + bd.bcol[j] + l31], c[0][j][r]);
                 }
             }
         }
@@ -1215,14 +1227,240 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
     const float tot = bs[0] + __shfl_xor(bs[0], 32, 64);                  // the two frame halves of feature row l31
     if (h == 0 && l31 < mv && bias_off >= 0) {
         const bool hi = split && l31 >= 16;
-        slab[hi ? bd.bias_off_hi + (l31 - 16) : bias_off + l31] = tot;
+        slab_store(&slab[hi ? bd.bias_off_hi + (l31 - 16) : bias_off + l31], tot);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct TensorDesc {
+    int64_t off;          // float offset in the flat parameter buffer
+    int32_t rows, cols;
+    // kernel-layout ("fragment-major") copies: element (row, col) of a [rows][ns * KSTEP] matrix sits at
+    //   off + (((col / KSTEP) * nt + row / 32) * 64 + ((col % KSTEP) / E) * 32 + row % 32) * E + col % E      (nt = row tiles)
+    int64_t sf_off;       // forward copy (A operand of the layer), -1 = none
+    int32_t sf_nt, sf_split, sf_gap, sf_roff;   // column c -> c (c < split) or c + gap; row r -> r + roff
+    int32_t sf_ld, st_ld;                       // row strides of the row-major variant (WFRAG == false)
+    int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
+    int32_t st_nt, st_roff, st_cmax, pad1;      // element (r, c < cmax) -> row c, column r + roff
+};
+
+struct ApplyArgs {
+    float* p; float* m; float* v;
+    const float* slabs; int64_t slab_stride; int nslabs;
+    const TensorDesc* tensors; int ntensors;
+    const unsigned char* chunk_tensor; int64_t n_params;
+    void* wcopy; int64_t wpl;      // kernel-layout weight copies; elements between the hi and lo planes (NP == 2)
+    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
+    const double* partials; int npartials; int64_t B; float* losses3; double* accum;
+    int info; float alpha, beta, gamma;
+};
+
+
+// Adam update of parameter idx (gradient gi = the fixed-order slab sum) and the refresh of its kernel-layout weight copies: the one
+// definition behind apply_kernel and the folded tail of wgrad4_kernel (bit-identical by construction).
+template <typename T, bool ADAM, int NP>
+__device__ __forceinline__ void apply_element(const ApplyArgs& g, int64_t idx, const TensorDesc& d, float pi, float m_old, float v_old, float gi) {
+    const int64_t i = idx - d.off;
+    if (i >= (int64_t)d.rows * d.cols) return;
+    T* wc = (T*)g.wcopy;
+    if (ADAM) {
+        gi *= g.gscale;
+        const float mi = m_old + g.one_minus_b1 * (gi - m_old);
+        const float vi = v_old * g.b2 + g.one_minus_b2 * (gi * gi);
+        const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
+        pi = pi - g.step_size * (mi / denom);
+        g.p[idx] = pi; g.m[idx] = mi; g.v[idx] = vi;
+    }
+    const int r = (int)((unsigned)i / (unsigned)d.cols), c = (int)i - r * d.cols;      // a tensor holds far fewer than 2^31 elements
+    constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
+    if (d.sf_off >= 0) {
+        const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
+        const int64_t o = WFRAG ? d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
+                                : d.sf_off + (int64_t)rr * d.sf_ld + cc;
+        const T ph = (T)pi;
+        wc[o] = ph;
+        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
+    }
+    if (d.st_off >= 0 && c < d.st_cmax) {
+        const int rr = c, cc = r + d.st_roff;
+        const int64_t o = WFRAG ? d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
+                                : d.st_off + (int64_t)rr * d.st_ld + cc;
+        const T ph = (T)pi;
+        wc[o] = ph;
+        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
+    }
+}
+
+// loss scalars from the rows kernel's per-workgroup partial sums (one workgroup; every thread calls)
+__device__ __forceinline__ void finalize_losses(const ApplyArgs& g, double (*red)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0.0, k = 0.0, c = 0.0, x = 0.0;
+    for (int i = threadIdx.x; i < g.npartials; i += 256) {
+        a += g.partials[4 * i]; k += g.partials[4 * i + 1]; c += g.partials[4 * i + 2]; x += g.partials[4 * i + 3];
+    }
+    a = wave_sum(a); k = wave_sum(k); c = wave_sum(c); x = wave_sum(x);
+    if (lane == 0) { red[wave][0] = a; red[wave][1] = k; red[wave][2] = c; red[wave][3] = x; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float recon = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)g.B);
+        const float kl = (float)((red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (double)g.B);
+        g.losses3[0] = recon + kl; g.losses3[1] = recon; g.losses3[2] = kl;
+        if (g.accum) { g.accum[0] += (double)(recon + kl); g.accum[1] += (double)recon; g.accum[2] += (double)kl; }
+        if (g.info) {   // scripts/training_M2_info_vad.py:162-183
+            const float bc = (float)((red[0][2] + red[1][2] + red[2][2] + red[3][2]) / (double)g.B);
+            const float ba = (float)((red[0][3] + red[1][3] + red[2][3] + red[3][3]) / (double)g.B);
+            const float classif = g.alpha * bc, aux_enc = g.beta * ba;
+            g.losses3[3] = (recon + kl) + classif - aux_enc;      // enc_loss
+            g.losses3[4] = classif;
+            g.losses3[5] = g.gamma * ba;                          // aux_loss
+            g.losses3[6] = aux_enc;
+            g.losses3[7] = 0.f;
+            if (g.accum) for (int q = 3; q < 8; ++q) g.accum[q] += (double)g.losses3[q];
+        }
+    }
+}
+
+// sum of the gradient slabs at flat index idx: every load issued before the first addition, additions in slab order (deterministic)
+// COH: the slabs were written by other workgroups of THIS launch (write-through stores): device-coherent loads (sc1), which do not
+// look at this XCD's L2 lines
+template <bool COH = false>
+__device__ __forceinline__ float slab_sum_at(const ApplyArgs& g, int64_t idx) {
+    auto ld = [&](int64_t o) __attribute__((always_inline)) {
+        if constexpr (COH) return __hip_atomic_load(g.slabs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return g.slabs[o];
+    };
+    auto sum_slabs = [&](auto nsc) __attribute__((always_inline)) {
+        constexpr int NS = decltype(nsc)::value;
+        float part[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) part[k] = ld((k < g.nslabs ? k : 0) * g.slab_stride + idx);   // independent loads
+        float t = part[0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) if (k < g.nslabs) t += part[k];                                    // fixed order: deterministic
+        return t;
+    };
+    if (g.nslabs <= 8) return sum_slabs(std::integral_constant<int, 8>{});
+    if (g.nslabs <= 12) return sum_slabs(std::integral_constant<int, 12>{});
+    if (g.nslabs <= 16) return sum_slabs(std::integral_constant<int, 16>{});
+    float gi = ld(idx);
+    for (int k = 1; k < g.nslabs; ++k) gi += ld(k * g.slab_stride + idx);
+    return gi;
+}
+
+// ---- the optimizer step folded into the tail of the weight-gradient kernel (a train step = two launches).
+// Every (slice, block) workgroup, once its partial block is in its slab, arrives at the block's counter and waits until all `ksplit`
+// slices of the block have arrived (the grid is one round of workgroups, all resident: the host folds only when the grid fits the CUs;
+// the wait is bounded and raises the error word instead of hanging).  Then the ksplit * 4 waves share the block's parameters: a wave
+// takes whole tensor rows (row u of the block's 128, u = wave id, + ksplit * 4, ...; units 128-131: the bias rows), a lane two elements
+// of a row; each element = the slab sum in slab order (the very additions of apply_kernel), Adam, the weight-copy refresh.  Workgroup 0
+// also turns the rows kernel's partial sums into the loss scalars.
+// Counters (unsigned words of the flag header): [2] error (sticky), [16 + b] arrivals of block b -- never reset: launch number n of a
+// workspace (counted by the host, fold_seq) waits for ksplit * n.  One fire-and-forget atomic and the polling loads are all the
+// synchronisation a workgroup pays (returning atomics cost a device-scope round trip each: 2 us on the critical path).
+constexpr int FOLD_MAXB = 120;
+struct FoldArgs { unsigned* cnt; unsigned target; unsigned max_polls; };
+
+template <typename T, int NP>
+__device__ __forceinline__ void fold_tail(const ApplyArgs& g, const FoldArgs& fa, const Block4& bd, const Block4* __restrict__ bdg, int bi, int slice,
+                                          int ks, int lane, int wave, char* wsm) {
+    int* const flag = reinterpret_cast<int*>(wsm);                     // the reduce-scatter is over: the exchange slots are free
+    // This wave's slab stores are complete, i.e. visible device-wide: they are write-through (sc1) stores, so waiting for them is
+    // enough.  (A release fence writes back the XCD's whole L2 and the matching acquire invalidates it -- 960 times per launch: the
+    // kernel took 75 us instead of 28.)
+#if W4_SLAB_AUX
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(fa.cnt + 16 + bi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned polls = 0;
+        int ok = 1;
+        while ((int)(__hip_atomic_load(fa.cnt + 16 + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fa.target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > fa.max_polls) { ok = 0; break; }
+        }
+        if (!ok) __hip_atomic_store(fa.cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = ok;
+    }
+    __syncthreads();
+    const int ok = flag[0];
+#if !W4_SLAB_AUX
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+#ifndef FOLD_DIAG
+#define FOLD_DIAG 0      // timing diagnostics (wrong results): 1 = wait only, 2 = wait + loads + stores of p only, 3 = no loss scalars
+#endif
+    if (ok && FOLD_DIAG != 1) {
+        int nb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (bd.Bt[k] != nullptr) nb = k + 1;
+        const int gw = slice * 4 + wave, nw = ks * 4;
+        constexpr int UB = 4;                                          // units per batch: their loads are all in flight together
+        for (int u0 = gw; u0 < 132; u0 += UB * nw) {
+            int64_t idx[UB][2];
+            float pi[UB][2], mo[UB][2], vo[UB][2], gi[UB][2];
+            int tq[UB][2];                                             // wave-uniform: a unit is a row of ONE tensor (two for the heads' bias unit: one per q)
+#pragma unroll
+            for (int b = 0; b < UB; ++b) {
+                const int u = u0 + b * nw;                             // wave-uniform
+                idx[b][0] = idx[b][1] = -1;
+                tq[b][0] = tq[b][1] = 0;
+                if (u < 128) {
+                    const int rot = u >> 5, rr = u & 31;
+                    if (rr < bdg->mvalid[rot]) {
+                        const bool hi = rot == 0 && bd.split16 && rr >= 16;
+                        const int64_t base = hi ? bd.a_off_hi + (int64_t)(rr - 16) * bd.ldo_hi : bdg->a_off[rot] + (int64_t)rr * bdg->ldo[rot];
+                        tq[b][0] = tq[b][1] = hi ? bd.wt_hi : bdg->wt[rot];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int j = (lane >> 5) + 2 * q, l = lane & 31;     // columns lane and lane + 64 of the block's 128
+                            if (j < nb && l < bdg->nvalid[j]) idx[b][q] = base + bdg->bcol[j] + l;
+                        }
+                    }
+                } else if (u < 132) {
+                    const int rot = u - 128;
+                    const int64_t bo = bdg->bias_off[rot];
+                    const int mv = bdg->mvalid[rot];
+                    if (bo >= 0) {
+                        const bool split = rot == 0 && bd.split16;
+                        tq[b][0] = bdg->bt[rot]; tq[b][1] = bd.bt_hi;
+                        if (lane < (split ? 16 : 32) && lane < mv) idx[b][0] = bo + lane;
+                        if (split && lane >= 16 && lane < 32 && lane < mv) idx[b][1] = bd.bias_off_hi + (lane - 16);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int64_t i = idx[b][q] >= 0 ? idx[b][q] : 0;  // masked lanes read element 0 (no branch around the loads)
+                    pi[b][q] = g.p[i]; mo[b][q] = g.m[i]; vo[b][q] = g.v[i];
+                    gi[b][q] = slab_sum_at<W4_SLAB_AUX != 0>(g, i);               // the other slices' slabs, not this XCD's stale L2 lines
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < UB; ++b)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const TensorDesc& d = g.tensors[tq[b][q]];                     // uniform address: scalar loads
+                    if (FOLD_DIAG == 2) { if (idx[b][q] >= 0) g.p[idx[b][q]] = pi[b][q] + mo[b][q] + vo[b][q] + gi[b][q]; continue; }
+                    if (idx[b][q] >= 0) apply_element<T, true, NP>(g, idx[b][q], d, pi[b][q], mo[b][q], vo[b][q], gi[b][q]);
+                }
+        }
+    }
+    if (blockIdx.x == 0 && g.losses3 != nullptr && FOLD_DIAG == 0) {   // workgroup 0 (always a participant): loss scalars
+        __syncthreads();
+        finalize_losses(g, reinterpret_cast<double (*)[4]>(wsm + 64));
+        // a wait that ran out (error word set, sticky): parameters were not all updated -- the loss says so
+        if (threadIdx.x == 0 && __hip_atomic_load(fa.cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) g.losses3[0] = __builtin_nanf("");
+    }
+    if (!ok && threadIdx.x == 0 && g.losses3 != nullptr) g.losses3[0] = __builtin_nanf("");
 }
 
 template <typename P>
 __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
                                                         int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride,
-                                                        const RawIn ri, int use_raw, const unsigned* __restrict__ ylo_epoch, unsigned launch_id) {
+                                                        const RawIn ri, int use_raw, const unsigned* __restrict__ ylo_epoch, unsigned launch_id,
+                                                        const ApplyArgs fold_apply, const FoldArgs fold) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1275,6 +1513,7 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
         else W4_GO(4, 4, 0);
     }
 #undef W4_GO
+    if (fold.cnt != nullptr) fold_tail<typename P::T, P::NP>(fold_apply, fold, bd, blocks + bi, bi, slice, ksplit, lane, wave, wsm);
 }
 
 // sum of up to NS slabs at element i: every load issued before the first addition (a run-time loop makes each addition wait for
@@ -1310,30 +1549,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ sl
         slabs[i] = slab_total_any(slabs, i, nslabs, stride);
 }
 
-// ---------------------------------------------------------------------------------------------
-struct TensorDesc {
-    int64_t off;          // float offset in the flat parameter buffer
-    int32_t rows, cols;
-    // kernel-layout ("fragment-major") copies: element (row, col) of a [rows][ns * KSTEP] matrix sits at
-    //   off + (((col / KSTEP) * nt + row / 32) * 64 + ((col % KSTEP) / E) * 32 + row % 32) * E + col % E      (nt = row tiles)
-    int64_t sf_off;       // forward copy (A operand of the layer), -1 = none
-    int32_t sf_nt, sf_split, sf_gap, sf_roff;   // column c -> c (c < split) or c + gap; row r -> r + roff
-    int32_t sf_ld, st_ld;                       // row strides of the row-major variant (WFRAG == false)
-    int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
-    int32_t st_nt, st_roff, st_cmax, pad1;      // element (r, c < cmax) -> row c, column r + roff
-};
-
-struct ApplyArgs {
-    float* p; float* m; float* v;
-    const float* slabs; int64_t slab_stride; int nslabs;
-    const TensorDesc* tensors; int ntensors;
-    const unsigned char* chunk_tensor; int64_t n_params;
-    void* wcopy; int64_t wpl;      // kernel-layout weight copies; elements between the hi and lo planes (NP == 2)
-    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
-    const double* partials; int npartials; int64_t B; float* losses3; double* accum;
-    int info; float alpha, beta, gamma;
-};
-
 // One thread per parameter over the flat buffer (every load independent); chunk_tensor maps each
 // 64-float chunk to its tensor (tensors start on 64-float boundaries), 255 = alignment padding.
 // The block after the last parameter block finalises the loss scalars.
@@ -1342,31 +1557,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     if (blockIdx.x == gridDim.x - 1) {                    // loss finalisation block
         if (!ADAM || g.losses3 == nullptr) return;
         __shared__ double red[4][4];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double a = 0.0, k = 0.0, c = 0.0, x = 0.0;
-        for (int i = threadIdx.x; i < g.npartials; i += 256) {
-            a += g.partials[4 * i]; k += g.partials[4 * i + 1]; c += g.partials[4 * i + 2]; x += g.partials[4 * i + 3];
-        }
-        a = wave_sum(a); k = wave_sum(k); c = wave_sum(c); x = wave_sum(x);
-        if (lane == 0) { red[wave][0] = a; red[wave][1] = k; red[wave][2] = c; red[wave][3] = x; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float recon = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)g.B);
-            const float kl = (float)((red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (double)g.B);
-            g.losses3[0] = recon + kl; g.losses3[1] = recon; g.losses3[2] = kl;
-            if (g.accum) { g.accum[0] += (double)(recon + kl); g.accum[1] += (double)recon; g.accum[2] += (double)kl; }
-            if (g.info) {   // scripts/training_M2_info_vad.py:162-183
-                const float bc = (float)((red[0][2] + red[1][2] + red[2][2] + red[3][2]) / (double)g.B);
-                const float ba = (float)((red[0][3] + red[1][3] + red[2][3] + red[3][3]) / (double)g.B);
-                const float classif = g.alpha * bc, aux_enc = g.beta * ba;
-                g.losses3[3] = (recon + kl) + classif - aux_enc;      // enc_loss
-                g.losses3[4] = classif;
-                g.losses3[5] = g.gamma * ba;                          // aux_loss
-                g.losses3[6] = aux_enc;
-                g.losses3[7] = 0.f;
-                if (g.accum) for (int q = 3; q < 8; ++q) g.accum[q] += (double)g.losses3[q];
-            }
-        }
+        finalize_losses(g, red);
         return;
     }
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1374,61 +1565,17 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     // Everything this thread reads sits at flat index idx (alignment padding between tensors included, the buffers
     // are allocated whole): request it all FIRST, so the two dependent table lookups below (chunk -> tensor ->
     // descriptor) overlap the one HBM round trip instead of preceding it.
-    float pi = g.p[idx];
+    const float pi = g.p[idx];
     float m_old = 0.f, v_old = 0.f, gi = 0.f;
     if (ADAM) {
         m_old = g.m[idx]; v_old = g.v[idx];
-        auto sum_slabs = [&](auto nsc) __attribute__((always_inline)) {
-            constexpr int NS = decltype(nsc)::value;
-            float part[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) part[k] = g.slabs[(k < g.nslabs ? k : 0) * g.slab_stride + idx];   // independent loads
-            float t = part[0];
-#pragma unroll
-            for (int k = 1; k < NS; ++k) if (k < g.nslabs) t += part[k];                                    // fixed order: deterministic
-            return t;
-        };
-        if (g.nslabs <= 8) gi = sum_slabs(std::integral_constant<int, 8>{});
-        else if (g.nslabs <= 12) gi = sum_slabs(std::integral_constant<int, 12>{});
-        else if (g.nslabs <= 16) gi = sum_slabs(std::integral_constant<int, 16>{});
-        else {
-            gi = g.slabs[idx];
-            for (int k = 1; k < g.nslabs; ++k) gi += g.slabs[k * g.slab_stride + idx];
-        }
+        gi = slab_sum_at(g, idx);
     }
     // a wave covers one 64-float chunk: its tensor and the descriptor are wave-uniform, fetched by scalar loads
     const int t = g.chunk_tensor[__builtin_amdgcn_readfirstlane((int)(idx >> 6))];
     if (t == 255) return;
     const TensorDesc d = g.tensors[t];
-    const int64_t i = idx - d.off;
-    if (i >= (int64_t)d.rows * d.cols) return;
-    T* wc = (T*)g.wcopy;
-    if (ADAM) {
-        gi *= g.gscale;
-        const float mi = m_old + g.one_minus_b1 * (gi - m_old);
-        const float vi = v_old * g.b2 + g.one_minus_b2 * (gi * gi);
-        const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
-        pi = pi - g.step_size * (mi / denom);
-        g.p[idx] = pi; g.m[idx] = mi; g.v[idx] = vi;
-    }
-    const int r = (int)(i / d.cols), c = (int)(i - (int64_t)r * d.cols);
-    constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
-    if (d.sf_off >= 0) {
-        const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
-        const int64_t o = WFRAG ? d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
-                                : d.sf_off + (int64_t)rr * d.sf_ld + cc;
-        const T ph = (T)pi;
-        wc[o] = ph;
-        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
-    }
-    if (d.st_off >= 0 && c < d.st_cmax) {
-        const int rr = c, cc = r + d.st_roff;
-        const int64_t o = WFRAG ? d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
-                                : d.st_off + (int64_t)rr * d.st_ld + cc;
-        const T ph = (T)pi;
-        wc[o] = ph;
-        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
-    }
+    apply_element<T, ADAM, NP>(g, idx, d, pi, m_old, v_old, gi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1501,7 +1648,8 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
-    L.o_flags = bytes(256 + 4 * (p.Bp / TB + 1));             // [0]: label-lo-plane epoch (RowsArgs::ylo_epoch); from byte 256: ylo_dirty[tile]
+    L.o_flags = bytes(1024 + 4 * (p.Bp / TB + 1));            // header of 256 words -- [0]: label-lo-plane epoch (RowsArgs::ylo_epoch), [1], [2], [16..]: the counters of the
+                                                              // folded optimizer tail (fold_tail) -- then from byte 1024: ylo_dirty[tile]
     L.o_wcopy = bytes(L.wcopy_elems * esz * np);              // PolX3: hi plane, then lo plane
     L.o_stash = bytes(L.stash_rows * p.Bp * esz * np);
     L.o_grads = bytes((int64_t)p.ksplit * p.n_params * sizeof(float));
@@ -1716,8 +1864,10 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
                             q.ldo[k] = p->tensor_cols[a.tensor];
                             q.a_off[k] = p->tensor_offset[a.tensor] + (int64_t)a.m0 * q.ldo[k];
                             q.mvalid[k] = a.mvalid;
+                            q.wt[k] = a.tensor; q.bt[k] = a.bias_tensor >= 0 ? a.bias_tensor : 0;
                             if (a.bias_tensor >= 0 && j0 == 0) q.bias_off[k] = p->tensor_offset[a.bias_tensor] + a.m0;
                             if (k == 0 && a.tensor_hi >= 0) {
+                                q.wt_hi = a.tensor_hi; q.bt_hi = a.bias_hi;
                                 q.split16 = 1;
                                 q.ldo_hi = p->tensor_cols[a.tensor_hi];
                                 q.a_off_hi = p->tensor_offset[a.tensor_hi];
@@ -1778,9 +1928,15 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     }
 }
 
-static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* params, float* m, float* v, char* ws, int n_slabs,
-                        bool adam, int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale,
-                        float* losses3, hipStream_t s) {
+// folded launches per workspace (the block counters of fold_tail count arrivals across launches); dvae_train_init zeroes the
+// workspace and forgets its count
+static std::mutex g_fold_mu;
+static std::unordered_map<const void*, unsigned> g_fold_seq;
+static unsigned fold_seq_next(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); return ++g_fold_seq[ws]; }
+static void fold_seq_reset(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_seq.erase(ws); }
+
+static ApplyArgs make_apply_args(const dvae_train_plan_t* plan, const Layout& L, float* params, float* m, float* v, char* ws, int n_slabs,
+                                 bool adam, int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale, float* losses3) {
     ApplyArgs a;
     memset(&a, 0, sizeof(a));
     a.p = params; a.m = m; a.v = v;
@@ -1795,6 +1951,13 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
     }
     a.partials = (const double*)(ws + L.o_partials); a.npartials = (int)plan->rows_grid; a.B = plan->B; a.losses3 = losses3; a.accum = (double*)(uintptr_t)plan->loss_accum;
     a.info = plan->model == DVAE_MODEL_M2_INFO; a.alpha = (float)plan->info_alpha; a.beta = (float)plan->info_beta; a.gamma = (float)plan->info_gamma;
+    return a;
+}
+
+static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* params, float* m, float* v, char* ws, int n_slabs,
+                        bool adam, int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale,
+                        float* losses3, hipStream_t s) {
+    const ApplyArgs a = make_apply_args(plan, L, params, m, v, ws, n_slabs, adam, step, lr, beta1, beta2, adam_eps, grad_scale, losses3);
     const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
     if (plan->precision == DVAE_PREC_BF16X3) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true, 2>), grid, dim3(256), 0, s, a);
@@ -1826,6 +1989,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)ws;
     DVAE_HIP(hipMemsetAsync(w, 0, (size_t)L.total, s));
+    fold_seq_reset(ws);
     GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
     BlockDesc* blocks = new BlockDesc[L.nblocks + 8];
     Block4* blocks4 = new Block4[L.nblocks4 + 8];
@@ -1869,6 +2033,25 @@ static int launch_rows(const RowsArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((vae_rows_kernel<P, YP, YENC, INFO>), dim3(grid), dim3(256), lds, s, a);
     DVAE_LAUNCH_OK("vae_rows_kernel");
     return 0;
+}
+
+// dvae_train_step -> dvae_train_grads: "run the optimizer step in the weight-gradient launch if you can" (done: it did)
+struct FoldRequest {
+    bool want = false, done = false;
+    float* params = nullptr; float* m = nullptr; float* v = nullptr; float* losses3 = nullptr;
+    int step = 0; double lr = 0, beta1 = 0, beta2 = 0, adam_eps = 0;
+};
+static thread_local FoldRequest g_fold;
+
+static int device_cu_count(int dev) {
+    static int cus[64] = {};
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+        cus[dev] = n;
+    }
+    return cus[dev];
 }
 
 extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
@@ -1926,7 +2109,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         const char* wk0 = getenv("DVAE_WGRAD");
         const bool wg4 = wgrad_form(wk0) == 4 && (plan->Bp > 128 || raw_inputs || wk0 != nullptr);
         a.ylo_epoch = (unsigned*)(w + L.o_flags);
-        a.ylo_dirty = (int*)(w + L.o_flags + 256);
+        a.ylo_dirty = (int*)(w + L.o_flags + 1024);
         a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);
         if (a.launch_id == 0) a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of a fresh workspace
         a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && wg4 && !(raw_mask & 2) &&
@@ -1999,9 +2182,23 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             attr_done[dev][pi] = true;
         }
         const Block4* bl = (const Block4*)(w + L.o_blocks4);
-        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id);
-        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u);
-        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u);
+        // the optimizer step in this launch's tail (dvae_train_step asked for it): only when every workgroup of the grid is resident at
+        // once -- one per CU, the tail's wait depends on it -- and the block counters fit the flag header
+        ApplyArgs fa_apply;
+        memset(&fa_apply, 0, sizeof(fa_apply));
+        FoldArgs fold{nullptr, 0u, 0u};
+        if (g_fold.want && wrep == 1 && a.mode == 0 && ks > 1 && ks <= 16 && L.nblocks4 <= FOLD_MAXB && (int)g3.x <= device_cu_count(dev)) {
+            fa_apply = make_apply_args(plan, L, g_fold.params, g_fold.m, g_fold.v, w, ks, true, g_fold.step, g_fold.lr, g_fold.beta1, g_fold.beta2,
+                                       g_fold.adam_eps, 1.0, g_fold.losses3);
+            fold.cnt = (unsigned*)(w + L.o_flags);
+            fold.target = (unsigned)ks * fold_seq_next(w);
+            fold.max_polls = 1u << 20;
+            { const char* e = getenv("DVAE_FOLD_MAX_POLLS"); if (e) fold.max_polls = (unsigned)strtoul(e, nullptr, 10); }
+            g_fold.done = true;
+        }
+        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id, fa_apply, fold);
+        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold);
+        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold);
         DVAE_LAUNCH_OK("wgrad4_kernel");
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
@@ -2059,10 +2256,27 @@ extern "C" int dvae_train_apply(const dvae_train_plan_t* plan, float* params, fl
 extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws,
                                const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
                                int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream) {
+    DVAE_CHECK_ARG(plan && params && m && v && ws && step >= 1, "train_step: bad argument");
     g_rng_step_override = step;
+    // DVAE_FOLD_APPLY=1: the optimizer step in the tail of the weight-gradient launch (two launches per step; results bit-identical,
+    // tested).  Opt-in, because it is SLOWER on the MI355X (M2 y513, 8192 frames, bf16x3, same box, alternating): the weight-gradient
+    // kernel goes 28.7 -> 47.1 us while the separate optimizer launch it replaces costs 9.5 us gross.  Ablation of the 18.4 us tail
+    // (FOLD_DIAG builds): arrive + wait for the block's slices 2.6 us; the 13 MB of slab partials + p, m, v as device-coherent loads
+    // 8 us; Adam + weight-copy element math and stores 8 us -- the kernel runs ONE wave per SIMD (512 registers of accumulators), so
+    // both phases are latency-bound, whereas apply_kernel does the same work at full occupancy in ~6 us behind a ~3 us launch gap.
+    // (First attempt with release / acquire fences instead of write-through stores + coherent loads: 75 us -- every fence writes back
+    // or invalidates the XCD's whole L2 under the workgroups that are still multiplying.)
+    const char* fe = getenv("DVAE_FOLD_APPLY");                       // read per call (tests flip it)
+    const bool fold_on = fe && atoi(fe) != 0;
+    g_fold = FoldRequest();
+    g_fold.want = fold_on; g_fold.params = params; g_fold.m = m; g_fold.v = v; g_fold.step = step; g_fold.lr = lr; g_fold.beta1 = beta1;
+    g_fold.beta2 = beta2; g_fold.adam_eps = adam_eps; g_fold.losses3 = losses3;
     int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, elbo_eps, 0, stream);
+    const bool folded = g_fold.done;
+    g_fold = FoldRequest();
     g_rng_step_override = -1;
     if (rc) return rc;
+    if (folded) return 0;
     return dvae_train_apply(plan, params, m, v, ws, 0, step, lr, beta1, beta2, adam_eps, 1.0, losses3, stream);
 }
 

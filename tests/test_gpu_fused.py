@@ -610,3 +610,33 @@ def test_label_lo_plane_on_demand_equals_always(y_dim, B, monkeypatch):
     np.testing.assert_allclose(res[False][0][0], [out["loss"], out["recon"], out["kl"]], rtol=1e-5)
     for k in grads:
         assert _relmax(res[False][0][1][k], np.asarray(grads[k], np.float64).reshape(res[False][0][1][k].shape)) < 4e-4, k
+
+
+@pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M2", 513, 3000, "fp32"), ("M2", 1, 5000, "bf16x3"),
+                                                       ("M1", 0, 8192, "bf16"), ("M2_info", 1, 8192, "bf16x3"), ("M2", 513, 20000, "bf16x3")])
+def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_launch(model, y_dim, B, precision, monkeypatch):
+    """dvae_train_step runs Adam + the weight-copy refresh + the loss scalars in the tail of the weight-gradient kernel (two launches per
+    step) whenever that kernel's grid is one resident round of workgroups; DVAE_FOLD_APPLY=0 keeps the third launch.  Same slab sums
+    in the same order, same element arithmetic: losses, gradients, parameters and both Adam moments are equal bit for bit over a run
+    of steps (the counters of the tail must come back to zero after every launch; ragged last tiles and partial k-slices included)."""
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 71)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    batches = [gu.make_batch(dims, B, 80 + i) for i in range(4)]
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("DVAE_FOLD_APPLY", fold)
+        tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+        out = []
+        for x, y, e in batches:
+            losses = tr.step(t(x), t(y) if y_dim else None, t(e)).cpu().numpy().copy()
+            out.append((losses, tr.grads_numpy(), tr.state_dict_numpy(), tr.m.cpu().numpy().copy(), tr.v.cpu().numpy().copy()))
+        res[fold] = out
+    for (la, ga, pa, ma, va), (lb, gb, pb, mb, vb) in zip(res["1"], res["0"]):
+        assert np.all(np.isfinite(la))
+        np.testing.assert_array_equal(la, lb)
+        np.testing.assert_array_equal(ma, mb)
+        np.testing.assert_array_equal(va, vb)
+        for k in ga:
+            np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
+            np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
