@@ -1702,8 +1702,8 @@ static int wgrad_form(const char* wk) {
 extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_hint, dvae_train_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr && B > 0, "train_plan: bad argument");
     if (!((model == DVAE_MODEL_M1 && y_dim == 0) || (model == DVAE_MODEL_M2 && (y_dim == 1 || y_dim == 513)) ||
-          (model == DVAE_MODEL_M2_INFO && y_dim == 1))) {
-        set_error("train_plan: fused kernels cover M1 (y 0), M2 (y 1 or 513) and M2_info (y 1) at x 513 / h [128,128] / z 16; got model %d y_dim %d", model, y_dim);
+          (model == DVAE_MODEL_M2_INFO && y_dim == 1) || (model == DVAE_MODEL_M2_DEC && y_dim == 1))) {
+        set_error("train_plan: fused kernels cover M1 (y 0), M2 (y 1 or 513), M2_info and M2_DEC (y 1) at x 513 / h [128,128] / z 16; got model %d y_dim %d", model, y_dim);
         return DVAE_E_UNSUPPORTED;
     }
     DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3, "train_plan: unknown precision %d", precision);
@@ -1729,6 +1729,10 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     int want = 2;
     if (rk && (atoi(rk) == 1 || atoi(rk) == 2)) want = atoi(rk);
     plan->rows_kernel = (want == 2 && rows2_supported(precision, model)) ? 2 : 1;
+    if (model == DVAE_MODEL_M2_DEC && plan->rows_kernel != 2) {
+        set_error("train_plan: M2_DEC exists in the 8-wave rows kernel only (bf16 / bf16x3 operands, DVAE_ROWS unset)");
+        return DVAE_E_UNSUPPORTED;
+    }
     // workgroups resident at once: the 8-wave kernel holds one per CU; the 4-wave bf16 kernel two.  Beyond that: persistent tile loop
     const int64_t maxg = plan->rows_kernel == 2 ? 256 : 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
     plan->rows_grid = ntiles < maxg ? ntiles : maxg;

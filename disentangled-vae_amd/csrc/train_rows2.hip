@@ -1101,13 +1101,17 @@ static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
     return launch_rows2_m<P, YP, YENC, 0>(a, grid, s);
 }
 
-// model: DVAE_MODEL_M1 / DVAE_MODEL_M2 / DVAE_MODEL_M2_INFO (train step only); precision: DVAE_PREC_BF16 / DVAE_PREC_BF16X3
+// model: DVAE_MODEL_M1 / DVAE_MODEL_M2 / DVAE_MODEL_M2_DEC / DVAE_MODEL_M2_INFO (train step only); precision: DVAE_PREC_BF16 / DVAE_PREC_BF16X3
 int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s) {
     const bool m2 = model == DVAE_MODEL_M2;
     if (model == DVAE_MODEL_M2_INFO) {
         if (a.mode != 0) { set_error("rows2 kernel: M2_info runs the fused train step only (mode %d)", a.mode); return DVAE_E_UNSUPPORTED; }
         if (precision == DVAE_PREC_BF16X3) return launch_rows2_m<PolX3v2, 16, false, 0, true>(a, grid, s);
         if (precision == DVAE_PREC_BF16) return launch_rows2_m<PolBF16v2, 16, false, 0, true>(a, grid, s);
+    }
+    if (model == DVAE_MODEL_M2_DEC) {          // labels in the decoder only (y_dim 1): the plain VAE kernel with a zero-length encoder label segment
+        if (precision == DVAE_PREC_BF16X3) return launch_rows2_t<PolX3v2, 16, false>(a, grid, s);
+        if (precision == DVAE_PREC_BF16) return launch_rows2_t<PolBF16v2, 16, false>(a, grid, s);
     }
     if (precision == DVAE_PREC_BF16X3) {
         if (!m2) return launch_rows2_t<PolX3v2, 0, false>(a, grid, s);
@@ -1124,7 +1128,8 @@ int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int gri
 }
 
 bool rows2_supported(int precision, int model) {
-    return (precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3) && (model == DVAE_MODEL_M1 || model == DVAE_MODEL_M2 || model == DVAE_MODEL_M2_INFO);
+    return (precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3) &&
+           (model == DVAE_MODEL_M1 || model == DVAE_MODEL_M2 || model == DVAE_MODEL_M2_INFO || model == DVAE_MODEL_M2_DEC);
 }
 
 }  // namespace fused

@@ -1,7 +1,10 @@
 """Whole-model autograd path of the drop-in modules.
 
 `packages.models.models.VariationalAutoencoder.forward` / `DeepGenerativeModel.forward` on CUDA tensors at the reference
-geometry (x 513, h [128, 128], z 16, y 0 / 1 / 513) run as ONE autograd Function instead of one Function per nn.Linear:
+geometry (x 513, h [128, 128], z 16, y 0 / 1 / 513) run as ONE autograd Function instead of one Function per nn.Linear, and so
+does the VAE body of M2_info -- `DeepGenerativeModel_v3.forward` / `DeepGenerativeModel_v5.forward` (encoder on x alone, decoder on
+[z | y], y 1; "M2_DEC"): the script's `model(x, y)` call (scripts/training_M2_info_vad.py:161) with z an output that the
+auxiliary classifier's loss differentiates through.  Its classifier / auxiliary MLP calls stay per-layer Functions:
 
     forward : dvae_module_forward  = weight-copy refresh + the 8-wave rows kernel in forward mode   (2 launches)
     backward: dvae_module_backward = rows kernel in backward mode (forward recomputed on chip, then the backward from the
@@ -43,17 +46,25 @@ def _precision():
     return p
 
 
+def vae_parameters(module, model):
+    """The 14 (name, parameter) pairs of the VAE in plan order.  M2_DEC (a _v3 module): encoder + decoder, not the classifier."""
+    if model == "M2_DEC":
+        return list(module.encoder.named_parameters(prefix="encoder")) + list(module.decoder.named_parameters(prefix="decoder"))
+    return list(module.named_parameters())
+
+
 class ModuleEngine:
-    """Fused kernels bound to one module instance (M1 or M2)."""
+    """Fused kernels bound to one module instance (M1, M2, or the encoder + decoder of a _v3: M2_DEC)."""
 
     def __init__(self, module, model, y_dim):
         self.lib = N.load()
         self.model, self.y_dim = model, int(y_dim)
         self.precision = _precision()
-        sd_names = [n for n, _ in module.named_parameters()]
+        named = vae_parameters(module, model)
+        sd_names = [n for n, _ in named]
         if sd_names != TENSOR_NAMES:
             raise RuntimeError(f"unexpected parameter set for the fused module path: {sd_names}")
-        self.params = [p for _, p in module.named_parameters()]
+        self.params = [p for _, p in named]
         self.device = self.params[0].device
         self.plans = {}
         p0 = self._plan(128)[0]
@@ -181,12 +192,12 @@ class VaeFunction(torch.autograd.Function):
 
 
 def engine_for(module, model, x, y):
-    """The module's engine when this call can take the fused path, else None.  model: "M1" | "M2"."""
+    """The module's engine when this call can take the fused path, else None.  model: "M1" | "M2" | "M2_DEC" (module: a _v3)."""
     if not (enabled() and x.is_cuda and x.dim() == 2 and x.shape[1] == 513 and x.dtype == torch.float32 and x.shape[0] > 0):
         return None
     if x.requires_grad or (y is not None and y.requires_grad):
         return None                                  # gradients with respect to the data are a layer-path feature
-    if not torch.is_grad_enabled() or not any(p.requires_grad for p in module.parameters()):
+    if not torch.is_grad_enabled() or not any(p.requires_grad for _, p in vae_parameters(module, model)):
         return None                                  # inference: the exact-fp32 per-layer kernels (module docstring)
     eng = module.__dict__.get("_dvae_engine")
     if eng is None:
@@ -194,19 +205,19 @@ def engine_for(module, model, x, y):
             return None
         ok = (module.z_dim == 16 and module.flow is None
               and [tuple(l.weight.shape) for l in module.encoder.hidden] == [(128, 513 + (module.y_dim if model == "M2" else 0)), (128, 128)]
-              and [tuple(l.weight.shape) for l in module.decoder.hidden] == [(128, 16 + (module.y_dim if model == "M2" else 0)), (128, 128)]
+              and [tuple(l.weight.shape) for l in module.decoder.hidden] == [(128, 16 + (module.y_dim if model != "M1" else 0)), (128, 128)]
               and tuple(module.decoder.reconstruction.weight.shape) == (513, 128)
-              and (model == "M1" or module.y_dim in (1, 513))
-              and all(p.is_cuda and p.dtype == torch.float32 for p in module.parameters())
-              and [n for n, _ in module.named_parameters()] == TENSOR_NAMES)
+              and (model == "M1" or module.y_dim in ((1, 513) if model == "M2" else (1,)))
+              and all(p.is_cuda and p.dtype == torch.float32 for _, p in vae_parameters(module, model))
+              and [n for n, _ in vae_parameters(module, model)] == TENSOR_NAMES)
         if not ok:
             object.__setattr__(module, "_dvae_engine_off", True)
             return None
-        eng = ModuleEngine(module, model, module.y_dim if model == "M2" else 0)
+        eng = ModuleEngine(module, model, module.y_dim if model != "M1" else 0)
         object.__setattr__(module, "_dvae_engine", eng)
     if not eng.usable(x):
         return None
-    if model == "M2" and (y is None or y.dim() != 2 or y.shape != (x.shape[0], eng.y_dim) or y.dtype != torch.float32 or y.device != x.device):
+    if model != "M1" and (y is None or y.dim() != 2 or y.shape != (x.shape[0], eng.y_dim) or y.dtype != torch.float32 or y.device != x.device):
         return None
     return eng
 

@@ -30,7 +30,7 @@ class TrainPlan(ctypes.Structure):
                 ("rows_kernel", ctypes.c_int32), ("reserved1", ctypes.c_int32)]
 
 
-MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3}
+MODEL_CODE = {"M1": 1, "M2": 2, "M2_info": 3, "M2_DEC": 4}    # M2_DEC: encoder on x alone, decoder on [z | y] (the VAE body of _v3 / _v5)
 # matrix-core operand policies (include/dvae_train.h): fp32 = exact fp32 MFMA; bf16 = one bf16 per operand (fast, loose);
 # bf16x3 = split bf16 (hi + lo planes, three MFMAs per product): the parity-grade throughput mode
 PREC_CODE = {"fp32": 0, "bf16": 1, "bf16x3": 2}

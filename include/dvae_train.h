@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-enum { DVAE_MODEL_M1 = 1, DVAE_MODEL_M2 = 2, DVAE_MODEL_M2_INFO = 3 };
+enum { DVAE_MODEL_M1 = 1, DVAE_MODEL_M2 = 2, DVAE_MODEL_M2_INFO = 3,
+       /* encoder on x alone, decoder on [z | y]: the VAE body of DeepGenerativeModel_v3 / _v5 (packages/models/models.py:245-297, 437-444)
+        * for the whole-model autograd path of the drop-in modules; y_dim 1, bf16 / bf16x3 operands (the 8-wave rows kernel) */
+       DVAE_MODEL_M2_DEC = 4 };
 /* Matrix-core operand policies (accumulation and master weights are always fp32):
  *   F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                       -- parity mode, 1/16 of the bf16 MFMA rate
  *   BF16   one bf16 per operand                                            -- fastest; weight gradients within ~4e-2 of their maximum
@@ -38,7 +41,7 @@ enum { DVAE_PREC_F32 = 0, DVAE_PREC_BF16 = 1, DVAE_PREC_BF16X3 = 2 };
 typedef struct {
     /* inputs (echoed) */
     int32_t model;            /* DVAE_MODEL_* */
-    int32_t y_dim;            /* 0 (M1), 1 or 513 (M2), 1 (M2_info) */
+    int32_t y_dim;            /* 0 (M1), 1 or 513 (M2), 1 (M2_info, M2_DEC) */
     int32_t precision;        /* DVAE_PREC_*: matrix-core operand type (accumulation is always fp32) */
     int32_t ksplit;           /* frame-axis slices of the weight-gradient reduction */
     int64_t B;                /* frames per step */

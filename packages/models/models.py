@@ -319,9 +319,19 @@ class DeepGenerativeModel_v3(nn.Module):
     def classify(self, x):
         return self.classifier(x)
 
-    def forward(self, x, y):
+    def _forward_z(self, x, y):
+        """-> (x_mu, z, z_mu, z_log_var): encoder + decoder as one autograd Function on CUDA at the reference geometry (the fused
+        module path, model "M2_DEC": z is an output, so a loss on z -- the auxiliary classifier of _v5 -- differentiates through)."""
+        if x.is_cuda and type(self) is DeepGenerativeModel_v3:
+            eng = _native.module_path().engine_for(self, "M2_DEC", x, y)
+            if eng is not None:
+                return _native.module_path().run(eng, x, y, Stochastic.draw_epsilon((x.shape[0], self.z_dim), x.device))
         z, z_mu, z_log_var = self.encoder(x)
-        return _decode_zy(self.decoder, z, y), z_mu, z_log_var
+        return _decode_zy(self.decoder, z, y), z, z_mu, z_log_var
+
+    def forward(self, x, y):
+        r, _, z_mu, z_log_var = self._forward_z(x, y)
+        return r, z_mu, z_log_var
 
     def sample(self, z, y):
         return _decode_zy(self.decoder, z, y.float())
@@ -388,8 +398,7 @@ class DeepGenerativeModel_v5(nn.Module):
         return self.auxiliary(z)
 
     def forward(self, x, y):
-        z, z_mu, z_log_var = self.enc_dec_clf.encoder(x)
-        return _decode_zy(self.enc_dec_clf.decoder, z, y), z, z_mu, z_log_var
+        return self.enc_dec_clf._forward_z(x, y)
 
     def sample(self, z, y):
         return _decode_zy(self.enc_dec_clf.decoder, z, y.float())
