@@ -1513,7 +1513,10 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
         else W4_GO(4, 4, 0);
     }
 #undef W4_GO
-    if (fold.cnt != nullptr) fold_tail<typename P::T, P::NP>(fold_apply, fold, bd, blocks + bi, bi, slice, ksplit, lane, wave, wsm);
+#ifndef W4_FOLD
+#define W4_FOLD 1      // 0: the folded optimizer tail compiled out (A/B of what its presence costs the main loop)
+#endif
+    if (W4_FOLD && fold.cnt != nullptr) fold_tail<typename P::T, P::NP>(fold_apply, fold, bd, blocks + bi, bi, slice, ksplit, lane, wave, wsm);
 }
 
 // sum of up to NS slabs at element i: every load issued before the first addition (a run-time loop makes each addition wait for

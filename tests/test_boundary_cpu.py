@@ -172,3 +172,21 @@ def test_train_plan_is_host_only_and_consistent(model, y_dim, precision):
     plan = T.TrainPlan()
     native.check(lib.dvae_train_plan(T.MODEL_CODE[model], y_dim, T.PREC_CODE[precision], 8192, 5, ctypes.byref(plan)), "dvae_train_plan")
     assert plan.ksplit == 5
+
+
+def test_train_plan_m2_dec_exists_for_the_8_wave_kernel_only(monkeypatch):
+    """Kernel model M2_DEC (encoder on x alone, decoder on [z | y]: the VAE body of DeepGenerativeModel_v3 / _v5 on the module
+    path): same 14 tensors as M2 with a 513-wide first encoder layer; y_dim 1 and the split-bf16 / bf16 policies only -- anything
+    else is refused with a message, never planned onto a kernel that does not exist."""
+    T = importlib.import_module("disentangled-vae_amd.trainer")
+    lib = native.load()
+    monkeypatch.delenv("DVAE_ROWS", raising=False)
+    plan = T.TrainPlan()
+    native.check(lib.dvae_train_plan(T.MODEL_CODE["M2_DEC"], 1, T.PREC_CODE["bf16x3"], 8192, 0, ctypes.byref(plan)), "dvae_train_plan")
+    assert plan.n_tensors == 14 and plan.rows_kernel == 2
+    assert (plan.tensor_rows[0], plan.tensor_cols[0]) == (128, 513) and (plan.tensor_rows[8], plan.tensor_cols[8]) == (128, 17)
+    for y_dim, prec in ((513, "bf16x3"), (0, "bf16x3"), (1, "fp32")):
+        assert lib.dvae_train_plan(T.MODEL_CODE["M2_DEC"], y_dim, T.PREC_CODE[prec], 8192, 0, ctypes.byref(plan)) != 0
+        assert "M2_DEC" in lib.dvae_last_error().decode("utf-8", "replace")
+    monkeypatch.setenv("DVAE_ROWS", "1")
+    assert lib.dvae_train_plan(T.MODEL_CODE["M2_DEC"], 1, T.PREC_CODE["bf16x3"], 8192, 0, ctypes.byref(plan)) != 0

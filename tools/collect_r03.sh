@@ -12,6 +12,13 @@ python bench.py --batch 1048576 --steps 20 --warmup 5 --pool-gb 8 --no-extras --
 python bench.py --batch 65536 --steps 50 --warmup 10 --pool-gb 4 --no-extras --no-cpu-baseline > $O/bench_B65536.json 2>/dev/null
 python bench.py --impl modules --steps 1000 --warmup 200 --no-extras --no-cpu-baseline > $O/bench_modules_B8192.json 2>/dev/null
 python bench.py --impl modules --batch 128 --steps 1000 --warmup 200 --no-extras --no-cpu-baseline > $O/bench_modules_B128.json 2>/dev/null
+python bench.py --impl modules --model M2_info --steps 300 --warmup 50 --no-extras --no-cpu-baseline > $O/bench_modules_M2_info.json 2>/dev/null
+DVAE_MODULE_PATH=layers python bench.py --impl modules --model M2_info --steps 300 --warmup 50 --no-extras --no-cpu-baseline > $O/bench_modules_layers_M2_info.json 2>/dev/null
+DVAE_FOLD_APPLY=1 python bench.py --no-extras --no-cpu-baseline > $O/bench_fold_apply.json 2>/dev/null
+python tools/bench_stft.py > $O/bench_stft.json 2>/dev/null
+for ex in gloo direct; do
+  DVAE_DIST_BACKEND=gloo DVAE_ALLREDUCE=$([ $ex = direct ] && echo direct || echo rccl) timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --steps 20 --warmup 5 --batch 4096 --no-extras --no-cpu-baseline > $O/bench_2rank_${ex}_rehearsal.json 2> $O/bench_2rank_${ex}.err
+done
 python tools/stamp_rows.py bf16x3 8192 > $O/stamps_bf16x3.txt 2>/dev/null
 DVAE_COLD=1 DVAE_HSTAMPS=1 python tools/stamp_rows.py bf16x3 8192 > $O/stamps_bf16x3_cold.txt 2>/dev/null
 python tools/r03/parity_report.py $O/parity.json > /dev/null 2>&1
