@@ -55,6 +55,9 @@ def parse():
                     help="untimed train steps for this long BEFORE the W warmup steps, so that the K timed steps run at the clocks a training run "
                          "sees (from idle the shader clock needs tens of ms of load to settle: 20 steps right after 5 measure 87.6 us/step, "
                          "the same 20 steps after 200 ms of steps 80); reported as `prewarm_steps`; 0 disables")
+    ap.add_argument("--no-direct-trial", action="store_true",
+                    help="N > 1: skip the second timed region that runs the library's own gradient exchange (dvae_allreduce_flat) "
+                         "after the RCCL one (reported under multi_gpu.direct; the headline value is always the RCCL run)")
     return ap.parse_args()
 
 
@@ -231,6 +234,59 @@ def side_kernels(device):
     return out
 
 
+def direct_trial(a, trainer_mod, dims, B, device, world, dist, batches, impl):
+    """N > 1, after the RCCL measurement: the same K steps with the library's own stream-ordered exchange (dvae_allreduce_flat over
+    hipIpc-mapped peer buffers, include/dvae_train.h) on a second trainer, so that one driver run carries both.  Every stage that can
+    fail on one rank is agreed on by all ranks before the next (no rank is left in a collective); the exchange is first checked
+    against the process group's all-reduce on a random vector.  Never the headline value."""
+    dp = importlib.import_module("disentangled-vae_amd.dp")
+    rec = {"exchange": "dvae_allreduce_flat (reduce-scatter by pull + all-gather by push over peer pointers, one launch per rank on the step's stream)"}
+    n = int(impl.tr.plan.n_params)
+    dx, why = dp.DirectExchange.try_create(n, dist.group.WORLD)
+    if dx is None:
+        rec["error"] = "setup: " + str(why)
+        return rec
+
+    def agree(ok):      # logical AND over the ranks
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+    try:
+        g = torch.Generator(device="cpu").manual_seed(4321 + dist.get_rank())
+        v = torch.randn(n, generator=g).to(device)
+        got = torch.empty_like(v)
+        dx.allreduce(v, 1, n, got)
+        ref = v.clone()
+        dp.allreduce_flat_(ref, dist.group.WORLD)
+        torch.cuda.synchronize()
+        dev_ = float((got - ref).abs().max().item())
+        ok = (not dx.failed()) and dev_ <= 1e-5 * float(ref.abs().max().item())
+        rec["check_max_abs_dev_vs_process_group"] = dev_
+    except Exception as e:                              # noqa: BLE001
+        ok = False
+        rec["error"] = "check: " + str(e)
+    if not agree(ok):
+        rec.setdefault("error", "check: the exchanged vector differs from the process group's sum, or a wait ran out (on some rank)")
+        dx.close()
+        return rec
+    try:
+        impl2 = trainer_mod.BenchImpl(a.model, dims, B, device, world, a.precision, ksplit=a.ksplit, direct_exchange=dx)
+        for i in range(max(a.warmup, 20)):
+            impl2.step(*batches[i % len(batches)])
+        dt2, _ = timed_steps(impl2, batches, a.warmup, a.steps, dist, device)
+        ok = not dx.failed()
+        rec.update({"ms_per_step": 1e3 * dt2 / a.steps, "value": world * B * a.steps / dt2, "steps": a.steps, "wait_ran_out": not ok})
+        impl2.tr.profile(True)
+        for i in range(min(a.steps, 50)):
+            impl2.step(*batches[i % len(batches)])
+        impl2.tr.profile_read()
+        rec["allreduce_us"] = impl2.tr.allreduce_us()
+        impl2.tr.profile(False)
+    except Exception as e:                              # noqa: BLE001
+        rec["error"] = "timed region: " + str(e)
+    return rec
+
+
 def timed_steps(impl, batches, first, steps, dist, device):
     """K steps bracketed by barrier + synchronize on both sides; max over ranks.  Returns (seconds, last loss tensor)."""
     nb = len(batches)
@@ -326,6 +382,10 @@ def main():
                   "ms_per_step_max": max(reps), "note": "five more repeats of the timed region, after it"}
 
     prof = impl.kernel_profile(batches, min(a.steps, 50))
+    direct_rec = None
+    if (world > 1 and impl_name == "fused" and not a.no_direct_trial and os.environ.get("DVAE_ALLREDUCE", "rccl") == "rccl"
+            and os.environ.get("DVAE_BENCH_DIRECT_TRIAL", "1") != "0"):
+        direct_rec = direct_trial(a, trainer_mod, dims, B, device, world, dist, batches, impl)
     key = (a.model, y_dim)
     out = {
         "metric": "spectrogram frames/sec (train step), M2 VAE 513-bin" if a.model == "M2" else f"spectrogram frames/sec (train step), {a.model} VAE 513-bin",
@@ -350,7 +410,7 @@ def main():
         "spread": spread,
     }
     if world > 1:
-        out["multi_gpu"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(),
+        out["multi_gpu"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "direct": direct_rec,
                             "exchange": os.environ.get("DVAE_ALLREDUCE", "rccl") + (" (dvae_allreduce_flat: peer pointers, one launch per rank)"
                                                                                     if os.environ.get("DVAE_ALLREDUCE") == "direct" else " (torch.distributed all_reduce)"),
                             "allreduce_us": None if prof is None else prof.get("allreduce_us"),

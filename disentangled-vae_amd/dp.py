@@ -70,6 +70,39 @@ class DirectExchange:
         N.check(self.lib.dvae_comm_connect(self.handle, blob), "dvae_comm_connect")
         dist.barrier(group=group)                      # every rank has mapped every buffer before the first launch
 
+    @classmethod
+    def try_create(cls, n_floats, group=None):
+        """-> (exchange, None) or (None, reason): like the constructor, but a rank whose create / connect step fails does not leave the
+        others waiting in a collective -- every stage's outcome is agreed on by all ranks before the next one starts."""
+        from . import native as N
+        self = cls.__new__(cls)
+        self.N, self.lib = N, N.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n = int(n_floats)
+        self.handle = ctypes.c_void_p()
+        mine = (ctypes.c_ubyte * IPC_HANDLE_BYTES)()
+        err = None
+        try:
+            N.check(self.lib.dvae_comm_create(self.rank, self.world, self.n, ctypes.byref(self.handle), mine), "dvae_comm_create")
+        except Exception as e:                          # noqa: BLE001 -- any local failure is reported, never raised past the collective
+            err = f"rank {self.rank}: {e}"
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (err, bytes(mine)), group=group)
+        errs = [g[0] for g in gathered if g[0]]
+        if not errs:
+            try:
+                blob = (ctypes.c_ubyte * (IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(g[1] for g in gathered))
+                N.check(self.lib.dvae_comm_connect(self.handle, blob), "dvae_comm_connect")
+            except Exception as e:                      # noqa: BLE001
+                err = f"rank {self.rank}: {e}"
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, err, group=group)
+            errs = [g for g in gathered if g]
+        if errs:
+            self.close()
+            return None, "; ".join(errs)
+        return self, None
+
     def allreduce(self, slabs, n_slabs, slab_stride, out):
         """out[i] = sum over ranks of sum_k slabs[k * slab_stride + i]  (fp32 CUDA tensors; `out` may be slab 0); enqueued on the
         current stream, returns at once."""

@@ -66,7 +66,7 @@ class Trainer:
 
     def __init__(self, model, dims, params=None, batch=128, device="cuda:0", precision="fp32", lr=1e-4, betas=(0.9, 0.999),
                  adam_eps=1e-8, elbo_eps=1e-8, process_group=None, world=1, ksplit=0, seed=None, alpha=0.0, beta=10.0, gamma=1.0,
-                 share=None):
+                 share=None, direct_exchange=None):
         if not torch.cuda.is_available():
             raise RuntimeError("Trainer needs the MI355X HIP path (no CPU fallback)")
         if not supported(model, dims):
@@ -103,8 +103,10 @@ class Trainer:
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
         # gradient exchange of the data-parallel step: the process group's all-reduce (RCCL over xGMI), or the library's own
         # stream-ordered exchange over peer pointers (DVAE_ALLREDUCE=direct; dp.DirectExchange) -- unmeasured on multi-GPU hardware
-        self.direct = share.direct if share is not None else None
-        if self.world > 1 and share is None and dp.exchange_mode() == "direct":
+        self.direct = share.direct if share is not None else direct_exchange      # direct_exchange: a connected dp.DirectExchange of n_params floats
+        if self.direct is not None and self.direct.n != P:
+            raise ValueError("direct_exchange was created for another parameter count")
+        if self.world > 1 and share is None and self.direct is None and dp.exchange_mode() == "direct":
             with torch.cuda.device(self.device):
                 self.direct = dp.DirectExchange(P, process_group)
         self._copy_version = self._shared["version"]
@@ -356,13 +358,13 @@ class Trainer:
 class BenchImpl:
     """bench.py adapter: the fused path."""
 
-    def __init__(self, model, dims, B, device, world, precision, ksplit=0):
+    def __init__(self, model, dims, B, device, world, precision, ksplit=0, direct_exchange=None):
         pg = None
         if world > 1:
             import torch.distributed as dist
             pg = dist.group.WORLD
         self.tr = Trainer(model, dims, None, batch=B, device=device, precision=precision, process_group=pg, world=world, seed=0,
-                          ksplit=ksplit)
+                          ksplit=ksplit, direct_exchange=direct_exchange)
         self.dtype = {"bf16": "bf16", "bf16x3": "bf16x3", "fp32": "f32"}[precision]
         self.name = f"fused(rows+wgrad+apply HIP kernels, {precision} MFMA operands, fp32 accumulate/master)"
         self.model, self.dims, self.B, self.precision = model, dims, B, precision

@@ -199,6 +199,11 @@ def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32", ex
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     Bg = 512
     lo, hi = dp.shard_rows(Bg, rank, world)
+    if exchange == "direct":
+        # the staged constructor bench.py uses: a stage that fails on ONE rank (here: rank 1 asks for an impossible size) is reported on
+        # every rank and nobody is left waiting in a collective
+        dx, why = dp.DirectExchange.try_create(1000 if rank == 0 else -5, dist.group.WORLD)
+        assert dx is None and "rank 1" in why, (dx, why)
     tr = tr_mod.Trainer(model, dims, gu.make_params(model, dims, 21), batch=hi - lo, precision=precision,
                         process_group=dist.group.WORLD, world=world)
     for step in range(2):
