@@ -645,3 +645,21 @@ def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_la
         for k in ga:
             np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
             np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+
+
+def test_folded_optimizer_tail_never_hangs_when_its_wait_runs_out(monkeypatch):
+    """The wait of the folded tail (a workgroup waiting for the other slices of its parameter block) is bounded: with a bound of zero
+    polls every workgroup that arrives early gives up at once -- the launch completes, the sticky error word turns the step's loss
+    into NaN (parameters are then partly updated: the trainer is to be discarded), and nothing waits forever."""
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 5)
+    x, y, e = gu.make_batch(dims, 8192, 6)
+    t = lambda a: torch.from_numpy(a).cuda()
+    monkeypatch.setenv("DVAE_FOLD_APPLY", "1")
+    monkeypatch.setenv("DVAE_FOLD_MAX_POLLS", "0")
+    tr = trainer.Trainer("M2", dims, params, batch=8192, precision="bf16x3")
+    losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+    assert np.isnan(losses[0])
+    monkeypatch.delenv("DVAE_FOLD_MAX_POLLS")
+    tr2 = trainer.Trainer("M2", dims, params, batch=8192, precision="bf16x3")      # a fresh workspace is unaffected
+    assert np.all(np.isfinite(tr2.step(t(x), t(y), t(e)).cpu().numpy()))
