@@ -1,0 +1,154 @@
+// Micro-benchmark of the rows kernel's k-step outside the kernel: one workgroup per CU, four waves (one per
+// SIMD), each wave streaming 2 KB of "weight" fragments per k-step from an L2-resident buffer through a register ring of depth D,
+// reading its B operand (2 x 1 KB) from LDS and issuing the k-step's MFMAs.  What is switched on is a bit mask:
+//   1 weight loads   2 LDS operand reads   4 MFMAs   8 MFMAs on three independent accumulators (instead of one dependent chain)
+//   16 MFMAs as 16x16x32 tiles (four per 32x32x16's worth of work; a quarter of the result bytes per instruction)
+//   32 weight loads as one plane only (1 KB per k-step)   64 a second wave per SIMD (8 waves per workgroup)
+// Output: ns per k-step (median over workgroups, wall clock 100 MHz) and the shader clock.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/r03/kstep_bench.hip -o gpurun_out/kstep_bench && gpurun_out/kstep_bench
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef PLANE_STRIDE
+#define PLANE_STRIDE (1048576u + 4352u)
+#endif
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int MODE, int D>
+__global__ __launch_bounds__(512, 1) void kstep_kernel(const void* __restrict__ w, unsigned wbytes, int nsteps, unsigned long long* __restrict__ out, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool WL = MODE & 1, BL = MODE & 2, MF = MODE & 4, IND = MODE & 8, SMALL = MODE & 16, ONEP = MODE & 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: a divergent soffset puts a waterfall loop around every load
+    // LDS image: 32 frames x 552 columns x 2 planes of bf16 (as U of the rows kernel)
+    for (int i = threadIdx.x; i < 2 * 32 * 552 / 2; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = 0x3f803f80u + i;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, (int)wbytes, 0x00020000);
+    const int voff = lane * 16;
+    // fragment (tile = wave & 3, k-step s): byte offset ((s * 4 + tile) * 1024), lo plane at + wbytes / 2
+    const unsigned tile_off = (unsigned)(wave & 3) * 1024u;
+    const unsigned plane = PLANE_STRIDE;                          // not a power of two (as the kernel's weight-copy planes)
+    const unsigned span = 216u;                                   // k-steps before wrapping: the 216 k-steps of a tile (0.86 MB per plane)
+    bf16x8 ring[D][2];
+    auto wload = [&](int s, bf16x8 (&r)[2]) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)(s % (int)span) * 4096u + tile_off;
+        r[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)so, 0));
+        if (!ONEP) r[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(so + plane), 0));
+        else r[1] = r[0];
+    };
+    const __bf16* brow = reinterpret_cast<const __bf16*>(smem) + (lane & 31) * 552 + (lane >> 5) * 8;
+    auto bload = [&](int s, bf16x8 (&b)[2]) __attribute__((always_inline)) {
+        const int c = (s % 33) * 16;
+        b[0] = *reinterpret_cast<const bf16x8*>(brow + c);
+        b[1] = *reinterpret_cast<const bf16x8*>(brow + 32 * 552 + c);
+    };
+    f32x16 acc0, acc1, acc2;
+    f32x4 sa[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 zero8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zero8[i] = (__bf16)(1.0f + lane);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { if (WL) wload(i, ring[i]); else { ring[i][0] = zero8; ring[i][1] = zero8; } }
+    bf16x8 bq[2] = {zero8, zero8};
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long c0 = clock64();
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            if (BL) bload(s0 + i, bq);
+            if (MF) {
+                if (!SMALL) {
+                    if (!IND) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i][0], bq[0], acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i][1], bq[0], acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i][0], bq[1], acc0, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i][0], bq[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i][1], bq[0], acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i][0], bq[1], acc2, 0, 0, 0);
+                    }
+                } else {
+                    // the same FLOPs as three 32x32x16 (3 x 32 768) on 16x16x32 tiles (16 384 each): six instructions, four accumulators
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        sa[q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i][q & 1], bq[(q >> 1) & 1], sa[q & 3], 0, 0, 0);
+                }
+            } else {
+                acc0[0] += (float)ring[i][0][0] + (float)ring[i][1][1] + (float)bq[0][0] + (float)bq[1][1];
+            }
+            if (WL) wload(s0 + i + D, ring[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long c1 = clock64();
+    const unsigned long long t1 = wall_clock64();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += acc0[i] + acc1[i] + acc2[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r += sa[i][0] + sa[i][1] + sa[i][2] + sa[i][3];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r += (float)ring[i][0][0] + (float)ring[i][1][0];
+    if (r == 12345.678f) sink[0] = r;
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = c1 - c0; }
+}
+
+template <int MODE, int D>
+static void run(const char* name, const void* w, unsigned wbytes, unsigned long long* dout, float* sink) {
+    const int nsteps = 1980, grid = 256;
+    const int threads = (MODE & 64) ? 512 : 256;
+    const size_t lds = 2 * 32 * 552 * 2 + 64;
+    CK(hipFuncSetAttribute((const void*)kstep_kernel<MODE, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((kstep_kernel<MODE, D>), dim3(grid), dim3(threads), lds, 0, w, wbytes, nsteps, dout, sink);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(2 * grid);
+    CK(hipMemcpy(h.data(), dout, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    std::vector<double> ns(grid), clk(grid);
+    for (int i = 0; i < grid; ++i) { ns[i] = 10.0 * (double)h[2 * i] / nsteps; clk[i] = (double)h[2 * i + 1] / nsteps; }
+    std::sort(ns.begin(), ns.end()); std::sort(clk.begin(), clk.end());
+    const double per_cu_bytes = ((MODE & 1) ? ((MODE & 32) ? 1024.0 : 2048.0) : 0.0) * (threads / 64);
+    printf("%-64s D=%2d  %6.1f ns/k-step (max %6.1f)  %6.1f clk  %5.2f GHz  %6.1f GB/s per CU\n", name, D, ns[grid / 2], ns[grid - 1], clk[grid / 2],
+           clk[grid / 2] / ns[grid / 2], per_cu_bytes / ns[grid / 2]);
+}
+
+int main() {
+    const unsigned wbytes = 2u * PLANE_STRIDE;                         // two planes of 216 k-steps x 4 tiles x 1 KB, L2-resident
+    void* w; unsigned long long* dout; float* sink;
+    CK(hipMalloc(&w, wbytes)); CK(hipMemset(w, 0x3f, wbytes));
+    CK(hipMalloc(&dout, sizeof(unsigned long long) * 1024)); CK(hipMalloc(&sink, 64));
+    // warm the clocks
+    for (int i = 0; i < 30; ++i) run<7, 6>("warm-up", w, wbytes, dout, sink);
+    printf("---\n");
+    run<1, 6>("weight loads only", w, wbytes, dout, sink);
+    run<2, 6>("LDS operand reads only", w, wbytes, dout, sink);
+    run<4, 6>("MFMAs only (3 dependent 32x32x16)", w, wbytes, dout, sink);
+    run<12, 6>("MFMAs only (3 independent accumulators)", w, wbytes, dout, sink);
+    run<20, 6>("MFMAs only (6 x 16x16x32)", w, wbytes, dout, sink);
+    run<6, 6>("MFMAs + LDS reads", w, wbytes, dout, sink);
+    run<3, 6>("weight loads + LDS reads", w, wbytes, dout, sink);
+    run<5, 6>("weight loads + MFMAs (no LDS)", w, wbytes, dout, sink);
+    run<7, 2>("everything", w, wbytes, dout, sink);
+    run<7, 4>("everything", w, wbytes, dout, sink);
+    run<7, 6>("everything", w, wbytes, dout, sink);
+    run<7, 8>("everything", w, wbytes, dout, sink);
+    run<7, 12>("everything", w, wbytes, dout, sink);
+    run<15, 6>("everything, independent accumulators", w, wbytes, dout, sink);
+    run<23, 6>("everything, 16x16x32 MFMAs", w, wbytes, dout, sink);
+    run<39, 6>("everything, ONE weight plane (1 KB per k-step)", w, wbytes, dout, sink);
+    run<71, 6>("everything, two waves per SIMD", w, wbytes, dout, sink);
+    run<65, 6>("weight loads only, two waves per SIMD", w, wbytes, dout, sink);
+    run<79, 6>("everything, independent accumulators, two waves per SIMD", w, wbytes, dout, sink);
+    return 0;
+}
