@@ -86,7 +86,10 @@ def test_full_batch_properties(model, y_dim):
     g3 = [p.grad for p in m.parameters() if p.grad is not None]
     for a, b in zip(g1, g3):
         scale = float(a.abs().max()) + 1e-30
-        assert float((3.0 * a - b).abs().max()) <= 2e-5 * 3 * scale       # split-K atomics reorder sums
+        # the whole-model path splits the (scaled) upstream gradient into bf16 planes anew: two evaluations, each within 7.8e-5 of the
+        # exact gradient (profiles/r03_parity.json), differ by up to 6.6e-5 of the tensor's maximum (measured, M2_info); the per-layer
+        # path's split-K atomics reorder sums (2e-5)
+        assert float((3.0 * a - b).abs().max()) <= 4e-5 * 3 * scale
     assert all(torch.isfinite(g).all() for g in g3)
 
 
