@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PLANE_STRIDE
-#define PLANE_STRIDE (1048576u + 4352u)
+#define PLANE_STRIDE (2u * 1048576u + 4352u)
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -30,10 +30,15 @@ __global__ __launch_bounds__(512, 1) void kstep_kernel(const void* __restrict__ 
     // LDS image: 32 frames x 552 columns x 2 planes of bf16 (as U of the rows kernel)
     for (int i = threadIdx.x; i < 2 * 32 * 552 / 2; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = 0x3f803f80u + i;
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, (int)wbytes, 0x00020000);
-    const int voff = lane * 16;
+    // MODE & 256: the per-lane offset (lane * 16) comes from the buffer descriptor (ADD_TID_ENABLE, stride 16) instead of a VGPR
+    constexpr bool TID = MODE & 256;
+    // (with ADD_TID_ENABLE the DATA_FORMAT field of word 3 is read as stride bits 17:14: it must be zero, or lane 63 lands 4 MB away)
+    const __amdgpu_buffer_rsrc_t rs = TID ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 16, (int)wbytes, (1 << 23))
+                                          : __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, (int)wbytes, 0x00020000);
+    const int voff = TID ? 0 : lane * 16;
     // fragment (tile = wave & 3, k-step s): byte offset ((s * 4 + tile) * 1024), lo plane at + wbytes / 2
-    const unsigned tile_off = (unsigned)(wave & 3) * 1024u;
+    // second wave of a SIMD (waves 4-7): its own fragments, 216 k-steps further on (never the lines its partner has just pulled into L1)
+    const unsigned tile_off = (unsigned)(wave & 3) * 1024u + (unsigned)(wave >> 2) * 216u * 4096u;
     const unsigned plane = PLANE_STRIDE;                          // not a power of two (as the kernel's weight-copy planes)
     const unsigned span = 216u;                                   // k-steps before wrapping: the 216 k-steps of a tile (0.86 MB per plane)
     bf16x8 ring[D][2];
@@ -142,9 +147,10 @@ static void run(const char* name, const void* w, unsigned wbytes, unsigned long 
 }
 
 int main() {
-    const unsigned wbytes = 2u * PLANE_STRIDE;                         // two planes of 216 k-steps x 4 tiles x 1 KB, L2-resident
+    const unsigned wbytes = 2u * PLANE_STRIDE;                         // two planes of 2 x 216 k-steps x 4 tiles x 1 KB, L2-resident
     void* w; unsigned long long* dout; float* sink;
-    CK(hipMalloc(&w, wbytes)); CK(hipMemset(w, 0x3f, wbytes));
+    CK(hipMalloc(&w, 16 * (size_t)wbytes)); CK(hipMemset(w, 0x3f, 16 * (size_t)wbytes));      // slack: whatever a descriptor variant makes of the range, it stays inside
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     CK(hipMalloc(&dout, sizeof(unsigned long long) * 1024)); CK(hipMalloc(&sink, 64));
     // warm the clocks
     for (int i = 0; i < 30; ++i) run<7, 6>("warm-up", w, wbytes, dout, sink);
@@ -164,6 +170,8 @@ int main() {
     run<7, 12>("everything", w, wbytes, dout, sink);
     run<130, 6>("LDS operand reads only, as 8-byte reads", w, wbytes, dout, sink);
     run<135, 6>("everything, LDS operand as 8-byte reads", w, wbytes, dout, sink);
+    run<257, 6>("weight loads only, lane offset from the descriptor (add-tid)", w, wbytes, dout, sink);
+    run<263, 6>("everything, lane offset from the descriptor (add-tid)", w, wbytes, dout, sink);
     run<15, 6>("everything, independent accumulators", w, wbytes, dout, sink);
     run<23, 6>("everything, 16x16x32 MFMAs", w, wbytes, dout, sink);
     run<39, 6>("everything, ONE weight plane (1 KB per k-step)", w, wbytes, dout, sink);
