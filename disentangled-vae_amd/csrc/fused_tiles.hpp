@@ -323,6 +323,22 @@ __device__ __forceinline__ void gemm_resident(f32x16& acc, const typename P::Fra
     }
 }
 
+// the same with every operand plane of the policy (split bf16: resident hi / lo fragments, three MFMAs per k-step)
+template <typename P, int NSTEPS>
+__device__ __forceinline__ void gemm_resident_p(f32x16& acc, const typename P::Frag (&w)[NSTEPS][P::NP], const typename P::T* brow) {
+    typedef typename P::Frag Frag;
+    constexpr int STR = 2 * P::E;
+    constexpr int BD = NSTEPS < 4 ? NSTEPS : 4;
+    Frag bq[BD][P::NP];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) bloadp<P>(bq[i], brow + i * STR);
+#pragma unroll
+    for (int i = 0; i < NSTEPS; ++i) {
+        mmap<P>(acc, w[i], bq[i % BD]);
+        if (i + BD < NSTEPS) bloadp<P>(bq[i % BD], brow + (i + BD) * STR);
+    }
+}
+
 template <typename P> __device__ __forceinline__ void zero_acc(f32x16& a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = 0.f;

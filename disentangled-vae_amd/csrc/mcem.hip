@@ -37,6 +37,7 @@ struct MhArgs {
     float sd;
     const void* wcopy; int64_t wcopy_bytes;
     int64_t oW3, oW4, oW5;     // element offsets of the fragment-major copies
+    unsigned wpl;              // bytes between the hi and lo planes of the copies (split-bf16 policy)
     const float* bias;         // b3[128] b4[128] b5[544]
 };
 
@@ -44,8 +45,9 @@ template <typename T> struct MhLds {
     static constexpr int per16 = 16 / (int)sizeof(T);
     static constexpr int hh = HD + per16, z = 32 + per16;
     static constexpr int nbias = 2 * HD + NO;
-    static constexpr size_t bytes(int yp) {
-        return (size_t)TB * (2 * hh + z + (yp ? yp + per16 : 0)) * sizeof(T) + (size_t)nbias * sizeof(float) + 64;
+    static constexpr int plane(int yp) { return TB * (2 * hh + z + (yp ? yp + per16 : 0)); }      // elements of one operand plane
+    static constexpr size_t bytes(int yp, int np = 1) {
+        return (size_t)plane(yp) * np * sizeof(T) + (size_t)nbias * sizeof(float) + 64;
     }
 };
 
@@ -70,6 +72,12 @@ struct PolF32Deep : PolF32 {
 
 struct PolF32Lean : PolF32Deep { static constexpr int PD = 6; static constexpr int PRE = 2; };
 
+// Split-bf16 chain policy (DVAE_PREC_BF16X3): every operand a (hi, lo) pair of bf16 planes, three MFMAs per product -- 16 mantissa
+// bits at 3/16 of the exact-fp32 matrix cost (the train step's parity-grade policy, fused_tiles.hpp).  Streaming variant (RES 0); the
+// lo planes of the LDS activation buffers sit one MhLds plane above the hi planes, those of the weight copies MhArgs::wpl bytes up.
+template <int YP> struct PolX3M : PolX3 { static constexpr int PD = 6; static constexpr int PRE = 2; };
+template <int YP> struct Pl<PolX3M<YP>> { static constexpr int lds = MhLds<__bf16>::plane(YP); };
+
 // Workgroups per CU the fp32 chain kernel is compiled for.  3 caps it at 168 registers (29 - 37 of them spill to scratch); 2 gives it 256
 // and no spill.  Measured (round 3, same box, alternating; tools/bench_mcem.py): E-step of one utterance 1027 us either way, 25 utterances
 // side by side 161 - 162 (3) against 154 - 161 (2) utterances / s: the spilled values are touched once per chain step, the third
@@ -78,17 +86,18 @@ struct PolF32Lean : PolF32Deep { static constexpr int PD = 6; static constexpr i
 #define MCEM_OCC 3
 #endif
 template <typename P, int YP, int RES>
-__global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(const MhArgs g) {
+__global__ __launch_bounds__(256, RES == 0 ? (P::NP == 2 ? 2 : MCEM_OCC) : 1) void mcem_mh_kernel(const MhArgs g) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP;
     constexpr int LDH = MhLds<T>::hh, LDZ = MhLds<T>::z, LDY = YP + MhLds<T>::per16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(P::NP == 1 || RES == 0, "the split-bf16 chain streams its weights");
     T* Ha = reinterpret_cast<T*>(smem);
     T* Hb = Ha + TB * LDH;
     T* Zb = Hb + TB * LDH;
     T* Yb = Zb + TB * LDZ;
-    float* Bias = reinterpret_cast<float*>(Yb + (YP ? TB * LDY : 0));
+    float* Bias = reinterpret_cast<float*>(Ha + MhLds<T>::plane(YP) * P::NP);       // behind the operand plane(s)
     constexpr int OB3 = 0, OB4 = HD, OB5 = 2 * HD;
     __shared__ double red[4][32];
 
@@ -101,10 +110,10 @@ __global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(c
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     constexpr unsigned S4 = 4 * FB * SZ, S17 = NT_OUT * FB * SZ, TSTEP = FB * SZ;
     constexpr unsigned KB3 = (ZD / KS) * 4 * FB * SZ;
-    const WRef W3r{lane * 16, (unsigned)(g.oW3 * SZ) + (unsigned)wave_u * TSTEP};
-    const WRef W4r{lane * 16, (unsigned)(g.oW4 * SZ) + (unsigned)wave_u * TSTEP};
-    const WRef W5r{lane * 16, (unsigned)(g.oW5 * SZ)};
-    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes}; };
+    const WRef W3r{lane * 16, (unsigned)(g.oW3 * SZ) + (unsigned)wave_u * TSTEP, g.wpl};
+    const WRef W4r{lane * 16, (unsigned)(g.oW4 * SZ) + (unsigned)wave_u * TSTEP, g.wpl};
+    const WRef W5r{lane * 16, (unsigned)(g.oW5 * SZ), g.wpl};
+    auto woff = [](WRef r, unsigned bytes) { return WRef{r.voff, r.soff + bytes, r.pl}; };
     const T* const Har = Ha + l31 * LDH + h * E;
     const T* const Hbr = Hb + l31 * LDH + h * E;
     const T* const Zbr = Zb + l31 * LDZ + h * E;
@@ -113,9 +122,9 @@ __global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(c
     for (int i = tid; i < MhLds<T>::nbias; i += 256) Bias[i] = g.bias[i];
     // resident weight fragments of this wave
     constexpr int NT5 = (NT_OUT + 3) / 4;                      // output tiles per wave (wave 0: 5, others 4)
-    Frag w3zR[ZD / KS], w4R[RES >= 1 ? HD / KS : 1], w5R[RES == 2 ? NT5 : 1][HD / KS];
+    Frag w3zR[ZD / KS][P::NP], w4R[RES >= 1 ? HD / KS : 1], w5R[RES == 2 ? NT5 : 1][HD / KS];
 #pragma unroll
-    for (int i = 0; i < ZD / KS; ++i) w3zR[i] = wload<P>(wrs, W3r, i * S4);
+    for (int i = 0; i < ZD / KS; ++i) wloadp<P>(w3zR[i], wrs, W3r, i * S4);
     if constexpr (RES >= 1) {
 #pragma unroll
         for (int i = 0; i < HD / KS; ++i) w4R[i] = wload<P>(wrs, W4r, i * S4);
@@ -145,7 +154,9 @@ __global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(c
                 const int f = idx >> 5, fr = idx & 31;          // consecutive threads: consecutive frames of one label row
                 float v = 0.f;
                 if (f < g.ydim && n0 + fr < g.N) v = g.y[(int64_t)f * g.N + n0 + fr];
-                Yb[fr * LDY + f] = P::cvt(v);
+                const T hi = P::cvt(v);
+                Yb[fr * LDY + f] = hi;
+                if constexpr (P::NP == 2) Yb[Pl<P>::lds + fr * LDY + f] = P::cvt(v - (float)hi);
             }
             __syncthreads();
             f32x16 acc;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(c
         auto decode = [&](auto&& epi_pre, auto&& epi) {
             f32x16 acc;
             zero_acc<P>(acc);
-            gemm_resident<P, ZD / KS>(acc, w3zR, Zbr);
+            gemm_resident_p<P, ZD / KS>(acc, w3zR, Zbr);
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + c1[r]);
@@ -326,8 +337,9 @@ __global__ __launch_bounds__(256, RES == 0 ? MCEM_OCC : 1) void mcem_mh_kernel(c
 
 // ---------------------------------------------------------------------------------------------
 // weight pack: nn.Linear [rows][ld] fp32 -> fragment-major [k-step][row tile][lane][E] copy
+// dst_lo (optional): the lo plane of the split-bf16 policy, what the first plane's rounding left
 template <typename T>
-__global__ void mcem_pack_kernel(const float* __restrict__ src, int rows, int cols, int ld, T* __restrict__ dst, int nt, int ksteps) {
+__global__ void mcem_pack_kernel(const float* __restrict__ src, int rows, int cols, int ld, T* __restrict__ dst, int nt, int ksteps, T* __restrict__ dst_lo = nullptr) {
     constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
     const int64_t total = (int64_t)ksteps * nt * 64 * E;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -337,7 +349,9 @@ __global__ void mcem_pack_kernel(const float* __restrict__ src, int rows, int co
         const int ks = (int)(i / ((int64_t)64 * E * nt));
         const int row = 32 * tile + (ln & 31), col = ks * KS + (ln >> 5) * E + e;
         const float v = (row < rows && col < cols) ? src[(int64_t)row * ld + col] : 0.f;
-        dst[i] = (T)v;
+        const T hi = (T)v;
+        dst[i] = hi;
+        if (dst_lo) dst_lo[i] = (T)(v - (float)hi);
     }
 }
 
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(256) void wiener_kernel(const float* __restrict__ V
 struct McemLayout { int yp, ld3; int64_t oW3, oW4, oW5, elems, bias_off_bytes, total_bytes; };
 static McemLayout mcem_layout(int y_dim, int precision) {
     McemLayout L;
-    const int esz = precision == DVAE_PREC_BF16 ? 2 : 4;
+    const int esz = precision == DVAE_PREC_F32 ? 4 : (precision == DVAE_PREC_BF16X3 ? 4 : 2);      // bytes per element over all planes
     L.yp = y_dim == 0 ? 0 : (y_dim + 15) / 16 * 16;
     L.ld3 = ZD + L.yp;
     L.oW3 = 0;
@@ -574,7 +588,7 @@ static McemLayout mcem_layout(int y_dim, int precision) {
 
 template <typename P, int YP, int RES>
 static int launch_mh(const MhArgs& a, hipStream_t s) {
-    const size_t lds = MhLds<typename P::T>::bytes(YP);
+    const size_t lds = MhLds<typename P::T>::bytes(YP, P::NP);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)mcem_mh_kernel<P, YP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -594,6 +608,12 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     a.oW3 = L.oW3; a.oW4 = L.oW4; a.oW5 = L.oW5;
     a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
     const bool bf = plan->precision == DVAE_PREC_BF16;
+    a.wpl = plan->precision == DVAE_PREC_BF16X3 ? (unsigned)(L.elems * 2) : 0u;
+    if (plan->precision == DVAE_PREC_BF16X3) {       // split bf16: streaming, like the fp32 chain
+        if (L.yp == 0) return launch_mh<PolX3M<0>, 0, 0>(a, s);
+        if (L.yp == 16) return launch_mh<PolX3M<16>, 16, 0>(a, s);
+        if (L.yp == 528) return launch_mh<PolX3M<528>, 528, 0>(a, s);
+    }
     // fp32: lean streaming variant (168 VGPRs, 3 workgroups per CU co-resident: 3.2 us per tile and chain at >= 768
     // tiles against 4.3 us with resident layers 1-2 at one workgroup per CU; equal at <= 256 tiles).
     // bf16: layers 1-2 resident (1.11 us per tile against 1.18 us).  Measured with tools/exp_mcem_occupancy.py.
@@ -613,7 +633,7 @@ using namespace dvae::fused;
 extern "C" int dvae_mcem_plan(int y_dim, int precision, dvae_mcem_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr, "mcem_plan: null plan");
     DVAE_CHECK_ARG(y_dim == 0 || (y_dim >= 1 && y_dim <= 16) || y_dim == XD, "mcem_plan: y_dim %d not supported (0, 1..16, 513)", y_dim);
-    DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16, "mcem_plan: bad precision %d", precision);
+    DVAE_CHECK_ARG(precision == DVAE_PREC_F32 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_BF16X3, "mcem_plan: bad precision %d", precision);
     const McemLayout L = mcem_layout(y_dim, precision);
     memset(plan, 0, sizeof(*plan));
     plan->y_dim = y_dim; plan->precision = precision; plan->x_dim = XD; plan->z_dim = ZD; plan->h_dim = HD;
@@ -627,16 +647,17 @@ extern "C" int dvae_mcem_pack(const dvae_mcem_plan_t* plan, const float* W3, int
     DVAE_CHECK_ARG(ld3 >= ZD + plan->y_dim && ld4 >= HD && ld5 >= HD, "mcem_pack: row strides too small");
     const McemLayout L = mcem_layout(plan->y_dim, plan->precision);
     hipStream_t s = (hipStream_t)stream;
-    if (plan->precision == DVAE_PREC_BF16) {
+    if (plan->precision == DVAE_PREC_BF16 || plan->precision == DVAE_PREC_BF16X3) {
         __bf16* w = (__bf16*)weights;
-        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, s, W3, HD, ZD + plan->y_dim, ld3, w + L.oW3, 4, L.ld3 / 16);
-        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, s, W4, HD, HD, ld4, w + L.oW4, 4, HD / 16);
-        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(128), dim3(256), 0, s, W5, XD, HD, ld5, w + L.oW5, NT_OUT, HD / 16);
+        __bf16* const lo = plan->precision == DVAE_PREC_BF16X3 ? w + L.elems : nullptr;       // second plane right behind the first
+        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, s, W3, HD, ZD + plan->y_dim, ld3, w + L.oW3, 4, L.ld3 / 16, lo ? lo + L.oW3 : nullptr);
+        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(64), dim3(256), 0, s, W4, HD, HD, ld4, w + L.oW4, 4, HD / 16, lo ? lo + L.oW4 : nullptr);
+        hipLaunchKernelGGL(mcem_pack_kernel<__bf16>, dim3(128), dim3(256), 0, s, W5, XD, HD, ld5, w + L.oW5, NT_OUT, HD / 16, lo ? lo + L.oW5 : nullptr);
     } else {
         float* w = (float*)weights;
-        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(64), dim3(256), 0, s, W3, HD, ZD + plan->y_dim, ld3, w + L.oW3, 4, L.ld3 / 8);
-        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(64), dim3(256), 0, s, W4, HD, HD, ld4, w + L.oW4, 4, HD / 8);
-        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(128), dim3(256), 0, s, W5, XD, HD, ld5, w + L.oW5, NT_OUT, HD / 8);
+        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(64), dim3(256), 0, s, W3, HD, ZD + plan->y_dim, ld3, w + L.oW3, 4, L.ld3 / 8, (float*)nullptr);
+        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(64), dim3(256), 0, s, W4, HD, HD, ld4, w + L.oW4, 4, HD / 8, (float*)nullptr);
+        hipLaunchKernelGGL(mcem_pack_kernel<float>, dim3(128), dim3(256), 0, s, W5, XD, HD, ld5, w + L.oW5, NT_OUT, HD / 8, (float*)nullptr);
     }
     hipLaunchKernelGGL(mcem_bias_kernel, dim3(1), dim3(256), 0, s, b3, b4, b5, (float*)((char*)weights + L.bias_off_bytes));
     DVAE_LAUNCH_OK("mcem_pack");

@@ -12,7 +12,7 @@ import torch
 from . import native as N
 
 F_BINS, Z_DIM, H_DIM = 513, 16, 128
-PREC = {"fp32": 0, "bf16": 1}
+PREC = {"fp32": 0, "bf16": 1, "bf16x3": 2}      # bf16x3: split-bf16 operands (hi + lo planes, three MFMAs per product): parity grade
 
 
 class McemPlan(ctypes.Structure):

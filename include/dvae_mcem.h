@@ -23,7 +23,8 @@ extern "C" {
 
 typedef struct {
     int32_t y_dim;            /* label rows fed to the decoder next to z: 0 (MCEM_M1), 1..16 or 513 */
-    int32_t precision;        /* DVAE_PREC_F32 (parity mode) or DVAE_PREC_BF16 (matrix-core operands in bf16) */
+    int32_t precision;        /* DVAE_PREC_F32 (exact fp32 products), DVAE_PREC_BF16X3 (split-bf16 operands: 16 mantissa bits, three MFMAs
+                                 per product -- parity grade at a fraction of the fp32 matrix cost) or DVAE_PREC_BF16 (one bf16 per operand) */
     int32_t x_dim, z_dim, h_dim;   /* echoed: 513, 16, 128 */
     int32_t reserved;
     int64_t weights_bytes;    /* size of the kernel-layout decoder copy filled by dvae_mcem_pack */

@@ -52,9 +52,11 @@ def chains_agree(accd, trace_a):
     return first
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("model,y_dim,N", [("M1", 0, 45), ("M2", 1, 70), ("M2", 513, 33), ("M2_info", 1, 100)])
-def test_sample_posterior_matches_oracle(model, y_dim, N):
-    params, prefix, pack, X2, y, Z, g, W, H, rng = setup(model, y_dim, N, 5)
+def test_sample_posterior_matches_oracle(model, y_dim, N, precision):
+    """fp32 = exact fp32 products; bf16x3 = split-bf16 operands (16 mantissa bits, three MFMAs per product): the same bounds."""
+    params, prefix, pack, X2, y, Z, g, W, H, rng = setup(model, y_dim, N, 5, precision=precision)
     nit, burnin = 12, 5
     noise = rng.standard_normal((nit, 16, N)).astype(np.float32)
     logu = np.log(rng.random((nit, N)).astype(np.float32))
@@ -104,12 +106,14 @@ def test_m_step_and_wiener_match_oracle(N, R, K):
     np.testing.assert_allclose((WFs + WFn).cpu().numpy(), 1.0, rtol=1e-5)        # the two gains partition the mixture
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", mc.CASES, ids=[c["name"] for c in mc.CASES])
-def test_full_run_matches_reference_golden(case):
-    """EM.run on the draws recorded from the reference: state after every iteration vs the reference's."""
+def test_full_run_matches_reference_golden(case, precision):
+    """EM.run on the draws recorded from the reference: state after every iteration vs the reference's (exact-fp32 and split-bf16
+    chain policies against the same bounds)."""
     fix = case_fix(case["name"])
     dims = mc.DIMS[case["model"]]
-    params, prefix, pack, *_ = setup(case["model"], dims["y_dim"], case["N"], case["seed"], case["wscale"])
+    params, prefix, pack, *_ = setup(case["model"], dims["y_dim"], case["N"], case["seed"], case["wscale"], precision=precision)
     X, S, y = mc.make_utterance(case)
     X2 = t((np.abs(X) ** 2).astype(np.float32))
     yd = t(y) if case["model"] != "M1" else None

