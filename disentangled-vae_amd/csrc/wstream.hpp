@@ -118,6 +118,18 @@ template <typename P, typename SC, int D> struct WStream {
             r[Q % D][1] = __builtin_bit_cast(typename P::Frag, v1);
         }
     }
+    // the next position of segment S (not its first) into ring slot SLOT: the request of a rolled lap of gemm_seg, where the position
+    // is a run-time quantity but the segment, the stride and the slot are not
+    template <int S, int SLOT> __device__ __forceinline__ void req_next() {
+        cur += SC::stride(S);
+        asm volatile("" : "+s"(cur));
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur, R2_WAUX);
+        r[SLOT][0] = __builtin_bit_cast(typename P::Frag, v0);
+        if constexpr (P::NP == 2) {
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur + pl, R2_WAUX);
+            r[SLOT][1] = __builtin_bit_cast(typename P::Frag, v1);
+        }
+    }
     __device__ __forceinline__ void fill() {
         static_for<0, (D < SC::total ? D : SC::total)>([&](auto ic) { this->template req<decltype(ic)::value>(); });
         __builtin_amdgcn_sched_barrier(0);
@@ -137,7 +149,44 @@ __device__ __forceinline__ void gemm_seg(f32x16& acc, WS& w, const typename P::T
 #pragma unroll
             for (int i = 0; i < BD; ++i) bloadp<P>(bq[i], brow + i * STR);
         }
-        static_for<0, N>([&](auto ic) {
+        // R2_ROLL=1 (experiment, off): long segments run the k-steps whose request (position + D) stays inside the segment as a ROLLED
+        // loop of ring laps -- the same D k-steps of code executed NL times.  Motive: the kernel's straight-line code (~110 KB) does not fit
+        // the 64 KB instruction cache two CUs share and a tile executes every k-step's code once (tools/r03/kstep_bench.hip: 145 -> 168
+        // clocks per k-step with the instruction cache invalidated every 18 k-steps).  Same operations in the same order (the fused tests
+        // pass bit for bit).  Measured, same box, alternating: 75.9 / 76.6 / 76.9 against 78.0 / 76.9 / 77.6 us per step, per-workgroup
+        // median 39.3 against 39.0 us, L1 x GEMM 3.12 against 3.32 us, L1 y phase 5.44 against 5.24: no gain beyond the noise, with
+        // 258 instead of 96 SGPR spills and 2 VGPR spills -- instruction fetch is not what separates the kernel's 100 ns k-step from
+        // the micro-benchmark's 72.
+#ifndef R2_ROLL
+#define R2_ROLL 0
+#endif
+        constexpr int NL = (R2_ROLL && D % BD == 0 && N >= 3 * D) ? (N - D) / D : 0;     // laps (at least two)
+        constexpr int NR = NL * D;                                                  // k-steps of the rolled part
+        if constexpr (NL > 0) {
+            const typename P::T* bl = brow;
+#pragma unroll 1
+            for (int lap = 0; lap < NL; ++lap) {
+                static_for<0, D>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if (active) {
+#ifndef R2_NOMFMA
+                        mmap<P>(acc, w.r[(Q0 + i) % D], bq[i % BD], blo);
+#else
+                        acc[0] += (float)w.r[(Q0 + i) % D][0][0] + (float)bq[i % BD][0][0];
+#endif
+#ifndef R2_NOBLOAD
+                        bloadp<P>(bq[i % BD], bl + (i + BD) * STR);                 // (lap * D + i + BD) < N: NR + BD - 1 <= N - 1
+#endif
+                    }
+#ifndef R2_NOWLOAD
+                    w.template req_next<S, (Q0 + i) % D>();                        // position Q0 + lap * D + i + D: inside segment S
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                bl += D * STR;
+            }
+        }
+        static_for<NR, N>([&](auto ic) {
             constexpr int I = decltype(ic)::value;
             if (active) {
 #ifndef R2_NOMFMA

@@ -44,6 +44,12 @@ __global__ __launch_bounds__(512, 1) void kstep_kernel(const void* __restrict__ 
     bf16x8 ring[D][2];
     auto wload = [&](int s, bf16x8 (&r)[2]) __attribute__((always_inline)) {
         const unsigned so = (unsigned)(s % (int)span) * 4096u + tile_off;
+        if constexpr (MODE & 512) {                                  // global_load_dwordx4 (scalar base + per-lane offset) instead of buffer loads
+            const char* base = reinterpret_cast<const char*>(w) + so;
+            r[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + lane * 16));
+            r[1] = ONEP ? r[0] : __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(base + plane + lane * 16));
+            return;
+        }
         r[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)so, 0));
         if (!ONEP) r[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(so + plane), 0));
         else r[1] = r[0];
@@ -82,8 +88,12 @@ __global__ __launch_bounds__(512, 1) void kstep_kernel(const void* __restrict__ 
     __builtin_amdgcn_s_barrier();
     const unsigned long long t0 = wall_clock64();
     const unsigned long long c0 = clock64();
+    // MODE & 1024: the instruction cache is invalidated before every lap of the loop (18 k-steps): every k-step's code comes from L2
+    // again -- the rows kernel's situation, whose 110 KB of straight-line code (every k-step of a tile its own piece of code, executed
+    // once per tile) does not fit the 64 KB instruction cache two CUs share
     constexpr int U = D * BD;                                     // unroll: both rings on compile-time indices
     for (int s0 = 0; s0 < nsteps; s0 += U) {
+        if constexpr (MODE & 1024) asm volatile("s_icache_inv" ::: "memory");
 #pragma unroll
         for (int ii = 0; ii < U; ++ii) {
             const int i = ii % D;
@@ -172,6 +182,10 @@ int main() {
     run<135, 6>("everything, LDS operand as 8-byte reads", w, wbytes, dout, sink);
     run<257, 6>("weight loads only, lane offset from the descriptor (add-tid)", w, wbytes, dout, sink);
     run<263, 6>("everything, lane offset from the descriptor (add-tid)", w, wbytes, dout, sink);
+    run<513, 6>("weight loads only, global_load instead of buffer_load", w, wbytes, dout, sink);
+    run<519, 6>("everything, global_load instead of buffer_load", w, wbytes, dout, sink);
+    run<1031, 6>("everything, instruction cache invalidated every 18 k-steps", w, wbytes, dout, sink);
+    run<1028, 6>("MFMAs only, instruction cache invalidated every 18 k-steps", w, wbytes, dout, sink);
     run<15, 6>("everything, independent accumulators", w, wbytes, dout, sink);
     run<23, 6>("everything, 16x16x32 MFMAs", w, wbytes, dout, sink);
     run<39, 6>("everything, ONE weight plane (1 KB per k-step)", w, wbytes, dout, sink);
