@@ -669,6 +669,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (src >= start) y[src - start] = 0.f;
 }
 
+// [513][ld] (bin-major rows, the legacy layout) -> [T][513] frame rows for the walk kernel: 64 x 64 tiles through LDS, 512-byte runs both ways
+constexpr int64_t ISTFT_TR_MIN_T = 1024;      // shorter spectrograms go through the staged kernel directly (a second launch costs more than it saves)
+__global__ __launch_bounds__(256) void c64_transpose_kernel(const float2* __restrict__ S, int64_t T, int64_t ld, float2* __restrict__ out) {
+    __shared__ float2 tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int b0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int b = b0 + ty + 4 * p;
+        if (b < 513 && t0 + tx < T) tile[ty + 4 * p][tx] = S[(int64_t)b * ld + t0 + tx];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int64_t t = t0 + ty + 4 * p;
+        if (t < T && b0 + tx < 513) out[t * 513 + b0 + tx] = tile[tx][ty + 4 * p];
+    }
+}
+
 template <int IF_FR, int NPASS, bool TF>
 static int launch_istft_fused(const float2* S, int64_t T, int64_t ld, const double* window, int64_t start, float* y, int64_t out_len, hipStream_t s) {
     typedef IstftFusedLds<IF_FR, NPASS> LT;
@@ -850,7 +870,8 @@ extern "C" size_t dvae_istft_workspace_bytes(int64_t T, int nfft) {
 
 // the 1024 / 256 transform (every caller of the reference) runs as one kernel and needs no frame scratch
 extern "C" size_t dvae_istft_workspace_bytes_hop(int64_t T, int nfft, int hop) {
-    if (nfft == 1024 && hop == 256 && getenv("DVAE_STFT_LEGACY") == nullptr && getenv("DVAE_ISTFT_2PASS") == nullptr) return 16;
+    if (nfft == 1024 && hop == 256 && getenv("DVAE_STFT_LEGACY") == nullptr && getenv("DVAE_ISTFT_2PASS") == nullptr)
+        return T >= ISTFT_TR_MIN_T ? (size_t)T * 513 * sizeof(float2) + 16 : 16;      // long bin-major input: its frame-major copy
     return dvae_istft_workspace_bytes(T, nfft);
 }
 
@@ -878,6 +899,18 @@ static int istft_run(const void* S, int64_t T, int64_t ld, bool tf, const double
             chunk = chunk < 1 ? 1 : chunk;
             const int wb = (int)cdiv(cdiv(T, chunk), 4);
             hipLaunchKernelGGL(istft1024_walk_kernel, dim3(wb), dim3(256), 0, s, (const float2*)S, T, ld, window, start, y, out_len, chunk);
+            DVAE_LAUNCH_OK("istft1024_walk_kernel");
+            return 0;
+        }
+        if (!tf && T >= ISTFT_TR_MIN_T && getenv("DVAE_ISTFT_STAGED") == nullptr) {
+            // long bin-major spectrograms: one transposing pass into the workspace, then the frame-major walk (ten minutes of audio:
+            // 88 + 81 us against the staged kernel's 207; the same arithmetic, bit-identical)
+            hipLaunchKernelGGL(c64_transpose_kernel, dim3((unsigned)cdiv(T, 64), 9), dim3(256), 0, s, (const float2*)S, T, ld, (float2*)ws);
+            DVAE_LAUNCH_OK("c64_transpose_kernel");
+            int chunk = (int)cdiv(T, 2048);
+            chunk = chunk < 1 ? 1 : chunk;
+            const int wb = (int)cdiv(cdiv(T, chunk), 4);
+            hipLaunchKernelGGL(istft1024_walk_kernel, dim3(wb), dim3(256), 0, s, (const float2*)ws, T, (int64_t)513, window, start, y, out_len, chunk);
             DVAE_LAUNCH_OK("istft1024_walk_kernel");
             return 0;
         }

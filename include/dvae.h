@@ -160,8 +160,9 @@ int dvae_stft(const void* x, int in_f64, int64_t n, const double* window, int nf
  * y[out_len] float32 = overlap-add of window * irfft(S[:, t]) (float32 accumulation in frame
  * order, as librosa), divided by the window sum-square where it exceeds FLT_MIN, read from
  * sample `start` on, zero padded / trimmed to out_len.  ws: dvae_istft_workspace_bytes_hop(T, nfft, hop) bytes
- * (nfft 1024 / hop 256 -- every caller of the reference -- runs inverse FFT and overlap-add in one kernel and
- * needs no frame scratch: 16; otherwise T * nfft doubles, which dvae_istft_workspace_bytes(T, nfft) always returns). */
+ * (nfft 1024 / hop 256 -- every caller of the reference -- runs inverse FFT and overlap-add in one kernel: 16 bytes below 1024
+ * frames, T * 513 complex64 from there on (dvae_istft transposes long bin-major input into it and runs the frame-major walk);
+ * otherwise T * nfft doubles, which dvae_istft_workspace_bytes(T, nfft) always returns). */
 size_t dvae_istft_workspace_bytes(int64_t T, int nfft);
 size_t dvae_istft_workspace_bytes_hop(int64_t T, int nfft, int hop);
 int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int nfft, int hop,

@@ -214,8 +214,10 @@ def test_istft_of_frame_major_input_equals_bin_major_bitwise(T):
     os.environ["DVAE_ISTFT_STAGED"] = "1"
     try:
         got_staged = H.istft_device(rows.T, w, 1024, 256, T, 0, ntot + 300)       # the LDS-staged kernel reading frame-major rows
+        ref_staged = H.istft_device(S_ft, w, 1024, 256, T, 0, ntot + 300)         # ... and bin-major rows (T >= 1024 otherwise transposes + walks)
     finally:
         del os.environ["DVAE_ISTFT_STAGED"]
+    assert torch.equal(ref.view(torch.int32), ref_staged.view(torch.int32))
     wide = torch.zeros((T, 520), dtype=torch.complex64, device="cuda")
     wide[:, :513] = rows
     got_wide = H.istft_device(wide[:, :513].T, w, 1024, 256, T, 0, ntot + 300)
