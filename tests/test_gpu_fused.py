@@ -279,6 +279,33 @@ def test_direct_exchange_equals_the_process_group_exchange(model, y_dim, precisi
             np.testing.assert_array_equal(got["direct"][r][1][k], got["rccl"][r][1][k], err_msg=k)
 
 
+def test_direct_exchange_at_four_ranks():
+    """World 4 (four processes on the one GPU): the reduce-scatter shards, the pull order and the all-gather of dvae_allreduce_flat beyond
+    two ranks.  The direct path adds the ranks' slab sums in rank order, gloo in its own: parameters after two steps agree to the Adam
+    noise of a re-ordered fp32 sum (every replica identical within a run; no bounded wait expired)."""
+    import torch.multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    got = {}
+    for exchange in ("direct", "rccl"):
+        q = ctx.Queue()
+        port = 33000 + (os.getpid() + (7 if exchange == "direct" else 0)) % 2000
+        procs = [ctx.Process(target=_dp_worker, args=(r, 4, port, q, "M2", 513, "bf16x3", exchange)) for r in range(4)]
+        for pr in procs:
+            pr.start()
+        res = sorted([q.get(timeout=400) for _ in procs], key=lambda t: t[0])
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+        got[exchange] = res
+    for r in range(4):
+        assert got["direct"][r][4] and not got["direct"][r][3]
+        for k in got["rccl"][0][1]:
+            np.testing.assert_array_equal(got["direct"][r][1][k], got["direct"][0][1][k], err_msg=k)      # replicas identical
+            d = np.abs(got["direct"][r][1][k] - got["rccl"][r][1][k])
+            assert d.max() <= 4.1e-4 and np.mean(d > 2e-6) < 0.02, (k, float(d.max()), float(np.mean(d > 2e-6)))
+
+
 class FusedInfoImpl(FusedImpl):
     """M2_info on the fused path: gradients of the enc_dec_clf group are what enc_loss.backward() leaves,
     gradients of the auxiliary group are the (gamma - beta) accumulation the second backward produces (quirk Q4)."""
