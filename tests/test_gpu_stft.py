@@ -235,3 +235,26 @@ def test_istft_of_frame_major_input_equals_bin_major_bitwise(T):
     y_f = ps.istft(np.asfortranarray(S), **kw)
     assert np.array_equal(y_c.view(np.uint32), y_f.view(np.uint32))
     assert np.array_equal(y_c.view(np.uint32), ref[:ntot].cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("T", [300, 1500])
+def test_istft_c_abi_with_a_padded_leading_dimension(T):
+    """dvae_istft on a [513, ldT] buffer with ldT > T (the first T columns are the frames): the staged kernel (T < 1024) and the
+    transposing pass + walk (T >= 1024) both honour the row stride -- same bits as the tightly packed spectrogram."""
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    N = importlib.import_module("disentangled-vae_amd.native")
+    lib = N.load()
+    rng = np.random.default_rng(T)
+    S = (rng.standard_normal((513, T)) + 1j * rng.standard_normal((513, T))).astype(np.complex64)
+    w = H.window_f64("hann", 1024, torch.device("cuda", 0))
+    ntot = 1024 + 256 * (T - 1)
+    tight = torch.from_numpy(S).cuda()
+    ref = H.istft_device(tight, w, 1024, 256, T, 0, ntot)
+    ld = T + 7
+    wide = torch.full((513, ld), complex(7.0, -3.0), dtype=torch.complex64, device="cuda")      # the padding must never be read as a frame
+    wide[:, :T] = tight
+    y = torch.empty(ntot, dtype=torch.float32, device="cuda")
+    ws = torch.empty(max(lib.dvae_istft_workspace_bytes_hop(T, 1024, 256), 16), dtype=torch.uint8, device="cuda")
+    N.check(lib.dvae_istft(N.ptr(wide), T, ld, N.ptr(w), 1024, 256, 0, N.ptr(y), ntot, N.ptr(ws), N.stream()), "dvae_istft")
+    assert torch.equal(ref.view(torch.int32), y.view(torch.int32))
