@@ -5,6 +5,7 @@ csrc/stft.hip through the C ABI.  No CPU transform exists here: without the
 library or a GPU these functions raise.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -83,11 +84,14 @@ def istft_device(S_dev, window, nfft, hop, n_frames, start, out_len):
     if not S_dev.is_cuda or S_dev.dtype != torch.complex64 or S_dev.dim() != 2 or S_dev.shape[0] != nfft // 2 + 1:
         raise TypeError("istft_device: complex64 [nfft/2+1, T] CUDA tensor required")
     y = torch.empty((out_len,), dtype=torch.float32, device=S_dev.device)
-    ws = torch.empty(max(lib.dvae_istft_workspace_bytes_hop(n_frames, nfft, hop), 16), dtype=torch.uint8, device=S_dev.device)
-    if S_dev.shape[1] > 1 and S_dev.stride(0) == 1 and S_dev.stride(1) >= S_dev.shape[0]:
+    if S_dev.shape[1] > 1 and S_dev.stride(0) == 1 and S_dev.stride(1) >= S_dev.shape[0] and nfft == 1024 and hop == 256:
+        # the frame-major walk needs no scratch; the A/B switches that route it to the two-pass kernels do (frames in double)
+        two_pass = os.environ.get("DVAE_STFT_LEGACY") is not None or os.environ.get("DVAE_ISTFT_2PASS") is not None
+        ws = torch.empty(max(lib.dvae_istft_workspace_bytes(n_frames, nfft), 16) if two_pass else 16, dtype=torch.uint8, device=S_dev.device)
         N.check(lib.dvae_istft_frames(N.ptr(S_dev), n_frames, S_dev.stride(1), N.ptr(window), nfft, hop, start, N.ptr(y), out_len,
                                       N.ptr(ws), N.stream()), "dvae_istft_frames")
         return y
+    ws = torch.empty(max(lib.dvae_istft_workspace_bytes_hop(n_frames, nfft, hop), 16), dtype=torch.uint8, device=S_dev.device)
     S_dev = S_dev.contiguous()
     N.check(lib.dvae_istft(N.ptr(S_dev), n_frames, S_dev.shape[1], N.ptr(window), nfft, hop, start, N.ptr(y), out_len,
                            N.ptr(ws), N.stream()), "dvae_istft")
