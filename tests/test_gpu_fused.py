@@ -347,7 +347,7 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
     # The classifier / auxiliary nets are ReLU MLPs: the reference's own gradient is discontinuous where a hidden
     # pre-activation is within rounding of zero, and a mask that flips in ONE frame moves ONE row of that layer's weight
     # gradient (and one bias element) by about one frame's contribution, ~1e-3 of the tensor's maximum at 8192 frames.
-    # tools/diag/info_rows.py: under bf16x3 every other row agrees to ~2e-6; the fp32 policy shows the same isolated rows
+    # tests/diag/info_rows.py: under bf16x3 every other row agrees to ~2e-6; the fp32 policy shows the same isolated rows
     # at other seeds (and the float32 and float64 oracles differ by up to 0.75 on the saturated classifier).  So: every
     # tensor within `tol` of its maximum except at most 2 rows per ReLU-net tensor, and those within 1e-2.
     worst_clean = 0.0

@@ -21,7 +21,7 @@ for ex in gloo direct; do
 done
 python tools/stamp_rows.py bf16x3 8192 > $O/stamps_bf16x3.txt 2>/dev/null
 DVAE_COLD=1 DVAE_HSTAMPS=1 python tools/stamp_rows.py bf16x3 8192 > $O/stamps_bf16x3_cold.txt 2>/dev/null
-python tools/r03/parity_report.py $O/parity.json > /dev/null 2>&1
+python tests/diag/parity_report.py $O/parity.json > /dev/null 2>&1
 else
 tools/pmc_collect.sh x3 --precision bf16x3 > $O/pmc_x3.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_x3 $O/pmc_M2_y513_B8192_bf16x3.json M2 513 8192 bf16x3 > $O/pmc_x3_summary.txt

@@ -2,8 +2,8 @@ cd $GRAFT_REPO_ROOT
 V=disentangled-vae_amd/build/variants; mkdir -p $V
 DVAE_CFLAGS="-DR2_STASH_SC=1" python disentangled-vae_amd/build.py --force > /dev/null 2>&1; cp disentangled-vae_amd/libdvae_hip.so $V/sc1.so
 DVAE_CFLAGS="-DR2_STASH_SC=0" python disentangled-vae_amd/build.py --force > /dev/null 2>&1; cp disentangled-vae_amd/libdvae_hip.so $V/sc0.so
-DVAE_LIB=$PWD/$V/sc0.so python tools/r03/sc_check2.py /tmp/sc0.npz 2>&1 | grep -v amdgpu
-DVAE_LIB=$PWD/$V/sc1.so python tools/r03/sc_check2.py /tmp/sc1.npz 2>&1 | grep -v amdgpu
+DVAE_LIB=$PWD/$V/sc0.so python tests/diag/sc_check2.py /tmp/sc0.npz 2>&1 | grep -v amdgpu
+DVAE_LIB=$PWD/$V/sc1.so python tests/diag/sc_check2.py /tmp/sc1.npz 2>&1 | grep -v amdgpu
 python - <<'PY'
 import numpy as np
 a=np.load('/tmp/sc0.npz'); b=np.load('/tmp/sc1.npz')
