@@ -16,5 +16,5 @@ cp $O/stft_stats/*/*kernel_stats.csv $O/stft_kernel_stats.csv 2>/dev/null
 cp $O/mcem_stats/*/*kernel_stats.csv $O/mcem_kernel_stats.csv 2>/dev/null
 python tools/r03/side_summary.py $O > $O/side_summary.json 2> $O/side_summary.err
 tail -c 3000 $O/side_summary.json
-# keep the merge-back small: drop the raw per-dispatch traces once summarised
-find $O -name "*kernel_trace.csv" -size +2M -delete
+# keep the merge-back small (gpurun merges at most 64 MiB): drop the raw per-dispatch traces and counter tables once summarised
+find $O \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*.db" \) -delete

@@ -25,7 +25,7 @@ for what in ("stft", "mcem"):
                 cnt[key][short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res = {}
     for k, v in dur.items():
-        if not any(s in k for s in ("stft", "mcem", "mstep", "wiener", "target", "frames")):
+        if not any(s in k for s in ("stft", "mcem", "mstep", "wiener", "target", "frames", "transpose")):
             continue
         e = {"launches": len(v), "avg_us": sum(v) / len(v), "max_us": max(v), "min_us": min(v)}
         if cnt["FETCH_SIZE"].get(k):
