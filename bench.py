@@ -55,9 +55,10 @@ def parse():
                     help="untimed train steps for this long BEFORE the W warmup steps, so that the K timed steps run at the clocks a training run "
                          "sees (from idle the shader clock needs tens of ms of load to settle: 20 steps right after 5 measure 87.6 us/step, "
                          "the same 20 steps after 200 ms of steps 80); reported as `prewarm_steps`; 0 disables")
-    ap.add_argument("--no-direct-trial", action="store_true",
-                    help="N > 1: skip the second timed region that runs the library's own gradient exchange (dvae_allreduce_flat) "
-                         "after the RCCL one (reported under multi_gpu.direct; the headline value is always the RCCL run)")
+    ap.add_argument("--direct-trial", action="store_true",
+                    help="N > 1, opt-in (also DVAE_BENCH_DIRECT_TRIAL=1): after the RCCL measurement, a second timed region with the library's own "
+                         "gradient exchange (dvae_allreduce_flat), reported under multi_gpu.direct; the headline value is always the RCCL run.  "
+                         "Off by default: the exchange is unmeasured on multi-GPU hardware and a device fault there would lose the headline line")
     return ap.parse_args()
 
 
@@ -271,10 +272,29 @@ def direct_trial(a, trainer_mod, dims, B, device, world, dist, batches, impl):
         rec.setdefault("error", "check: the exchanged vector differs from the process group's sum, or a wait ran out (on some rank)")
         dx.close()
         return rec
-    try:
+    impl2 = None
+    try:                                                 # a rank-local failure up to here must not leave the peers in timed_steps' barrier
         impl2 = trainer_mod.BenchImpl(a.model, dims, B, device, world, a.precision, ksplit=a.ksplit, direct_exchange=dx)
+        ok = True
+    except Exception as e:                              # noqa: BLE001
+        ok = False
+        rec["error"] = "trainer: " + str(e)
+    if not agree(ok):
+        rec.setdefault("error", "trainer: construction failed on some rank")
+        dx.close()
+        return rec
+    try:
         for i in range(max(a.warmup, 20)):
             impl2.step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        ok = not dx.failed()
+    except Exception as e:                              # noqa: BLE001
+        ok = False
+        rec["error"] = "warmup: " + str(e)
+    if not agree(ok):
+        rec.setdefault("error", "warmup: a step failed or a bounded wait ran out on some rank")
+        return rec
+    try:
         dt2, _ = timed_steps(impl2, batches, a.warmup, a.steps, dist, device)
         ok = not dx.failed()
         rec.update({"ms_per_step": 1e3 * dt2 / a.steps, "value": world * B * a.steps / dt2, "steps": a.steps, "wait_ran_out": not ok})
@@ -385,8 +405,8 @@ def main():
 
     prof = impl.kernel_profile(batches, min(a.steps, 50))
     direct_rec = None
-    if (world > 1 and impl_name == "fused" and not a.no_direct_trial and os.environ.get("DVAE_ALLREDUCE", "rccl") == "rccl"
-            and os.environ.get("DVAE_BENCH_DIRECT_TRIAL", "1") != "0"):
+    if (world > 1 and impl_name == "fused" and os.environ.get("DVAE_ALLREDUCE", "rccl") == "rccl"
+            and (a.direct_trial or os.environ.get("DVAE_BENCH_DIRECT_TRIAL", "0") == "1")):
         direct_rec = direct_trial(a, trainer_mod, dims, B, device, world, dist, batches, impl)
     key = (a.model, y_dim)
     out = {

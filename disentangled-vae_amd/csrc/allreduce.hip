@@ -13,12 +13,19 @@
 // On an 8-GPU node phase B reads 7 shards and writes 7 shards per rank, all over different xGMI links at once: 2 * 7/8 * 1.2 MB per rank
 // and two flag hops, against RCCL's generic ring / tree for a 1.2 MB message.
 //
-// No waiting on workgroups of the SAME rank anywhere (counters are only added to), so residency is not assumed.  Every wait on ANOTHER
-// rank is a bounded poll (s_sleep between system-scope loads): when a bound expires the launch sets header.status, stops waiting and
-// ends; the result is then undefined and dvae_comm_status() reports it -- a missing peer is an error code, never a hang.
+// Waits: phase B waits for `ready` == k * G of EVERY rank (its own included) and phase C for own `done` == k * G * world, so a launch
+// completes only once all G workgroups of every rank have run phase A and phase B -- the 64 workgroups of a rank need not be resident
+// TOGETHER (no workgroup waits for a counter only later workgroups of its own launch could raise before it has added to it itself),
+// but a rank whose launch is starved of CUs for longer than the bound (other streams or processes holding the chip) times out like a
+// missing peer.  Every wait is bounded by WALL TIME (s_memrealtime, 100 MHz; dvae_comm_set_timeout_ms, default 20 s, env
+// DVAE_COMM_TIMEOUT_MS): when the bound expires the launch stores a non-zero status into the header of EVERY rank, still adds to the
+// `done` counters (nobody waits a second bound for it) and ends; every rank that sees a non-zero status -- its own or a peer's -- fills
+// `out` with NaN, so the failure is in-band (the optimizer step that follows turns the parameters and every later loss into NaN) and
+// dvae_comm_status() reports it -- a missing or late peer is an error, never a hang and never a silently stale gradient.
 // Buffer reuse across calls: a rank leaves phase C only after every peer has finished reading its send[] (their `done` adds come
 // after their phase-B reads), and a peer starts pushing call k + 1 into recv[] only after this rank's phase A of call k + 1.
 #include <stdlib.h>
+#include <unistd.h>
 #include "common.hpp"
 #include "../../include/dvae_train.h"
 
@@ -30,6 +37,7 @@ constexpr int GRID = 64;          // workgroups per launch (also the unit of the
 constexpr int HDR = 256;          // header bytes
 
 struct Header { unsigned long long ready, done; unsigned status, pad; };
+constexpr unsigned long long TICKS_PER_MS = 100000ull;      // s_memrealtime: 100 MHz
 
 struct Peers { char* p[MAXW]; };
 
@@ -37,18 +45,19 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// bounded wait: true when *p reached `want`
-__device__ __forceinline__ bool wait_ge(const unsigned long long* p, unsigned long long want, long long max_polls) {
-    for (long long i = 0; i < max_polls; ++i) {
+// bounded wait: true when *p reached `want` before the wall clock passed `deadline` (at least one poll is always made)
+__device__ __forceinline__ bool wait_ge(const unsigned long long* p, unsigned long long want, unsigned long long deadline) {
+    for (;;) {
         if (ld_sys(p) >= want) return true;
+        if (__builtin_amdgcn_s_memrealtime() >= deadline) return false;
         __builtin_amdgcn_s_sleep(16);
     }
-    return false;
 }
 
 __global__ __launch_bounds__(256) void allreduce_kernel(Peers peers, int rank, int world, int64_t n, int64_t n_pad, int64_t shard,
                                                         const float* slabs, int n_slabs, int64_t slab_stride,
-                                                        float* out /* may alias slab 0: element i is read and written by the same thread */, unsigned long long call, long long max_polls) {
+                                                        float* out /* may alias slab 0: element i is read and written by the same thread */, unsigned long long call,
+                                                        unsigned long long timeout_ticks) {
     char* const me = peers.p[rank];
     Header* const hdr = reinterpret_cast<Header*>(me);
     // all exchange traffic moves as 8-byte granules (two floats) through system-scope accesses: n_pad is a multiple of 64
@@ -57,7 +66,12 @@ __global__ __launch_bounds__(256) void allreduce_kernel(Peers peers, int rank, i
     u64* const recv = send + n_pad / 2;
     const int64_t n2 = n_pad / 2;
     const int tid = threadIdx.x;
+    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + timeout_ticks;      // per workgroup, from its own start
     __shared__ int ok_s;
+    auto fail_everywhere = [&]() {                                        // the failure is every rank's: status into every header
+        for (int p = 0; p < world; ++p)
+            __hip_atomic_store(&reinterpret_cast<Header*>(peers.p[p])->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     auto pack = [](float a, float b) { return (u64)__float_as_uint(a) | ((u64)__float_as_uint(b) << 32); };
     auto slab_sum = [&](int64_t i) {
         if (i >= n) return 0.f;
@@ -75,8 +89,8 @@ __global__ __launch_bounds__(256) void allreduce_kernel(Peers peers, int rank, i
     if (tid == 0) {
         int ok = 1;
         for (int p = 0; p < world && ok; ++p)
-            ok = wait_ge(&reinterpret_cast<const Header*>(peers.p[p])->ready, call * (unsigned long long)gridDim.x, max_polls) ? 1 : 0;
-        if (!ok) __hip_atomic_store(&hdr->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = wait_ge(&reinterpret_cast<const Header*>(peers.p[p])->ready, call * (unsigned long long)gridDim.x, deadline) ? 1 : 0;
+        if (!ok) fail_everywhere();
         ok_s = ok;
     }
     __syncthreads();
@@ -103,14 +117,18 @@ __global__ __launch_bounds__(256) void allreduce_kernel(Peers peers, int rank, i
     // ---- C: every rank has pushed its shard into own recv[] -> out
     if (tid == 0) {
         int ok = ok_s;
-        if (ok) ok = wait_ge(&hdr->done, call * (unsigned long long)gridDim.x * (unsigned long long)world, max_polls) ? 1 : 0;
-        if (!ok) __hip_atomic_store(&hdr->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (ok) ok = wait_ge(&hdr->done, call * (unsigned long long)gridDim.x * (unsigned long long)world, deadline) ? 1 : 0;
+        if (!ok) fail_everywhere();
+        // a peer that gave up in phase B has stored its status here BEFORE its `done` adds (release), so it is visible now: its shard of
+        // recv[] is stale.  (The status word is sticky: once set, every later call of this communicator ends in NaN as well.)
+        if (__hip_atomic_load(&hdr->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ok = 0;
         ok_s = ok;
     }
     __syncthreads();
     __threadfence_system();
+    const bool good = ok_s != 0;
     for (int64_t j = (int64_t)blockIdx.x * 256 + tid; j < n2; j += (int64_t)gridDim.x * 256) {
-        const u64 t = __hip_atomic_load(recv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const u64 t = good ? __hip_atomic_load(recv + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0x7fc000007fc00000ull;
         if (2 * j < n) out[2 * j] = __uint_as_float((unsigned)t);
         if (2 * j + 1 < n) out[2 * j + 1] = __uint_as_float((unsigned)(t >> 32));
     }
@@ -129,8 +147,20 @@ struct dvae_comm {
     void* peer[MAXW];            // mapped peer buffers (peer[rank] == local)
     bool opened[MAXW];
     unsigned long long call;
-    long long max_polls;
+    unsigned long long timeout_ticks;
+    int device;
 };
+
+// What travels in the DVAE_IPC_HANDLE_BYTES of a rank: the hipIpc handle of its exchange buffer, then who and where it is -- the owning
+// process (several ranks hosted by ONE process connect through plain pointers: a process cannot open its own IPC handle) and the
+// device's PCI address (dvae_comm_connect checks peer access between the two devices before the first launch needs it).
+struct HandleBlob {
+    hipIpcMemHandle_t ipc;
+    long long pid;
+    void* local;                  // valid inside process `pid` only
+    int pci_domain, pci_bus, pci_device, pad;
+};
+static_assert(sizeof(HandleBlob) <= DVAE_IPC_HANDLE_BYTES, "handle blob size");
 
 static int64_t pad_n(int64_t n, int world, int64_t* shard) {
     int64_t s = (n + world - 1) / world;
@@ -139,41 +169,85 @@ static int64_t pad_n(int64_t n, int world, int64_t* shard) {
     return s * world;
 }
 
+static unsigned long long default_timeout_ticks() {
+    const char* ms = getenv("DVAE_COMM_TIMEOUT_MS");
+    long long v = ms ? atoll(ms) : 20000;            // generous: a peer may be checkpointing or validating; a dead peer still ends the launch
+    if (v < 0) v = 0;
+    return (unsigned long long)v * TICKS_PER_MS;
+}
+
 extern "C" int dvae_comm_create(int rank, int world, int64_t n_floats, dvae_comm_t** out, unsigned char handle[DVAE_IPC_HANDLE_BYTES]) {
     DVAE_CHECK_ARG(out && handle && world >= 1 && world <= MAXW && rank >= 0 && rank < world && n_floats > 0, "comm_create: bad argument");
-    static_assert(sizeof(hipIpcMemHandle_t) <= DVAE_IPC_HANDLE_BYTES, "IPC handle size");
     dvae_comm* c = (dvae_comm*)calloc(1, sizeof(dvae_comm));
     DVAE_CHECK_ARG(c != nullptr, "comm_create: out of host memory");
     c->rank = rank; c->world = world; c->n = n_floats;
     c->n_pad = pad_n(n_floats, world, &c->shard);
     const size_t bytes = (size_t)HDR + 2 * (size_t)c->n_pad * sizeof(float);
-    // fine-grained (coherent across devices inside a running kernel); plain hipMalloc memory is only coherent at kernel boundaries
-    hipError_t e = hipExtMallocWithFlags(&c->local, bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&c->local, bytes); }
-    if (e != hipSuccess) { free(c); set_error("comm_create: allocation of %zu B failed: %s", bytes, hipGetErrorString(e)); return (int)e; }
+    // Fine-grained memory only (coherent across devices INSIDE a running kernel).  Plain hipMalloc memory is coherent at kernel boundaries
+    // only: the in-kernel flag and shard reads of a peer could then see stale data and still pass the bounded waits, so there is no
+    // fallback -- a platform that cannot give fine-grained device memory gets an error here and keeps the process-group exchange.
+    hipError_t e = hipGetDevice(&c->device);
+    if (e == hipSuccess) e = hipExtMallocWithFlags(&c->local, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); free(c);
+        set_error("comm_create: no fine-grained device memory for the exchange buffer (%zu B): %s -- the direct exchange is unavailable, use the process group", bytes, hipGetErrorString(e));
+        return (int)e;
+    }
     e = hipMemset(c->local, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    hipIpcMemHandle_t h;
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, c->local);
+    HandleBlob hb;
+    memset(&hb, 0, sizeof(hb));
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&hb.ipc, c->local);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
     if (e != hipSuccess) { (void)hipFree(c->local); free(c); set_error("comm_create: %s", hipGetErrorString(e)); return (int)e; }
+    hb.pid = (long long)getpid(); hb.local = c->local;
+    hb.pci_domain = prop.pciDomainID; hb.pci_bus = prop.pciBusID; hb.pci_device = prop.pciDeviceID;
     memset(handle, 0, DVAE_IPC_HANDLE_BYTES);
-    memcpy(handle, &h, sizeof(h));
+    memcpy(handle, &hb, sizeof(hb));
     c->peer[rank] = c->local;
     c->call = 0;
-    const char* mp = getenv("DVAE_COMM_MAX_POLLS");
-    c->max_polls = mp ? atoll(mp) : (1ll << 19);          // 0.5 M polls of ~1000 clocks + one uncached load each: of the order of a second
+    c->timeout_ticks = default_timeout_ticks();
     *out = c;
+    return 0;
+}
+
+extern "C" int dvae_comm_set_timeout_ms(dvae_comm_t* c, int64_t ms) {
+    DVAE_CHECK_ARG(c && ms >= 0, "comm_set_timeout_ms: bad argument");
+    c->timeout_ticks = (unsigned long long)ms * TICKS_PER_MS;
     return 0;
 }
 
 extern "C" int dvae_comm_connect(dvae_comm_t* c, const unsigned char* handles /* world x DVAE_IPC_HANDLE_BYTES */) {
     DVAE_CHECK_ARG(c && handles, "comm_connect: bad argument");
+    int ndev = 0;
+    DVAE_HIP(hipGetDeviceCount(&ndev));
     for (int p = 0; p < c->world; ++p) {
         if (p == c->rank) continue;
-        hipIpcMemHandle_t h;
-        memcpy(&h, handles + (size_t)p * DVAE_IPC_HANDLE_BYTES, sizeof(h));
+        HandleBlob hb;
+        memcpy(&hb, handles + (size_t)p * DVAE_IPC_HANDLE_BYTES, sizeof(hb));
+        // the peer's device, if this process can see it: peer access must be possible before a kernel dereferences the mapping
+        int pdev = -1;
+        for (int d = 0; d < ndev && pdev < 0; ++d) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.pciDomainID == hb.pci_domain && pr.pciBusID == hb.pci_bus && pr.pciDeviceID == hb.pci_device) pdev = d;
+        }
+        if (pdev >= 0 && pdev != c->device) {
+            int can = 0;
+            DVAE_HIP(hipDeviceCanAccessPeer(&can, c->device, pdev));
+            DVAE_CHECK_ARG(can != 0, "comm_connect: device %d (rank %d) cannot access device %d (rank %d): no peer path between them", c->device, c->rank, pdev, p);
+        }
+        if (hb.pid == (long long)getpid()) {           // a rank hosted by this same process: its pointer is valid here as it is
+            if (pdev >= 0 && pdev != c->device) {
+                hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("comm_connect: hipDeviceEnablePeerAccess(%d): %s", pdev, hipGetErrorString(e)); return (int)e; }
+                (void)hipGetLastError();
+            }
+            c->peer[p] = hb.local; c->opened[p] = false;
+            continue;
+        }
         void* ptr = nullptr;
-        DVAE_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        DVAE_HIP(hipIpcOpenMemHandle(&ptr, hb.ipc, hipIpcMemLazyEnablePeerAccess));
         c->peer[p] = ptr; c->opened[p] = true;
     }
     return 0;
@@ -185,10 +259,10 @@ extern "C" int dvae_allreduce_flat(dvae_comm_t* c, const float* slabs, int n_sla
     Peers pr;
     memset(&pr, 0, sizeof(pr));
     for (int p = 0; p < c->world; ++p) pr.p[p] = (char*)c->peer[p];
-    c->call += 1;
     hipLaunchKernelGGL(allreduce_kernel, dim3(GRID), dim3(256), 0, (hipStream_t)stream, pr, c->rank, c->world, c->n, c->n_pad, c->shard,
-                       slabs, n_slabs, slab_stride, out, c->call, c->max_polls);
+                       slabs, n_slabs, slab_stride, out, c->call + 1, c->timeout_ticks);
     DVAE_LAUNCH_OK("allreduce_kernel");
+    c->call += 1;                                      // only a launch that was accepted counts: a failed one leaves the counters in step
     return 0;
 }
 
@@ -197,7 +271,7 @@ extern "C" int dvae_comm_status(dvae_comm_t* c, int* failed) {
     Header h;
     DVAE_HIP(hipMemcpy(&h, c->local, sizeof(h), hipMemcpyDeviceToHost));     // synchronises with the device
     *failed = h.status != 0 ? 1 : 0;
-    if (h.status) set_error("allreduce_flat: a bounded wait for a peer expired (rank %d of %d, call %llu)", c->rank, c->world, c->call);
+    if (h.status) set_error("allreduce_flat: a bounded wait for a peer expired on some rank (seen by rank %d of %d, call %llu): the reduced gradient was filled with NaN", c->rank, c->world, c->call);
     return 0;
 }
 

@@ -8,7 +8,7 @@ import os
 
 import torch.distributed as dist
 
-IPC_HANDLE_BYTES = 64          # include/dvae_train.h: DVAE_IPC_HANDLE_BYTES
+IPC_HANDLE_BYTES = 128         # include/dvae_train.h: DVAE_IPC_HANDLE_BYTES
 
 
 def shard_rows(global_rows, rank, world):
@@ -110,8 +110,14 @@ class DirectExchange:
         N.check(self.lib.dvae_allreduce_flat(self.handle, N.ptr(slabs), int(n_slabs), int(slab_stride), N.ptr(out), N.stream()),
                 "dvae_allreduce_flat")
 
+    def set_timeout_ms(self, ms):
+        """Wall-time bound of every in-kernel wait for a peer in the launches that follow (default 20 s, env DVAE_COMM_TIMEOUT_MS): generous
+        enough for a peer that checkpoints or validates between two steps, finite so that a dead peer ends the launch."""
+        self.N.check(self.lib.dvae_comm_set_timeout_ms(self.handle, int(ms)), "dvae_comm_set_timeout_ms")
+
     def failed(self):
-        """Synchronises; True when a bounded wait for a peer expired (the exchanged values are then undefined)."""
+        """Synchronises; True when a bounded wait for a peer expired on ANY rank (every rank's reduced gradient was then filled with NaN: the
+        failure is also in-band -- parameters and losses turn NaN from that step on)."""
         f = ctypes.c_int(0)
         self.N.check(self.lib.dvae_comm_status(self.handle, ctypes.byref(f)), "dvae_comm_status")
         return bool(f.value)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "dvae_comm_create": (c_i, [c_i, c_i, c_i64, c_vp, c_vp]),
     "dvae_comm_connect": (c_i, [c_vp, c_vp]),
     "dvae_allreduce_flat": (c_i, [c_vp, c_vp, c_i, c_i64, c_vp, c_vp]),
+    "dvae_comm_set_timeout_ms": (c_i, [c_vp, c_i64]),
     "dvae_comm_status": (c_i, [c_vp, c_vp]),
     "dvae_comm_destroy": (c_i, [c_vp]),
     # include/dvae_mcem.h

@@ -185,7 +185,23 @@ class Trainer:
         self._shared["version"] += 1
         self._copy_version = self._shared["version"]
 
+    def check_exchange(self):
+        """Multi-GPU with the direct exchange: raises RuntimeError when a bounded wait for a peer ran out in any step so far (synchronises).
+        The failure is in-band as well -- the kernel fills the reduced gradient with NaN on every rank, so parameters and losses turn NaN --
+        and this check runs wherever the trainer synchronises with the device anyway (state_dict, grads_numpy, losses_host)."""
+        if self.direct is not None and self.direct.failed():
+            raise RuntimeError("gradient exchange (dvae_allreduce_flat): a bounded wait for a peer ran out (a rank was missing or later than "
+                               "the bound, see DirectExchange.set_timeout_ms); the reduced gradient was NaN-filled on every rank -- this "
+                               "trainer's parameters are no longer valid")
+
+    def losses_host(self):
+        """The last step's loss scalars on the host (synchronises; checks the gradient exchange first)."""
+        out = self.losses.cpu().numpy().copy()
+        self.check_exchange()
+        return out
+
     def state_dict(self):
+        self.check_exchange()
         return {name: self.tensor_view(i).clone() for i, name in enumerate(self.names)}
 
     def state_dict_numpy(self):
@@ -193,6 +209,7 @@ class Trainer:
 
     def grads_numpy(self):
         """Flat gradient of the last step (sum of the k-split slabs), per tensor, as numpy."""
+        self.check_exchange()
         P, ks = self.plan.n_params, self.plan.ksplit
         go = self.plan.grad_offset_bytes
         slabs = self.ws[go:go + 4 * P * ks].view(torch.float32).view(ks, P)

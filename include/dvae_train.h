@@ -154,18 +154,21 @@ int dvae_train_profile_read(double ms[4], int64_t calls[4]);
 
 /* ---- direct gradient exchange of the data-parallel step (no reference call site: scripts/training_M2.py:31-33 is
  * single-device).  One launch per rank on the step's stream: slab sum -> reduce-scatter by pull -> all-gather by push over peer pointers
- * (hipIpc-mapped exchange buffers; xGMI on a multi-GPU node), see csrc/allreduce.hip.  Every wait for a peer is bounded: a missing peer
- * ends the launch with dvae_comm_status() != 0, never with a hang.
+ * (hipIpc-mapped exchange buffers; xGMI on a multi-GPU node), see csrc/allreduce.hip.  Every wait for a peer is bounded by wall time
+ * (dvae_comm_set_timeout_ms; default 20 s, env DVAE_COMM_TIMEOUT_MS): a missing or late peer ends the launch on EVERY rank with `out`
+ * filled with NaN and dvae_comm_status() != 0 from then on, never with a hang and never with a stale sum.  The exchange buffer is
+ * fine-grained device memory; where the platform has none, dvae_comm_create fails (no coarse-grained fallback).
  *   dvae_comm_create   allocates this rank's exchange buffer for n_floats and returns its IPC handle (DVAE_IPC_HANDLE_BYTES bytes);
  *   the caller gathers the handles of all ranks in rank order (e.g. torch.distributed.all_gather_object) and passes them to
  *   dvae_comm_connect; every rank must call dvae_allreduce_flat the same number of times.
  *   dvae_allreduce_flat: out[0 .. n) = sum over ranks of (sum over k < n_slabs of slabs[k * slab_stride + i]); `out` may alias slab 0. */
-#define DVAE_IPC_HANDLE_BYTES 64
+#define DVAE_IPC_HANDLE_BYTES 128   /* hipIpc handle + owning process + PCI address of the device */
 typedef struct dvae_comm dvae_comm_t;
 int dvae_comm_create(int rank, int world, int64_t n_floats, dvae_comm_t** out, unsigned char handle[DVAE_IPC_HANDLE_BYTES]);
 int dvae_comm_connect(dvae_comm_t* c, const unsigned char* handles /* world x DVAE_IPC_HANDLE_BYTES, rank order */);
 int dvae_allreduce_flat(dvae_comm_t* c, const float* slabs, int n_slabs, int64_t slab_stride, float* out, void* stream);
-int dvae_comm_status(dvae_comm_t* c, int* failed);      /* synchronises; *failed = 1 when a bounded wait expired since creation */
+int dvae_comm_set_timeout_ms(dvae_comm_t* c, int64_t ms);   /* bound of every in-kernel wait of the following launches (0: one poll) */
+int dvae_comm_status(dvae_comm_t* c, int* failed);      /* synchronises; *failed = 1 when a bounded wait expired on ANY rank since creation */
 int dvae_comm_destroy(dvae_comm_t* c);
 
 #ifdef __cplusplus

@@ -306,6 +306,157 @@ def test_direct_exchange_at_four_ranks():
             assert d.max() <= 4.1e-4 and np.mean(d > 2e-6) < 0.02, (k, float(d.max()), float(np.mean(d > 2e-6)))
 
 
+def _late_peer_worker(rank, world, port, q):
+    import os, sys, time
+    os.environ["DVAE_ALLREDUCE"] = "direct"
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import importlib, numpy as np, torch, torch.distributed as dist
+    import golden_util as gu
+    tr_mod = importlib.import_module("disentangled-vae_amd.trainer")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    tr = tr_mod.Trainer("M2", dims, gu.make_params("M2", dims, 21), batch=64, precision="fp32", process_group=dist.group.WORLD, world=world)
+    x, y, e = gu.make_batch(dims, 64, 30 + rank)
+    t = lambda a: torch.from_numpy(a).cuda()
+    l1 = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()          # both ranks on time (default bound: 20 s)
+    ok1 = not tr.direct.failed()
+    tr.direct.set_timeout_ms(150)
+    dist.barrier()
+    if rank == 1:
+        time.sleep(1.5)                                           # a checkpoint / validation / data stall longer than the bound
+    t0 = time.time()
+    l2 = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+    dt = time.time() - t0
+    failed = tr.direct.failed()
+    raised = False
+    try:
+        tr.state_dict()
+    except RuntimeError:
+        raised = True
+    p = np.concatenate([tr.tensor_view(i).reshape(-1).cpu().numpy() for i in range(len(tr.names))])
+    l3 = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()          # the step after: its forward runs on the NaN parameters
+    q.put((rank, ok1, bool(np.all(np.isfinite(l1))), failed, raised, bool(np.isnan(l3[0])), float(np.mean(np.isnan(p))), dt))
+    dist.barrier()
+    tr.direct.close()
+    dist.destroy_process_group()
+
+
+def test_direct_exchange_late_peer_fails_in_band_on_every_rank():
+    """a rank that arrives later than the bound of the in-kernel waits must not leave its peers with a stale sum.  Rank 1 sleeps
+    1.5 s in front of a step whose bound is 150 ms: rank 0's launch gives up, stores its status into EVERY rank's header and fills its
+    reduced gradient with NaN; rank 1's launch (which finds everything it waits for) sees the status and does the same.  Both ranks:
+    failed() is True, every parameter is NaN after the step (its own loss was computed before the exchange), the next step's loss is NaN,
+    state_dict() raises, nothing hangs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_late_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, ok1, fin1, failed, raised, nan_loss, nan_frac, dt in res:
+        assert ok1 and fin1, (rank, "the on-time step must succeed")
+        assert failed and raised, (rank, failed, raised)
+        assert nan_loss and nan_frac == 1.0, (rank, nan_loss, nan_frac)
+        assert dt < 10.0, (rank, dt)
+
+
+def _world8_worker(proc, nproc, port, q, n, n_slabs):
+    """Two ranks of an eight-rank exchange hosted by ONE process (ranks 2 proc, 2 proc + 1; each on its own stream): four processes on the
+    one GPU stay within the box's process limit.  Straight through the C ABI (include/dvae_train.h)."""
+    import os, sys, ctypes
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import importlib, numpy as np, torch, torch.distributed as dist
+    N = importlib.import_module("disentangled-vae_amd.native")
+    dp = importlib.import_module("disentangled-vae_amd.dp")
+    lib = N.load()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=proc, world_size=nproc)
+    world = 2 * nproc
+    HB = dp.IPC_HANDLE_BYTES
+    ranks = (2 * proc, 2 * proc + 1)
+    comms, blobs = [], []
+    for r in ranks:
+        h = ctypes.c_void_p(); mine = (ctypes.c_ubyte * HB)()
+        N.check(lib.dvae_comm_create(r, world, n, ctypes.byref(h), mine), "dvae_comm_create")
+        comms.append(h); blobs.append(bytes(mine))
+    gathered = [None] * nproc
+    dist.all_gather_object(gathered, blobs)
+    allb = b"".join(b for pair in gathered for b in pair)                    # rank order
+    blob = (ctypes.c_ubyte * (HB * world)).from_buffer_copy(allb)
+    for h in comms:
+        N.check(lib.dvae_comm_connect(h, blob), "dvae_comm_connect")
+    dist.barrier()
+    outs, streams, keep = [], [torch.cuda.Stream(), torch.cuda.Stream()], []
+    for call in range(3):                                                    # three calls: counters and buffer reuse across calls
+        res = []
+        for i, r in enumerate(ranks):
+            g = torch.Generator().manual_seed(1000 * call + r)
+            slabs = torch.randn(n_slabs, n, generator=g).cuda()
+            out = torch.empty(n, dtype=torch.float32, device="cuda")
+            keep.append(slabs)
+            res.append(out)
+        torch.cuda.synchronize()
+        for i, r in enumerate(ranks):
+            N.check(lib.dvae_allreduce_flat(comms[i], N.ptr(keep[-2 + i]), n_slabs, n, N.ptr(res[i]), ctypes.c_void_p(streams[i].cuda_stream)),
+                    "dvae_allreduce_flat")
+        torch.cuda.synchronize()
+        outs.append([o.cpu().numpy() for o in res])
+    failed = []
+    for h in comms:
+        f = ctypes.c_int(0)
+        N.check(lib.dvae_comm_status(h, ctypes.byref(f)), "dvae_comm_status")
+        failed.append(bool(f.value))
+    q.put((proc, outs, failed))
+    dist.barrier()
+    for h in comms:
+        lib.dvae_comm_destroy(h)
+    dist.destroy_process_group()
+
+
+def test_direct_exchange_at_eight_ranks_padded_last_shard():
+    """World 8 on the flat gradient of M2 y 513 (302 625 floats: shard = ceil(n / 8) padded to 64 = 37 888, the last shard holds 37 409 real
+    elements and 479 of padding): every rank's result equals the sum over the 8 ranks of the rank's slab sums, the ranks' results are
+    bit-identical, over three calls (counter and buffer reuse).  Eight processes on the one GPU would exceed the box's process limit, so four
+    processes host two ranks each (same-process peers connect by pointer, the others through their hipIpc handles).  One GPU: a rehearsal of
+    the protocol's indexing and hand-offs, not a measurement -- the exchange is UNMEASURED on multi-GPU hardware."""
+    import torch.multiprocessing as mp
+    n, n_slabs, nproc = 302625, 3, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_world8_worker, args=(r, nproc, port, q, n, n_slabs)) for r in range(nproc)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for call in range(3):
+        per_rank = []
+        for r in range(8):
+            g = torch.Generator().manual_seed(1000 * call + r)
+            slabs = torch.randn(n_slabs, n, generator=g).numpy()
+            t = slabs[0].copy()
+            for k in range(1, n_slabs):
+                t = t + slabs[k]                                              # the kernel's slab order, fp32
+            per_rank.append(t)
+        ref = np.zeros(n, np.float32)
+        for r in range(8):
+            ref = ref + per_rank[r]                                           # rank order, fp32, from zero: the kernel's sum
+        for proc, outs, failed in res:
+            assert not any(failed), (proc, failed)
+            for o in outs[call]:
+                np.testing.assert_array_equal(o, ref)
+
+
 class FusedInfoImpl(FusedImpl):
     """M2_info on the fused path: gradients of the enc_dec_clf group are what enc_loss.backward() leaves,
     gradients of the auxiliary group are the (gamma - beta) accumulation the second backward produces (quirk Q4)."""
