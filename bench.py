@@ -457,6 +457,29 @@ def main():
             g128 = other(a.precision, 128, 200)
             out["b128"] = {"frames_per_step": 128, "gpu_ms_per_step": g128, "gpu_frames_per_s": 128 / (g128 * 1e-3),
                            "note": "the batch size of scripts/training_M2.py:60"}
+        if world == 1 and extras and impl_name == "fused" and B == 8192:
+            # the roofline regime of SURVEY 8(d): many tiles per workgroup, the persistent tile loop hides the input load and the launch
+            # boundaries; per-frame step time against the MFMA ceiling of issued work and the HBM ceiling of the algorithmic bytes
+            try:
+                Bl, stepsl = 262144, 10
+                bs = synth.device_batches(dims, Bl, 2, 77, device)
+                o = trainer_mod.BenchImpl(a.model, dims, Bl, device, 1, a.precision)
+                for i in range(4):
+                    o.step(*bs[i % 2])
+                tl, _ = timed_steps(o, bs, 0, stepsl, None, device)
+                usl = 1e6 * tl / stepsl
+                pk = 2500.0 if a.precision in ("bf16", "bf16x3") else 157.3
+                tf = TRAIN_FLOPS[key] * Bl / (usl * 1e-6) * 1e-12
+                out["large_batch"] = {"frames_per_step": Bl, "us_per_step": usl, "frames_per_s": Bl / (usl * 1e-6), "ns_per_frame": 1e3 * usl / Bl,
+                                      "hbm_frac": MIN_BYTES[key] * Bl / (usl * 1e-6) / 8.0e12, "mfma_frac": tf / pk,
+                                      "mfma_frac_issued": tf / (pk / 3.0) if a.precision == "bf16x3" else tf / pk,
+                                      "note": "same model and policy at 262 144 frames per step (fractions: whole step, algorithmic flops / bytes of "
+                                              "SURVEY 8d); from 131 072 frames on the weight-gradient kernel reads x and the labels from the input matrices "
+                                              "instead of a stash (DVAE_RAW_INPUTS)"}
+                del o, bs
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                out["large_batch"] = {"error": repr(exc)}
         if world == 1 and extras and impl_name == "fused" and a.model == "M2" and B == 8192:
             try:
                 out["side_kernels"] = side_kernels(device)

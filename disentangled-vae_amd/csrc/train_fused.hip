@@ -2105,10 +2105,19 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     // rows kernel writes no stash for them (35 MB of writes less in its HBM-bound opening window).  Measured (M2 y513, 8192 frames, bf16x3,
     // same box, alternating): rows 46.0 -> 44.0 us, but the weight-gradient kernel 29.0 -> 34.6 us -- its input-fed blocks convert and
     // transpose 8 KB per k-step and wave through LDS behind a two-deep ring -- so the stash stays the default (step 78.6 vs 81.8 us).
-    const bool raw_inputs = getenv("DVAE_RAW_INPUTS") != nullptr && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) &&
-                            a.rows == nullptr && wgrad_form(getenv("DVAE_WGRAD")) == 4 && g_mode.mode != 1;
+    // Round 4, large batches: from ~1e5 frames on the rows kernel runs many tiles per workgroup and sets the step time (4.7 ns per frame against
+    // 2.5 for the weight-gradient kernel, which is HBM-bound there), so the 6.3 KB per frame of input stash it no longer writes pay:
+    // B = 262 144: 139.3 -> 143.2 M frames/s, B = 2^20: 137.0 -> 142.8 (x only: 143.3 / 139.1; profiles/r04_bigb_raw.txt).  Chosen
+    // automatically from DVAE_RAW_AUTO_B frames on (131 072); DVAE_RAW_INPUTS=0 keeps the stash, =x / =1 force a variant at any size.
+    const char* raw_env = getenv("DVAE_RAW_INPUTS");
+    const bool raw_possible = plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && a.rows == nullptr &&
+                              wgrad_form(getenv("DVAE_WGRAD")) == 4 && g_mode.mode != 1;
+    int64_t raw_auto_b = 131072;
+    { const char* e = getenv("DVAE_RAW_AUTO_B"); if (e) raw_auto_b = atoll(e); }
+    const bool raw_auto = raw_env == nullptr && raw_possible && g_mode.mode == 0 && plan->B >= raw_auto_b;
+    const bool raw_inputs = raw_possible && ((raw_env != nullptr && strcmp(raw_env, "0") != 0) || raw_auto);
     // DVAE_RAW_INPUTS=x: only the x tile is read raw (the label stash stays: one plane for binary labels); any other value: x and labels
-    const int raw_mask = !raw_inputs ? 0 : (strcmp(getenv("DVAE_RAW_INPUTS"), "x") == 0 ? 1 : 3);
+    const int raw_mask = !raw_inputs ? 0 : ((raw_env != nullptr && strcmp(raw_env, "x") == 0) ? 1 : 3);
     a.stash_inputs = 3 & ~raw_mask;
     a.mode = g_mode.mode;
     {   // label lo plane on demand: 8-wave kernel + the workgroup k-split weight-gradient kernel, split-bf16 operands, labels from the stash

@@ -68,13 +68,29 @@ def _relmax(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
 
 
+# bf16x3 gradient bound per tensor (fraction of the tensor's maximum), see test_fused_step_vs_oracle
+def x3_grad_bound(name):
+    return X3_TOL_L1 if name.endswith("encoder.hidden.0.weight") else X3_TOL
+
+
+X3_TOL, X3_TOL_L1 = 1e-4, 4e-4
+
+
 # 20 000 frames = 625 tiles: more tiles than workgroups (256 fp32 / 512 bf16), i.e. the persistent tile loop
-@pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M1", 0, 8192), ("M2", 1, 1000), ("M2", 513, 33), ("M1", 0, 1), ("M2", 1, 20000)])
+@pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M1", 0, 8192), ("M2", 1, 1000), ("M2", 513, 33), ("M1", 0, 1), ("M2", 1, 20000),
+                                           ("M2", 513, 20000), ("M2", 513, 65536)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_fused_step_vs_oracle(model, y_dim, B, precision):
     """fp32 operand mode: <= 1e-4 relative (north_star bar) on losses and gradients.
-    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-5 relative (measured <= 3e-7),
-    every gradient tensor within 2e-4 of its maximum (measured <= 1.1e-4, profiles/r03_parity.json; tools/exp_precision.py predicts 1e-4).
+    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-5 relative (measured <= 3e-7).  Gradients, the LAW
+    measured in round 4 (profiles/r04_parity.json, tests/diag/r04_parity_law.py, B = 1000 / 8192 / 20 000 / 65 536, binary and
+    full-mantissa labels): every tensor within 1e-4 of its maximum (measured <= 4.3e-5) EXCEPT the weight of encoder layer 1, whose worst
+    ELEMENT reaches 7.5e-5 ... 3.3e-4 depending on the batch's content, not on its size (9.4e-5 at 65 536 frames, 2.25e-4 at 20 000), while
+    its rms error stays <= 1.2e-4 of the tensor's rms.  Cause (tools/r04/sim_l1x.py: the step in float64 with the split applied to one
+    operand role at a time): the 16-bit operands of the L1 x GEMM move a pre-activation by ~4e-6 of its LARGEST term; on heavy-tailed power
+    spectra (x up to 1e4) a unit whose terms are ~100 but whose sum is ~5 sits on the knee of tanh, and the 2 dpre / (1 - h^2) sensitivity
+    turns that into ~1e-4 of one frame's row of dW1 = dpre1^T x -- with that one GEMM exact the whole policy holds 1.4e-5.  Bound here:
+    4e-4 for that tensor (and 1.5e-4 on its rms error), 1e-4 for every other tensor.
     bf16 (one bf16 per operand, opt-in fast mode): the synthetic power spectra span 1e-12 .. 1e4, so bf16
     rounding of x and W1 moves encoder pre-activations by O(1) on the loudest frames; measured deviation bound
     stated here: losses 2e-3 relative, every gradient tensor cosine >= 0.99 with the fp64 oracle and within 0.3 of its max."""
@@ -87,14 +103,17 @@ def test_fused_step_vs_oracle(model, y_dim, B, precision):
     t = lambda a: None if a is None else torch.from_numpy(a).cuda()
     losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
     ref = np.array([out["loss"], out["recon"], out["kl"]])
-    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16x3": (1e-5, 2e-4), "bf16": (2e-3, 0.3)}[precision]
+    ltol, gtol = {"fp32": (1e-4, 1e-4), "bf16x3": (1e-5, None), "bf16": (2e-3, 0.3)}[precision]
     np.testing.assert_allclose(losses, ref, rtol=ltol)
     g = tr.grads_numpy()
     worst = max(_relmax(g[k], np.asarray(grads[k], np.float64).reshape(g[k].shape)) for k in grads)
     print(f"fused[{model},y{y_dim},B{B},{precision}]: loss rel err {np.max(np.abs(losses - ref) / np.abs(ref)):.2e}, worst grad relmax {worst:.2e}")
     for k in grads:
         gr = np.asarray(grads[k], np.float64).reshape(g[k].shape)
-        assert _relmax(g[k], gr) < gtol, k
+        assert _relmax(g[k], gr) < (gtol if gtol is not None else x3_grad_bound(k)), k
+        if precision == "bf16x3":
+            rms = float(np.sqrt(np.mean((g[k].astype(np.float64) - gr) ** 2)) / (np.sqrt(np.mean(gr ** 2)) + 1e-30))
+            assert rms < 1.5e-4, (k, rms)
         if precision == "bf16" and B > 1:
             cos = float(np.sum(g[k] * gr) / (np.linalg.norm(g[k]) * np.linalg.norm(gr) + 1e-300))
             assert cos > (0.99 if B < 20000 else 0.97), (k, cos)     # the 20 000-frame draw holds louder outliers (0.982 on W1)
@@ -494,6 +513,9 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
     ref = np.array([out["ELBO"], out["recon"], out["kl"], out["enc_loss"], out["classif_loss"], out["aux_loss"], out["aux_enc_loss"]])
     np.testing.assert_allclose(losses[:7], ref, rtol=5e-3 if precision == "bf16" else 1e-4, atol=1e-5)
     g = tr.grads_numpy()
+    # bf16x3 on the RAW batch: 1e-3 bounds rows hit by ReLU flips (~110 frames of this batch have a unit within 1e-5 of a tie, and a layer-2
+    # flip moves every row of the layer-1 gradient); the same batch without its near-tie frames holds the VAE's 1e-4 / 4e-4 law on every row:
+    # test_fused_m2info_tie_free_batch_vs_oracle (round 4; measured figures in profiles/r04_parity.json)
     tol = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16": 0.3}[precision]
     # The classifier / auxiliary nets are ReLU MLPs: the reference's own gradient is discontinuous where a hidden
     # pre-activation is within rounding of zero, and a mask that flips in ONE frame moves ONE row of that layer's weight
@@ -516,6 +538,68 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
             worst_clean = max(worst_clean, float(err.max()))
     print(f"fused[M2_info,B{B},{precision}]: loss rel err {np.max(np.abs(losses[:7] - ref) / (np.abs(ref) + 1e-5)):.2e}, worst gradient error "
           f"(outside <= 2 ReLU-tie rows per tensor) {worst_clean:.2e}")
+
+
+def _relu_margins(params, x, e):
+    """float64 oracle: per frame, the smallest margin |pre| / (sum_k |w_k in_k| + |b|) over every hidden unit of the four ReLU layers of
+    M2_info (classifier on x: layers 1, 2; auxiliary net on z: layers 1, 2).  A unit whose margin is below the relative error of an
+    arithmetic's products can take the other ReLU branch under that arithmetic."""
+    p = {k: v.astype(np.float64) for k, v in params.items()}
+    x = x.astype(np.float64)
+    enc = vo.encoder_fwd(p, "enc_dec_clf.encoder.", x, e.astype(np.float64))
+    worst = np.full(x.shape[0], np.inf)
+    for prefix, inp in (("enc_dec_clf.classifier.", x), ("auxiliary.", enc["z"])):
+        h = inp
+        for name in vo._hidden_names(p, prefix):
+            W, b = p[name + ".weight"], p[name + ".bias"]
+            pre = h @ W.T + b
+            worst = np.minimum(worst, (np.abs(pre) / (np.abs(h) @ np.abs(W).T + np.abs(b) + 1e-300)).min(axis=1))
+            h = np.maximum(pre, 0)
+    return worst
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_fused_m2info_tie_free_batch_vs_oracle(precision):
+    """Round 4: what is left of the M2_info gradient deviation once ReLU ties are out of the batch.
+    A ReLU mask is a discontinuity of the reference's own gradient: a hidden pre-activation within the arithmetic's product error of zero
+    takes either branch, and a flip in LAYER 2 of a side net moves EVERY row of its layer-1 weight gradient (dpre1 = W2^T dpre2 * mask1),
+    which is why 'at most two rows per tensor' (test_fused_m2info_vs_oracle_full_batch) cannot bound the layer-1 tensors under 16-bit
+    operands: at 8192 frames ~110 frames have a unit with margin < 1e-5, ~1070 with margin < 1e-4 (tests/diag/r04_parity_law.py).
+    Here the oracle replaces every frame that has a unit with margin < 1e-4 by a frame whose margins are all >= 4e-4 (1067 of 8192), and on
+    that batch -- same model, same sizes, same kernel -- every gradient tensor obeys the VAE's per-tensor law with NO row exempted:
+    1e-4 of the tensor's maximum (measured <= 7.0e-5 on the ReLU nets), 4e-4 for the weight of encoder layer 1 (3.3e-4: the L1 x GEMM's
+    operand precision, see test_fused_step_vs_oracle); the fp32 policy holds 1e-4 (measured 2.4e-5)."""
+    dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
+    B, delta = 8192, 1e-4
+    params = gu.make_params("M2_info", dims, 31)
+    x, y, e = gu.make_batch(dims, B, 32)
+    replaced = 0
+    for _ in range(4):                                                   # a replaced frame brings its own noise, hence its own z: iterate
+        worst = _relu_margins(params, x, e)
+        risky = np.flatnonzero(worst < delta)
+        if risky.size == 0:
+            break
+        safe = np.flatnonzero(worst >= 4 * delta)
+        src = safe[(np.arange(risky.size) * 7919) % safe.size]
+        x[risky], y[risky], e[risky] = x[src], y[src], e[src]
+        replaced += risky.size
+    assert _relu_margins(params, x, e).min() >= delta and replaced < B // 4
+    p32 = {k: v.astype(np.float32) for k, v in params.items()}
+    out, g1, g2 = vo.m2info_losses_and_grads(p32, x, y, e, 0.5, 10.0, 1.0)
+    tr = trainer.Trainer("M2_info", dims, params, batch=B, precision=precision, alpha=0.5, beta=10.0, gamma=1.0)
+    t = lambda a: torch.from_numpy(a).cuda()
+    losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+    ref = np.array([out["ELBO"], out["recon"], out["kl"], out["enc_loss"], out["classif_loss"], out["aux_loss"], out["aux_enc_loss"]])
+    np.testing.assert_allclose(losses[:7], ref, rtol=1e-4, atol=1e-5)
+    g = tr.grads_numpy()
+    worst_by = {}
+    for k in params:
+        gr = (np.asarray(g1[k], np.float64) + (np.asarray(g2[k], np.float64) if k in g2 else 0.0)).reshape(g[k].shape)
+        worst_by[k] = float(np.max(np.abs(g[k].astype(np.float64) - gr)) / (np.abs(gr).max() + 1e-30))
+    wk = max(worst_by, key=worst_by.get)
+    print(f"fused[M2_info tie-free, {replaced} frames replaced, {precision}]: worst gradient error {worst_by[wk]:.2e} ({wk})")
+    for k, v in worst_by.items():
+        assert v < (1e-4 if precision == "fp32" else x3_grad_bound(k)), (k, v)
 
 
 def test_evaluate_is_forward_only_and_matches_step_losses():
@@ -755,8 +839,9 @@ def test_label_lo_plane_on_demand_equals_always(y_dim, B, monkeypatch):
     weight-gradient kernel reads the label lo plane only in launches where some tile needs it.  Sequence of steps with real-valued
     labels everywhere, in ONE tile, nowhere, and in another tile again (stale lo planes of tile slots that turned binary must
     not be read): losses and parameters equal the always-both-planes path (DVAE_YLO_ALWAYS=1) bit for bit, and the
-    real-valued-label gradients match the float64 oracle (within 4e-4 of a tensor's maximum: full-mantissa labels on every one
-    of the 513 label inputs are the worst case for the split-bf16 products; measured 2.2e-4 at 20 000 frames, 1e-4 at 1 000)."""
+    real-valued-label gradients match the float64 oracle under the same per-tensor law as test_fused_step_vs_oracle (1e-4 of a tensor's
+    maximum; 4e-4 for the weight of encoder layer 1, where this 20 000-frame batch measures 2.2e-4 -- the L1 x GEMM's operand precision
+    on a heavy-tailed frame, not the labels and not the batch size: profiles/r04_parity.json)."""
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     params = gu.make_params("M2", dims, 51)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -792,7 +877,7 @@ def test_label_lo_plane_on_demand_equals_always(y_dim, B, monkeypatch):
     out, grads, _ = _oracle_step("M2", dims, params, x.astype(np.float64), y.astype(np.float64), e.astype(np.float64))
     np.testing.assert_allclose(res[False][0][0], [out["loss"], out["recon"], out["kl"]], rtol=1e-5)
     for k in grads:
-        assert _relmax(res[False][0][1][k], np.asarray(grads[k], np.float64).reshape(res[False][0][1][k].shape)) < 4e-4, k
+        assert _relmax(res[False][0][1][k], np.asarray(grads[k], np.float64).reshape(res[False][0][1][k].shape)) < x3_grad_bound(k), k
 
 
 @pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M2", 513, 3000, "fp32"), ("M2", 1, 5000, "bf16x3"),

@@ -65,3 +65,37 @@ def test_loss_zoo_gradients_on_gpu_match_host_autograd():
         for n in host[k][1]:
             ref = host[k][1][n]
             np.testing.assert_allclose(dev[k][1][n], ref, rtol=2e-4, atol=2e-6 * float(np.abs(ref).max()), err_msg=f"{k}/{n}")
+
+
+@pytest.mark.gpu
+def test_loss_zoo_accepts_what_the_reference_expressions_accept():
+    """the secondary losses' HIP kernels cover one dtype and one shape; a [B, 1] target broadcast against [B, F], float64 inputs
+    and complex spectra that require grad are legal inputs of the reference's expressions (packages/models/utils.py:65-118) and must give
+    the reference's values and gradients, not an exception -- they run as the ATen expression on the tensors' own device."""
+    g = torch.Generator().manual_seed(5)
+    B, F = 12, 33
+    y = torch.rand(B, F, generator=g); yh = torch.rand(B, F, generator=g)
+    y1 = torch.rand(B, 1, generator=g)
+    r1 = torch.rand(B, F, generator=g) * 0.8 + 0.1; r2 = torch.rand(B, F, generator=g) * 0.8 + 0.1
+    xc = torch.complex(torch.randn(B, F, generator=g), torch.randn(B, F, generator=g))
+    sc = torch.complex(torch.randn(B, F, generator=g), torch.randn(B, F, generator=g))
+
+    def run(dev):
+        out = {}
+        a = yh.to(dev).requires_grad_(True)
+        v = U.mean_square_error_mask(y1.to(dev), a)                                  # broadcast target
+        out["mask_b"] = (float(v), torch.autograd.grad(v, a)[0].cpu().numpy())
+        a = yh.double().to(dev).requires_grad_(True)
+        v = U.mean_square_error_mask(y.double().to(dev), a)                          # float64
+        out["mask_f64"] = (float(v), torch.autograd.grad(v, a)[0].cpu().numpy())
+        a = r1.to(dev).requires_grad_(True)
+        v = U.binary_cross_entropy_2classes(a, r2.to(dev), y1.to(dev), 1e-8)        # broadcast target
+        out["bce2_b"] = (float(v), torch.autograd.grad(v, a)[0].cpu().numpy())
+        a = xc.to(dev).requires_grad_(True)
+        v = U.magnitude_spectrum_approxiamation_loss(a, sc.to(dev), yh.to(dev))      # gradient with respect to the complex spectrum
+        out["msa_cgrad"] = (float(v), torch.view_as_real(torch.autograd.grad(v, a)[0]).cpu().numpy())
+        return out
+    host, dev = run("cpu"), run("cuda")
+    for k in host:
+        np.testing.assert_allclose(dev[k][0], host[k][0], rtol=1e-5, err_msg=k)
+        np.testing.assert_allclose(dev[k][1], host[k][1], rtol=1e-4, atol=1e-7, err_msg=k)
