@@ -1,0 +1,49 @@
+// Plain argument structs of the optimizer step (apply_common.hpp has the device code): TensorDesc / ApplyArgs of apply_kernel, and the
+// task table / arguments of the deferred step that the rows kernel carries in its RowsArgs.
+#pragma once
+#include <stdint.h>
+
+namespace dvae {
+namespace fused {
+
+struct TensorDesc {
+    int64_t off;          // float offset in the flat parameter buffer
+    int32_t rows, cols;
+    // kernel-layout ("fragment-major") copies: element (row, col) of a [rows][ns * KSTEP] matrix sits at
+    //   off + (((col / KSTEP) * nt + row / 32) * 64 + ((col % KSTEP) / E) * 32 + row % 32) * E + col % E      (nt = row tiles)
+    int64_t sf_off;       // forward copy (A operand of the layer), -1 = none
+    int32_t sf_nt, sf_split, sf_gap, sf_roff;   // column c -> c (c < split) or c + gap; row r -> r + roff
+    int32_t sf_ld, st_ld;                       // row strides of the row-major variant (WFRAG == false)
+    int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
+    int32_t st_nt, st_roff, st_cmax, pad1;      // element (r, c < cmax) -> row c, column r + roff
+};
+
+struct ApplyArgs {
+    float* p; float* m; float* v;
+    const float* slabs; int64_t slab_stride; int nslabs;
+    const TensorDesc* tensors; int ntensors;
+    const unsigned char* chunk_tensor; int64_t n_params;
+    void* wcopy; int64_t wpl;      // kernel-layout weight copies; elements between the hi and lo planes (NP == 2)
+    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
+    const double* partials; int npartials; int64_t B; float* losses3; double* accum;
+    int info; float alpha, beta, gamma;
+};
+
+struct DeferTask { int32_t tensor, r0, cbeg, cend, kind, pad0, pad1, pad2; };   // kind 0: rows r0.., parameter columns cbeg.. (< cend) of `tensor`; kind 1: elements cbeg.. (< cend)
+constexpr int DEFER_SHARDS = 32;
+struct DeferArgs {
+    int on;                       // 1: this launch finalises its own loss scalars (the deferred protocol); 0: off
+    int have;                     // a pending update exists: run the tasks and the arrival protocol
+    ApplyArgs a;
+    const DeferTask* tasks; int ntasks;
+    unsigned* shard;              // DEFER_SHARDS counters, 32 words (128 bytes) apart
+    unsigned* done;               // arrivals of finished workgroups (loss finalisation)
+    unsigned* err;                // sticky error word (a bounded wait ran out)
+    unsigned seq_arrive;          // number of this launch among the workspace's deferred launches that carry an update (1, 2, ...)
+    unsigned seq_done;            // ... among all its deferred launches
+    unsigned long long timeout_ticks;   // 100 MHz wall clock
+};
+
+
+}  // namespace fused
+}  // namespace dvae

@@ -2,6 +2,7 @@
 // 8-wave chain + helper kernel): reparametrisation noise, kernel arguments, tile loaders, LDS -> stash transposition.
 #pragma once
 #include "fused_tiles.hpp"
+#include "apply_types.hpp"
 
 namespace dvae {
 namespace fused {
@@ -78,6 +79,8 @@ struct RowsArgs {
     // ylo_dirty[tile]: this tile slot's lo plane in the stash holds non-zero values from an earlier launch -- a tile that needs no lo plane
     // now still rewrites it (with its zeros) once, so that a launch in which SOME tile is flagged never reads stale lo values of the others.
     unsigned* ylo_epoch; unsigned launch_id; int ylo_skip; int* ylo_dirty;
+    // deferred optimizer step (apply_common.hpp): the previous step's Adam update at the top of this launch, the loss scalars at its end
+    DeferArgs defer;
 };
 
 #ifdef DVAE_FINE_STAMPS

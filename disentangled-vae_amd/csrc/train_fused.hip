@@ -29,6 +29,7 @@
 #include <type_traits>
 #include "fused_tiles.hpp"
 #include "rows_common.hpp"
+#include "apply_common.hpp"
 #include "../../include/dvae_train.h"
 
 namespace dvae {
@@ -1232,121 +1233,6 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-struct TensorDesc {
-    int64_t off;          // float offset in the flat parameter buffer
-    int32_t rows, cols;
-    // kernel-layout ("fragment-major") copies: element (row, col) of a [rows][ns * KSTEP] matrix sits at
-    //   off + (((col / KSTEP) * nt + row / 32) * 64 + ((col % KSTEP) / E) * 32 + row % 32) * E + col % E      (nt = row tiles)
-    int64_t sf_off;       // forward copy (A operand of the layer), -1 = none
-    int32_t sf_nt, sf_split, sf_gap, sf_roff;   // column c -> c (c < split) or c + gap; row r -> r + roff
-    int32_t sf_ld, st_ld;                       // row strides of the row-major variant (WFRAG == false)
-    int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
-    int32_t st_nt, st_roff, st_cmax, pad1;      // element (r, c < cmax) -> row c, column r + roff
-};
-
-struct ApplyArgs {
-    float* p; float* m; float* v;
-    const float* slabs; int64_t slab_stride; int nslabs;
-    const TensorDesc* tensors; int ntensors;
-    const unsigned char* chunk_tensor; int64_t n_params;
-    void* wcopy; int64_t wpl;      // kernel-layout weight copies; elements between the hi and lo planes (NP == 2)
-    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps, gscale;
-    const double* partials; int npartials; int64_t B; float* losses3; double* accum;
-    int info; float alpha, beta, gamma;
-};
-
-
-// Adam update of parameter idx (gradient gi = the fixed-order slab sum) and the refresh of its kernel-layout weight copies: the one
-// definition behind apply_kernel and the folded tail of wgrad4_kernel (bit-identical by construction).
-template <typename T, bool ADAM, int NP>
-__device__ __forceinline__ void apply_element(const ApplyArgs& g, int64_t idx, const TensorDesc& d, float pi, float m_old, float v_old, float gi) {
-    const int64_t i = idx - d.off;
-    if (i >= (int64_t)d.rows * d.cols) return;
-    T* wc = (T*)g.wcopy;
-    if (ADAM) {
-        gi *= g.gscale;
-        const float mi = m_old + g.one_minus_b1 * (gi - m_old);
-        const float vi = v_old * g.b2 + g.one_minus_b2 * (gi * gi);
-        const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
-        pi = pi - g.step_size * (mi / denom);
-        g.p[idx] = pi; g.m[idx] = mi; g.v[idx] = vi;
-    }
-    const int r = (int)((unsigned)i / (unsigned)d.cols), c = (int)i - r * d.cols;      // a tensor holds far fewer than 2^31 elements
-    constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
-    if (d.sf_off >= 0) {
-        const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
-        const int64_t o = WFRAG ? d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
-                                : d.sf_off + (int64_t)rr * d.sf_ld + cc;
-        const T ph = (T)pi;
-        wc[o] = ph;
-        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
-    }
-    if (d.st_off >= 0 && c < d.st_cmax) {
-        const int rr = c, cc = r + d.st_roff;
-        const int64_t o = WFRAG ? d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
-                                : d.st_off + (int64_t)rr * d.st_ld + cc;
-        const T ph = (T)pi;
-        wc[o] = ph;
-        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
-    }
-}
-
-// loss scalars from the rows kernel's per-workgroup partial sums (one workgroup; every thread calls)
-__device__ __forceinline__ void finalize_losses(const ApplyArgs& g, double (*red)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double a = 0.0, k = 0.0, c = 0.0, x = 0.0;
-    for (int i = threadIdx.x; i < g.npartials; i += 256) {
-        a += g.partials[4 * i]; k += g.partials[4 * i + 1]; c += g.partials[4 * i + 2]; x += g.partials[4 * i + 3];
-    }
-    a = wave_sum(a); k = wave_sum(k); c = wave_sum(c); x = wave_sum(x);
-    if (lane == 0) { red[wave][0] = a; red[wave][1] = k; red[wave][2] = c; red[wave][3] = x; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float recon = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)g.B);
-        const float kl = (float)((red[0][1] + red[1][1] + red[2][1] + red[3][1]) / (double)g.B);
-        g.losses3[0] = recon + kl; g.losses3[1] = recon; g.losses3[2] = kl;
-        if (g.accum) { g.accum[0] += (double)(recon + kl); g.accum[1] += (double)recon; g.accum[2] += (double)kl; }
-        if (g.info) {   // scripts/training_M2_info_vad.py:162-183
-            const float bc = (float)((red[0][2] + red[1][2] + red[2][2] + red[3][2]) / (double)g.B);
-            const float ba = (float)((red[0][3] + red[1][3] + red[2][3] + red[3][3]) / (double)g.B);
-            const float classif = g.alpha * bc, aux_enc = g.beta * ba;
-            g.losses3[3] = (recon + kl) + classif - aux_enc;      // enc_loss
-            g.losses3[4] = classif;
-            g.losses3[5] = g.gamma * ba;                          // aux_loss
-            g.losses3[6] = aux_enc;
-            g.losses3[7] = 0.f;
-            if (g.accum) for (int q = 3; q < 8; ++q) g.accum[q] += (double)g.losses3[q];
-        }
-    }
-}
-
-// sum of the gradient slabs at flat index idx: every load issued before the first addition, additions in slab order (deterministic)
-// COH: the slabs were written by other workgroups of THIS launch (write-through stores): device-coherent loads (sc1), which do not
-// look at this XCD's L2 lines
-template <bool COH = false>
-__device__ __forceinline__ float slab_sum_at(const ApplyArgs& g, int64_t idx) {
-    auto ld = [&](int64_t o) __attribute__((always_inline)) {
-        if constexpr (COH) return __hip_atomic_load(g.slabs + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else return g.slabs[o];
-    };
-    auto sum_slabs = [&](auto nsc) __attribute__((always_inline)) {
-        constexpr int NS = decltype(nsc)::value;
-        float part[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) part[k] = ld((k < g.nslabs ? k : 0) * g.slab_stride + idx);   // independent loads
-        float t = part[0];
-#pragma unroll
-        for (int k = 1; k < NS; ++k) if (k < g.nslabs) t += part[k];                                    // fixed order: deterministic
-        return t;
-    };
-    if (g.nslabs <= 8) return sum_slabs(std::integral_constant<int, 8>{});
-    if (g.nslabs <= 12) return sum_slabs(std::integral_constant<int, 12>{});
-    if (g.nslabs <= 16) return sum_slabs(std::integral_constant<int, 16>{});
-    float gi = ld(idx);
-    for (int k = 1; k < g.nslabs; ++k) gi += ld(k * g.slab_stride + idx);
-    return gi;
-}
-
 // ---- the optimizer step folded into the tail of the weight-gradient kernel (a train step = two launches).
 // Every (slice, block) workgroup, once its partial block is in its slab, arrives at the block's counter and waits until all `ksplit`
 // slices of the block have arrived (the grid is one round of workgroups, all resident: the host folds only when the grid fits the CUs;
@@ -1593,9 +1479,15 @@ struct Layout {
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
-    int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_flags, o_wcopy, o_stash, o_grads, total;
+    int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_flags, o_defer, o_wcopy, o_stash, o_grads, total;
     int ntiles, nblocks, nblocks4;
 };
+// deferred optimizer step (apply_common.hpp): task table, then the arrival counters (DEFER_SHARDS lines of 128 bytes), then one line with
+// the `done` counter (word 0) and the error word (word 1)
+constexpr int DEFER_MAX_TASKS = 640;
+constexpr int64_t DEFER_O_SHARD = (int64_t)DEFER_MAX_TASKS * (int64_t)sizeof(DeferTask);
+constexpr int64_t DEFER_O_DONE = DEFER_O_SHARD + DEFER_SHARDS * 128;
+constexpr int64_t DEFER_BYTES = DEFER_O_DONE + 128;
 
 static inline int64_t al(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -1653,6 +1545,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
     L.o_flags = bytes(1024 + 4 * (p.Bp / TB + 1));            // header of 256 words -- [0]: label-lo-plane epoch (RowsArgs::ylo_epoch), [1], [2], [16..]: the counters of the
                                                               // folded optimizer tail (fold_tail) -- then from byte 1024: ylo_dirty[tile]
+    L.o_defer = bytes(DEFER_BYTES);
     L.o_wcopy = bytes(L.wcopy_elems * esz * np);              // PolX3: hi plane, then lo plane
     L.o_stash = bytes(L.stash_rows * p.Bp * esz * np);
     L.o_grads = bytes((int64_t)p.ksplit * p.n_params * sizeof(float));
@@ -1942,6 +1835,38 @@ static std::unordered_map<const void*, unsigned> g_fold_seq;
 static unsigned fold_seq_next(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); return ++g_fold_seq[ws]; }
 static void fold_seq_reset(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_seq.erase(ws); }
 
+// ---- deferred optimizer step: host-side state per workspace
+struct PendingUpdate { float* params; float* m; float* v; int step; double lr, beta1, beta2, adam_eps; int n_slabs; };
+struct DeferState { bool pending = false; PendingUpdate u{}; unsigned seq_arrive = 0, seq_done = 0; int ntasks = 0; };
+static std::mutex g_defer_mu;
+static std::unordered_map<const void*, DeferState> g_defer_state;
+static DeferState defer_state_get(const void* ws) { std::lock_guard<std::mutex> lk(g_defer_mu); return g_defer_state[ws]; }
+static void defer_state_put(const void* ws, const DeferState& st) { std::lock_guard<std::mutex> lk(g_defer_mu); g_defer_state[ws] = st; }
+static void defer_state_reset(const void* ws) { std::lock_guard<std::mutex> lk(g_defer_mu); g_defer_state.erase(ws); }
+// dvae_train_step_deferred -> dvae_train_grads: run the rows kernel in its deferred form
+struct DeferRequest { bool on = false, have = false; PendingUpdate u{}; unsigned seq_arrive = 0, seq_done = 0; float* losses3 = nullptr; };
+static thread_local DeferRequest g_defer_req;
+
+// tasks of the deferred update (apply_common.hpp: DeferTask): 32 x 32 tiles of every tensor with kernel-layout copies, per column block
+// (a tile never straddles the split of the forward copy), and 1024-element chunks of the tensors without copies
+static int build_defer_tasks(const dvae_train_plan_t* p, const TensorDesc* td, DeferTask* out, int cap) {
+    int n = 0;
+    auto put = [&](int t, int r0, int cbeg, int cend, int kind) { if (n < cap) out[n] = DeferTask{t, r0, cbeg, cend, kind, 0, 0, 0}; ++n; };
+    for (int t = 0; t < p->n_tensors; ++t) {
+        const int rows = p->tensor_rows[t], cols = p->tensor_cols[t];
+        if (td[t].sf_off < 0 && td[t].st_off < 0) {
+            for (int e0 = 0; e0 < rows * cols; e0 += 1024) put(t, 0, e0, rows * cols, 1);
+            continue;
+        }
+        const int split = td[t].sf_off >= 0 && td[t].sf_split < cols ? td[t].sf_split : cols;
+        for (int r0 = 0; r0 < rows; r0 += 32) {
+            for (int cb = 0; cb < split; cb += 32) put(t, r0, cb, split, 0);
+            for (int cb = split; cb < cols; cb += 32) put(t, r0, cb, cols, 0);
+        }
+    }
+    return n;
+}
+
 static ApplyArgs make_apply_args(const dvae_train_plan_t* plan, const Layout& L, float* params, float* m, float* v, char* ws, int n_slabs,
                                  bool adam, int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale, float* losses3) {
     ApplyArgs a;
@@ -1982,6 +1907,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
 
 extern "C" int dvae_train_repack(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream) {
     DVAE_CHECK_ARG(plan && params && ws, "train_repack: bad argument");
+    DVAE_CHECK_ARG(!defer_state_get(ws).pending, "train_repack: an optimizer update is pending on this workspace (dvae_train_step_deferred): call dvae_train_flush BEFORE writing parameters");
     Layout L;
     make_layout(*plan, L);
     return launch_apply(plan, L, const_cast<float*>(params), nullptr, nullptr, (char*)ws, 0, false, 1, 0, 0, 0, 0, 0, nullptr, (hipStream_t)stream);
@@ -1997,6 +1923,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     char* w = (char*)ws;
     DVAE_HIP(hipMemsetAsync(w, 0, (size_t)L.total, s));
     fold_seq_reset(ws);
+    defer_state_reset(ws);
     GroupDesc* tiles = new GroupDesc[L.ntiles + 8];
     BlockDesc* blocks = new BlockDesc[L.nblocks + 8];
     Block4* blocks4 = new Block4[L.nblocks4 + 8];
@@ -2016,12 +1943,17 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
         for (int64_t c = c0; c < c0 + (ne + 63) / 64; ++c) ct[c] = (unsigned char)t;
     }
     hipError_t e4 = hipMemcpyAsync(w + L.o_chunks, ct, (size_t)nchunks, hipMemcpyHostToDevice, s);
+    DeferTask* dt = new DeferTask[DEFER_MAX_TASKS];
+    memset(dt, 0, sizeof(DeferTask) * DEFER_MAX_TASKS);
+    { DeferState st; st.ntasks = build_defer_tasks(plan, td, dt, DEFER_MAX_TASKS); defer_state_put(ws, st); }
+    hipError_t e7 = hipMemcpyAsync(w + L.o_defer, dt, sizeof(DeferTask) * DEFER_MAX_TASKS, hipMemcpyHostToDevice, s);
     hipError_t e3 = hipStreamSynchronize(s);
+    delete[] dt;
     delete[] tiles;
     delete[] blocks;
     delete[] blocks4;
     delete[] ct;
-    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e6); DVAE_HIP(e3);
+    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e6); DVAE_HIP(e7); DVAE_HIP(e3);
     return dvae_train_repack(plan, params, ws, stream);
 }
 
@@ -2061,10 +1993,43 @@ static int device_cu_count(int dev) {
     return cus[dev];
 }
 
+// The pending update of a workspace (dvae_train_step_deferred), applied now with apply_kernel: the same slab sums, the same element
+// arithmetic as the in-kernel form.  Every entry point that reads parameters, moments, weight copies or gradient slabs calls this first.
+extern "C" int dvae_train_flush(const dvae_train_plan_t* plan, void* ws, void* stream) {
+    DVAE_CHECK_ARG(plan && ws, "train_flush: bad argument");
+    DeferState st = defer_state_get(ws);
+    if (!st.pending) return 0;
+    Layout L;
+    make_layout(*plan, L);
+    st.pending = false;
+    defer_state_put(ws, st);
+    ProfScope ps((hipStream_t)stream, 3);
+    return launch_apply(plan, L, st.u.params, st.u.m, st.u.v, (char*)ws, st.u.n_slabs, true, st.u.step, st.u.lr, st.u.beta1, st.u.beta2, st.u.adam_eps,
+                        1.0, nullptr /* the step's loss scalars were finalised by its own rows kernel */, (hipStream_t)stream);
+}
+
+extern "C" int dvae_train_pending(const void* ws) { return defer_state_get(ws).pending ? 1 : 0; }
+
+// can this plan run the deferred form?  (8-wave rows kernel, M1 / M2 train step; the whole grid resident at once: one workgroup per CU;
+// at most two update tasks per chain wave: otherwise the update would take longer in the opening than in its own launch)
+static bool defer_possible(const dvae_train_plan_t* plan, const void* ws) {
+    if (!(plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model))) return false;
+    if (!(plan->model == DVAE_MODEL_M1 || plan->model == DVAE_MODEL_M2)) return false;
+    if (plan->row_index != 0 && plan->row_count <= 0) return false;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int nt = defer_state_get(ws).ntasks;
+    if (nt <= 0 || nt > DEFER_MAX_TASKS) return false;
+    if (plan->rows_grid > device_cu_count(dev) || 8 * plan->rows_grid < nt) return false;
+    const int64_t kper = kper_of(plan);
+    return (plan->Bp + kper - 1) / kper <= 12;
+}
+
 extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                                 const float* y, int ldy, const float* eps_noise, float elbo_eps, int reduce_slabs, void* stream) {
     DVAE_CHECK_ARG(plan && params && ws && x && ldx >= XD, "train_grads: bad argument");
     DVAE_CHECK_ARG(plan->y_dim == 0 || (y != nullptr && ldy >= plan->y_dim), "train_grads: y missing or ldy < y_dim");
+    if (!g_defer_req.on) { const int frc = dvae_train_flush(plan, ws, stream); if (frc) return frc; }
     Layout L;
     make_layout(*plan, L);
     hipStream_t s = (hipStream_t)stream;
@@ -2101,6 +2066,19 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     a.spl = L.stash_rows * plan->Bp; a.wpl_bytes = (unsigned)(L.wcopy_elems * esz);
     a.dbg = g_dbg;
     { const char* ab = getenv("DVAE_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    if (g_defer_req.on) {
+        const PendingUpdate& u = g_defer_req.u;
+        a.defer.on = 1; a.defer.have = g_defer_req.have ? 1 : 0;
+        a.defer.a = g_defer_req.have ? make_apply_args(plan, L, u.params, u.m, u.v, w, u.n_slabs, true, u.step, u.lr, u.beta1, u.beta2, u.adam_eps, 1.0, g_defer_req.losses3)
+                                     : make_apply_args(plan, L, const_cast<float*>(params), nullptr, nullptr, w, 1, false, 1, 0, 0, 0, 0, 0, g_defer_req.losses3);
+        a.defer.tasks = (const DeferTask*)(w + L.o_defer); a.defer.ntasks = defer_state_get(ws).ntasks;
+        a.defer.shard = (unsigned*)(w + L.o_defer + DEFER_O_SHARD);
+        a.defer.done = (unsigned*)(w + L.o_defer + DEFER_O_DONE); a.defer.err = a.defer.done + 1;
+        a.defer.seq_arrive = g_defer_req.seq_arrive; a.defer.seq_done = g_defer_req.seq_done;
+        long long ms = 2000;                                   // bound of the arrival wait (the whole grid is resident: it is microseconds)
+        { const char* e = getenv("DVAE_DEFER_TIMEOUT_MS"); if (e) ms = atoll(e); }
+        a.defer.timeout_ticks = (unsigned long long)(ms < 0 ? 0 : ms) * 100000ull;
+    }
     // DVAE_RAW_INPUTS=1 (opt-in, tested): the weight-gradient kernel takes x and the labels straight from the fp32 input matrices and the
     // rows kernel writes no stash for them (35 MB of writes less in its HBM-bound opening window).  Measured (M2 y513, 8192 frames, bf16x3,
     // same box, alternating): rows 46.0 -> 44.0 us, but the weight-gradient kernel 29.0 -> 34.6 us -- its input-fed blocks convert and
@@ -2260,6 +2238,7 @@ extern "C" int dvae_train_apply(const dvae_train_plan_t* plan, float* params, fl
                                 int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale,
                                 float* losses3, void* stream) {
     DVAE_CHECK_ARG(plan && params && m && v && ws && step >= 1, "train_apply: bad argument");
+    { const int frc = dvae_train_flush(plan, ws, stream); if (frc) return frc; }
     Layout L;
     make_layout(*plan, L);
     if (n_slabs <= 0) n_slabs = used_slabs(plan);
@@ -2296,12 +2275,38 @@ extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, flo
     return dvae_train_apply(plan, params, m, v, ws, 0, step, lr, beta1, beta2, adam_eps, 1.0, losses3, stream);
 }
 
+// Two launches per step: rows(n) applies the update of step n - 1 in its opening and finalises the losses of step n at its end, wgrad(n)
+// leaves the gradient slabs of step n; the update of step n stays PENDING until the next deferred step or dvae_train_flush.
+extern "C" int dvae_train_step_deferred(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws,
+                                        const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
+                                        int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream) {
+    DVAE_CHECK_ARG(plan && params && m && v && ws && step >= 1 && losses3, "train_step_deferred: bad argument");
+    const char* de = getenv("DVAE_DEFER_APPLY");
+    if ((de && atoi(de) == 0) || getenv("DVAE_FOLD_APPLY") != nullptr || !defer_possible(plan, ws))
+        return dvae_train_step(plan, params, m, v, ws, x, ldx, y, ldy, eps_noise, elbo_eps, step, lr, beta1, beta2, adam_eps, losses3, stream);   // flushes first
+    DeferState st = defer_state_get(ws);
+    g_defer_req = DeferRequest();
+    g_defer_req.on = true; g_defer_req.have = st.pending; g_defer_req.u = st.u; g_defer_req.losses3 = losses3;
+    g_defer_req.seq_arrive = st.seq_arrive + (st.pending ? 1u : 0u); g_defer_req.seq_done = st.seq_done + 1u;
+    g_rng_step_override = step;
+    const int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, elbo_eps, 0, stream);
+    g_defer_req = DeferRequest();
+    g_rng_step_override = -1;
+    if (rc) return rc;
+    st.seq_arrive += st.pending ? 1u : 0u; st.seq_done += 1u;
+    st.pending = true;
+    st.u = PendingUpdate{params, m, v, step, lr, beta1, beta2, adam_eps, used_slabs(plan)};
+    defer_state_put(ws, st);
+    return 0;
+}
+
 /* ---- whole-model autograd path of the drop-in modules (packages/models/models.py) ---- */
 extern "C" int dvae_module_forward(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                                    const float* y, int ldy, const float* eps_noise, float* out_r, int ld_r, float* out_mu,
                                    float* out_lv, float* out_z, int repack, void* stream) {
     DVAE_CHECK_ARG(plan && params && ws && x && eps_noise && out_r && out_mu && out_lv && ld_r >= XD, "module_forward: bad argument");
     DVAE_CHECK_ARG(plan->rows_kernel == 2 && plan->row_index == 0, "module_forward: needs the 8-wave rows kernel and no gather table");
+    { const int frc = dvae_train_flush(plan, ws, stream); if (frc) return frc; }
     if (repack) { int rc = dvae_train_repack(plan, params, ws, stream); if (rc) return rc; }
     g_mode = ModeArgs();
     g_mode.mode = 1; g_mode.out_r = out_r; g_mode.ld_r = ld_r; g_mode.out_mu = out_mu; g_mode.out_lv = out_lv; g_mode.out_z = out_z;

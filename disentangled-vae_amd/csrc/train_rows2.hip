@@ -40,6 +40,7 @@
 #include "fused_tiles.hpp"
 #include "rows_common.hpp"
 #include "wstream.hpp"
+#include "apply_common.hpp"
 #include "../../include/dvae_train.h"
 
 namespace dvae {
@@ -101,9 +102,12 @@ __device__ __forceinline__ void get_raw4(float (&v)[4], const typename P::T* lds
 
 // MODE (RowsArgs::mode, compile time so the train-step instantiation carries none of the other modes' code or registers):
 // 0 fused train step, 1 forward outputs only, 2 backward from upstream gradients
-template <typename P, int YP, bool YENC, int MODE, bool INFO = false>
+// DEFER: the deferred optimizer step (apply_common.hpp) -- the previous step's Adam update on the chain waves at the top of the launch,
+// an arrival barrier in front of the first weight / bias load (which are sc1 loads then), the loss scalars by the last workgroup at the end
+template <typename P, int YP, bool YENC, int MODE, bool INFO = false, bool DEFER = false>
 __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     static_assert(!INFO || (MODE == 0 && YP == 16 && !YENC), "M2_info: train step, 1-dim label, encoder on x only");
+    static_assert(!DEFER || (MODE == 0 && !INFO && sizeof(typename P::T) == 2), "deferred optimizer step: M1 / M2 train step, bf16 copies");
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         constexpr int D = OFFL ? P::PDO : P::PD;
         typedef Sched<P, YP, YENC, D, INFO> SC;
         typedef HSched<P, YP, YENC, DH, INFO> HS;
-        typedef WStream<P, SC, D> WS;
+        typedef WStream<P, SC, D, DEFER ? 16 : R2_WAUX> WS;
         constexpr unsigned FBB = SC::FBB;
         WS ws;
         ws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
@@ -210,6 +214,32 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if constexpr (INFO) {
                 ws.sb[G_A1] = mo(g.Wa1s) + tw;  ws.sb[G_A2] = mo(g.Wa2s) + tw;  ws.sb[G_A2T] = mo(g.Wa2t) + tw;  ws.sb[G_A1T] = mo(g.Wa1t);
             } else { ws.sb[G_A1] = ws.sb[G_A2] = ws.sb[G_A2T] = ws.sb[G_A1T] = 0; }
+        }
+        if constexpr (DEFER) {
+            // ---- the previous step's optimizer update (apply_common.hpp): this wave's tasks, then the arrival of every wave of the grid
+            if (g.defer.have) {
+                T* const tile = reinterpret_cast<T*>(keep) + cw * DeferLds<T, NP>::wave_elems;      // `keep` is free until the first epilogue
+                for (int task = cw * (int)gridDim.x + (int)blockIdx.x; task < g.defer.ntasks; task += 4 * (int)gridDim.x)
+                    defer_task<T, NP>(g.defer.a, g.defer.tasks[task], tile, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have left
+                if (lane == 0)
+                    __hip_atomic_fetch_add(g.defer.shard + 32 * (((int)blockIdx.x * 4 + cw) & (DEFER_SHARDS - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cw == 0) {
+                    // waves (b, w) with (4 b + w) mod 32 == s add to shard s: its value after this launch is seq_arrive x that count
+                    const int nw = 4 * (int)gridDim.x, sh = lane & (DEFER_SHARDS - 1);
+                    const unsigned want = g.defer.seq_arrive * (unsigned)((nw - sh + DEFER_SHARDS - 1) / DEFER_SHARDS);
+                    const unsigned long long deadline = wall_clock64() + g.defer.timeout_ticks;
+                    bool ok = true;
+                    for (;;) {
+                        const unsigned have = __hip_atomic_load(g.defer.shard + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__ballot((int)(have - want) < 0) == 0ull) break;
+                        if (wall_clock64() >= deadline) { ok = false; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (!ok && lane == 0) __hip_atomic_store(g.defer.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            wg_barrier();                                                   // BARR: no weight fragment, no bias value is requested before this
         }
         ws.fill();                                                         // the first D k-steps of the stream, in flight under the x tile load
         const T* const Ur = U + l31 * LDU + h * E;
@@ -613,6 +643,38 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         }
         R2_STAMP(15);
         if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 31] = clock64();
+        if constexpr (DEFER) {
+            // loss scalars by the workgroup whose partial sums arrive last (apply_kernel's reduction shape: 256 strided threads, wave sums,
+            // four wave totals in order).  Partial sums leave as sc1 stores and are read back with sc1 loads.
+            double* const pr = g.partials + 4 * (size_t)blockIdx.x;
+            if (tid == 0) {
+                __hip_atomic_store(pr, tot_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pr + 1, tot_kl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pr + 2, tot_bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pr + 3, tot_ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned old = __hip_atomic_fetch_add(g.defer.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flags[1] = old + 1u == g.defer.seq_done * gridDim.x ? 1 : 0;
+            }
+            wg_barrier();                                                   // BFIN1
+            if (__builtin_amdgcn_readfirstlane(flags[1]) != 0) {
+                double (*redd)[4] = reinterpret_cast<double (*)[4]>(keep);
+                double a = 0.0, k = 0.0, c = 0.0, x = 0.0;
+                for (int i = tid; i < g.defer.a.npartials; i += 256) {
+                    a += __hip_atomic_load(g.defer.a.partials + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    k += __hip_atomic_load(g.defer.a.partials + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c += __hip_atomic_load(g.defer.a.partials + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x += __hip_atomic_load(g.defer.a.partials + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                a = wave_sum(a); k = wave_sum(k); c = wave_sum(c); x = wave_sum(x);
+                if (lane == 0) { redd[cw][0] = a; redd[cw][1] = k; redd[cw][2] = c; redd[cw][3] = x; }
+                wg_barrier();                                               // BFIN2
+                if (tid == 0) {
+                    write_losses(g.defer.a, redd);
+                    if (__hip_atomic_load(g.defer.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) g.defer.a.losses3[0] = __builtin_nanf("");
+                }
+            }
+        } else
         if (tid == 0) {
             g.partials[4 * blockIdx.x] = tot_rec;
             g.partials[4 * blockIdx.x + 1] = tot_kl;
@@ -628,22 +690,34 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         constexpr int NBT = Ld<T>::nbias;
         constexpr int NB = (NBT + 255) / 256;
         float bvv[NB];
+        auto load_bias = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            int i = ht + 256 * q;
-            i = i < NBT ? i : NBT - 1;
-            const float* src;
-            int k;
-            if (i < OB2) { src = g.b1; k = i; }
-            else if (i < OBMV) { src = g.b2; k = i - OB2; }
-            else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
-            else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
-            else if (i < OB4) { src = g.b3; k = i - OB3; }
-            else if (i < OB5) { src = g.b4; k = i - OB4; }
-            else if (i < OB5 + NO) { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
-            else { src = g.w5last; k = i - OB5 - NO; }
-            bvv[q] = src[k];
-        }
+            for (int q = 0; q < NB; ++q) {
+                int i = ht + 256 * q;
+                i = i < NBT ? i : NBT - 1;
+                const float* src;
+                int k;
+                if (i < OB2) { src = g.b1; k = i; }
+                else if (i < OBMV) { src = g.b2; k = i - OB2; }
+                else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
+                else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
+                else if (i < OB4) { src = g.b3; k = i - OB3; }
+                else if (i < OB5) { src = g.b4; k = i - OB4; }
+                else if (i < OB5 + NO) { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
+                else { src = g.w5last; k = i - OB5 - NO; }
+                // deferred step: the values were written by other workgroups of THIS launch (write-through stores): sc1 loads, after BARR
+                if constexpr (DEFER) bvv[q] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else bvv[q] = src[k];
+            }
+        };
+        auto store_bias = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int i = ht + 256 * q;
+                if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
+            }
+        };
+        if constexpr (!DEFER) load_bias();
         // gather table of tile `tl_` into half `half` (threads 0..31 of the helper group); bad indices are clamped and counted
         auto fill_rows = [&](int tl_, int half) {
             if (ht < TB) {
@@ -703,11 +777,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 if (gather) { fill_rows(tile, 0); wg_barrier(); }       // BROW
                 if (g.fastx && full) {
                     tile513_issue(g.x, rowof, xv, tl);
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        const int i = ht + 256 * q;
-                        if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
-                    }
+                    if constexpr (!DEFER) store_bias();
 #if R2_EARLY_Y
                     if (YP > 0 && Y513 && g.fasty) {
                         // The label tile is requested BEHIND the x tile, a quarter at a time, each quarter followed by the commit of
@@ -737,11 +807,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 } else {
 #pragma unroll
                     for (int i = 0; i < NQ513; ++i) { xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; yv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        const int i = ht + 256 * q;
-                        if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
-                    }
+                    if constexpr (!DEFER) store_bias();
                     load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
                 }
                 if constexpr (INFO) {
@@ -755,6 +821,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     }
                 }
                 if (ht == 0) flags[0] = 0;
+                if constexpr (DEFER) {
+                    wg_barrier();                                       // BARR: the optimizer update of the previous step has arrived from every workgroup
+                    load_bias();
+                    store_bias();
+                }
                 wg_barrier();                                           // BX
                 if constexpr (OFFL) { if (g.fastx && full) lsum2 += tile513_log2sum(xv, g.elbo_eps, tl); }   // the tile is still in registers
             }
@@ -1074,10 +1145,14 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             }
             wg_barrier();                                               // BRED
         }
+        if constexpr (DEFER) {
+            wg_barrier();                                                   // BFIN1
+            if (__builtin_amdgcn_readfirstlane(flags[1]) != 0) wg_barrier();   // BFIN2
+        }
     }
 }
 
-template <typename P, int YP, bool YENC, int MODE, bool INFO = false>
+template <typename P, int YP, bool YENC, int MODE, bool INFO = false, bool DEFER = false>
 static int launch_rows2_m(const RowsArgs& a, int grid, hipStream_t s) {
     const size_t lds = Lds2<P, INFO>::bytes;
     static bool attr_done[64] = {};
@@ -1085,11 +1160,11 @@ static int launch_rows2_m(const RowsArgs& a, int grid, hipStream_t s) {
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC, MODE, INFO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)vae_rows2_kernel<P, YP, YENC, MODE, INFO, DEFER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(rows2 kernel, %zu B LDS): %s", lds, hipGetErrorString(e)); return (int)e; }
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC, MODE, INFO>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((vae_rows2_kernel<P, YP, YENC, MODE, INFO, DEFER>), dim3(grid), dim3(512), lds, s, a);
     DVAE_LAUNCH_OK("vae_rows2_kernel");
     return 0;
 }
@@ -1098,6 +1173,7 @@ template <typename P, int YP, bool YENC>
 static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
     if (a.mode == 1) return launch_rows2_m<P, YP, YENC, 1>(a, grid, s);
     if (a.mode == 2) return launch_rows2_m<P, YP, YENC, 2>(a, grid, s);
+    if (a.defer.on) return launch_rows2_m<P, YP, YENC, 0, false, true>(a, grid, s);
     return launch_rows2_m<P, YP, YENC, 0>(a, grid, s);
 }
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-template <typename P, typename SC, int D> struct WStream {
+template <typename P, typename SC, int D, int AUX = R2_WAUX> struct WStream {
     typename P::Frag r[D][P::NP];
     __amdgpu_buffer_rsrc_t rs;
     int voff;                  // lane * 16
@@ -111,10 +111,10 @@ template <typename P, typename SC, int D> struct WStream {
         else cur += SC::stride(s);
         asm volatile("" : "+s"(cur));
         // R2_WAUX: cache-policy bits of the weight stream's loads (gfx950 buffer aux: 1 = sc0, 2 = nt, 16 = sc1)
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur, R2_WAUX);
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur, AUX);
         r[Q % D][0] = __builtin_bit_cast(typename P::Frag, v0);
         if constexpr (P::NP == 2) {
-            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur + pl, R2_WAUX);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur + pl, AUX);
             r[Q % D][1] = __builtin_bit_cast(typename P::Frag, v1);
         }
     }
@@ -123,10 +123,10 @@ template <typename P, typename SC, int D> struct WStream {
     template <int S, int SLOT> __device__ __forceinline__ void req_next() {
         cur += SC::stride(S);
         asm volatile("" : "+s"(cur));
-        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur, R2_WAUX);
+        const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur, AUX);
         r[SLOT][0] = __builtin_bit_cast(typename P::Frag, v0);
         if constexpr (P::NP == 2) {
-            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur + pl, R2_WAUX);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, cur + pl, AUX);
             r[SLOT][1] = __builtin_bit_cast(typename P::Frag, v1);
         }
     }

@@ -8,6 +8,7 @@ state_dict names so checkpoints move both ways.  No fallback: unsupported geomet
 raise (the layer-level modules in packages/models cover them).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -79,6 +80,9 @@ class Trainer:
         self.precision = precision
         self.lr, self.betas, self.adam_eps, self.elbo_eps = lr, betas, adam_eps, elbo_eps
         self.pg, self.world = process_group, int(world)
+        # two launches per step (the optimizer update deferred into the next step's rows kernel) unless DVAE_DEFER_APPLY=0; single-GPU only:
+        # the data-parallel step puts the gradient exchange between the weight-gradient kernel and the update
+        self._defer = int(world) == 1 and os.environ.get("DVAE_DEFER_APPLY", "1") != "0"
         self.y_dim = 0 if model == "M1" else int(dims["y_dim"])
         self.plan = TrainPlan()
         N.check(self.lib.dvae_train_plan(MODEL_CODE[model], self.y_dim, PREC_CODE[precision], self.B, ksplit, ctypes.byref(self.plan)),
@@ -89,12 +93,12 @@ class Trainer:
         P = self.plan.n_params
         with torch.cuda.device(self.device):
             if share is None:
-                self.params = torch.zeros(P, dtype=torch.float32, device=self.device)
-                self.m = torch.zeros(P, dtype=torch.float32, device=self.device)
-                self.v = torch.zeros(P, dtype=torch.float32, device=self.device)
+                self._params = torch.zeros(P, dtype=torch.float32, device=self.device)
+                self._m = torch.zeros(P, dtype=torch.float32, device=self.device)
+                self._v = torch.zeros(P, dtype=torch.float32, device=self.device)
                 self._shared = {"step_count": 0, "version": 0}
             else:                       # same parameters / Adam state, another batch size (see fork())
-                self.params, self.m, self.v, self._shared = share.params, share.m, share.v, share._shared
+                self._params, self._m, self._v, self._shared = share._params, share._m, share._v, share._shared
             self.ws = torch.empty(self.plan.workspace_bytes, dtype=torch.uint8, device=self.device)
             self.losses = torch.zeros(8 if model == "M2_info" else 3, dtype=torch.float32, device=self.device)
             self.bad_rows = torch.zeros(1, dtype=torch.int32, device=self.device)      # gather indices the kernels refused (see bad_row_count)
@@ -118,7 +122,52 @@ class Trainer:
                 params = self._reference_init(seed)
             self._write_params(params)
         with torch.cuda.device(self.device):
-            N.check(self.lib.dvae_train_init(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_init")
+            N.check(self.lib.dvae_train_init(ctypes.byref(self.plan), N.ptr(self._params), N.ptr(self.ws), N.stream()), "dvae_train_init")
+
+    # ---- deferred optimizer step (include/dvae_train.h: dvae_train_step_deferred): the update of the last step() is applied in the opening
+    # of the next step's first kernel; anything that looks at parameters or moments flushes it first (one apply launch)
+    def flush(self):
+        """Apply this trainer's pending optimizer update, if any (stream-ordered, no host sync)."""
+        if self.lib.dvae_train_pending(N.ptr(self.ws)):
+            with torch.cuda.device(self.device):
+                N.check(self.lib.dvae_train_flush(ctypes.byref(self.plan), N.ptr(self.ws), N.stream()), "dvae_train_flush")
+        if self._shared.get("pending") is self:
+            self._shared["pending"] = None
+
+    def _flush_shared(self, but=None):
+        other = self._shared.get("pending")
+        if other is not None and other is not but:
+            other.flush()
+
+    @property
+    def params(self):
+        self._flush_shared()
+        return self._params
+
+    @params.setter
+    def params(self, t):
+        self._flush_shared()
+        self._params = t
+
+    @property
+    def m(self):
+        self._flush_shared()
+        return self._m
+
+    @m.setter
+    def m(self, t):
+        self._flush_shared()
+        self._m = t
+
+    @property
+    def v(self):
+        self._flush_shared()
+        return self._v
+
+    @v.setter
+    def v(self, t):
+        self._flush_shared()
+        self._v = t
 
     @property
     def step_count(self):
@@ -137,8 +186,10 @@ class Trainer:
                        alpha=self.plan.info_alpha, beta=self.plan.info_beta, gamma=self.plan.info_gamma, share=self)
 
     def _sync_copies(self):
+        self._flush_shared(but=self)                 # a fork's pending update changes the parameters this trainer is about to use
         if self._copy_version != self._shared["version"]:
-            N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
+            self.flush()
+            N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self._params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
             self._copy_version = self._shared["version"]
 
     # ---- parameters under the reference's state_dict names ----
@@ -179,9 +230,10 @@ class Trainer:
     def load_state_dict(self, sd, strict=True):
         """strict=False overwrites only the tensors present (the pretrain flow of
         scripts/training_M2_info_vad_pretrain.py:102-112: `model_dict.update(filtered); load_state_dict(model_dict)`)."""
+        self._flush_shared()
         self._write_params(sd, strict)
         with torch.cuda.device(self.device):
-            N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
+            N.check(self.lib.dvae_train_repack(ctypes.byref(self.plan), N.ptr(self._params), N.ptr(self.ws), N.stream()), "dvae_train_repack")
         self._shared["version"] += 1
         self._copy_version = self._shared["version"]
 
@@ -278,13 +330,16 @@ class Trainer:
     def _launch_step(self, plan, x, yp, ldy, eps_noise):
         s = N.stream()
         if self.world == 1:
-            N.check(self.lib.dvae_train_step(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), N.ptr(x), N.ld(x),
+            fn = self.lib.dvae_train_step_deferred if self._defer else self.lib.dvae_train_step
+            N.check(fn(plan, N.ptr(self._params), N.ptr(self._m), N.ptr(self._v), N.ptr(self.ws), N.ptr(x), N.ld(x),
                                              yp, ldy, N.ptr(eps_noise), self.elbo_eps, self.step_count, self.lr, self.betas[0],
-                                             self.betas[1], self.adam_eps, N.ptr(self.losses), s), "dvae_train_step")
+                       self.betas[1], self.adam_eps, N.ptr(self.losses), s), "dvae_train_step")
+            if self._defer:
+                self._shared["pending"] = self if self.lib.dvae_train_pending(N.ptr(self.ws)) else None
             self._reduced = False
         else:
             direct = self.direct
-            N.check(self.lib.dvae_train_grads(plan, N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
+            N.check(self.lib.dvae_train_grads(plan, N.ptr(self._params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
                                               self.elbo_eps, 0 if direct is not None else 1, s), "dvae_train_grads")
             ev = None
             if self._ar_events is not None:                           # profiling: device time of the exchange, on the launch stream
@@ -297,7 +352,7 @@ class Trainer:
             if ev is not None:
                 ev[1].record()
                 self._ar_events.append(ev)
-            N.check(self.lib.dvae_train_apply(plan, N.ptr(self.params), N.ptr(self.m), N.ptr(self.v), N.ptr(self.ws), 1, self.step_count,
+            N.check(self.lib.dvae_train_apply(plan, N.ptr(self._params), N.ptr(self._m), N.ptr(self._v), N.ptr(self.ws), 1, self.step_count,
                                               self.lr, self.betas[0], self.betas[1], self.adam_eps, 1.0 / self.world,
                                               N.ptr(self.losses), s), "dvae_train_apply")
             self._reduced = True
@@ -317,7 +372,7 @@ class Trainer:
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         out = torch.zeros_like(self.losses)
         with torch.cuda.device(self.device):
-            N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
+            N.check(self.lib.dvae_train_eval(ctypes.byref(self.plan), N.ptr(self._params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
                                              N.ptr(None if eps_noise is None else eps_noise.contiguous()), self.elbo_eps, N.ptr(out), N.stream()),
                     "dvae_train_eval")
         return out
@@ -346,7 +401,7 @@ class Trainer:
             y = y if y.stride(1) == 1 else y.contiguous()
         yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
         with torch.cuda.device(self.device):
-            N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self.params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
+            N.check(self.lib.dvae_train_grads(ctypes.byref(self.plan), N.ptr(self._params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy,
                                               N.ptr(eps_noise.contiguous()), self.elbo_eps, 1 if reduce else 0, N.stream()), "dvae_train_grads")
         self._reduced = bool(reduce)
 
@@ -383,11 +438,17 @@ class BenchImpl:
         self.tr = Trainer(model, dims, None, batch=B, device=device, precision=precision, process_group=pg, world=world, seed=0,
                           ksplit=ksplit, direct_exchange=direct_exchange)
         self.dtype = {"bf16": "bf16", "bf16x3": "bf16x3", "fp32": "f32"}[precision]
-        self.name = f"fused(rows+wgrad+apply HIP kernels, {precision} MFMA operands, fp32 accumulate/master)"
+        self.name = (f"fused(rows+wgrad HIP kernels, Adam deferred into the next step's rows kernel, {precision} MFMA operands, fp32 accumulate/master)"
+                     if self.tr._defer else f"fused(rows+wgrad+apply HIP kernels, {precision} MFMA operands, fp32 accumulate/master)")
         self.model, self.dims, self.B, self.precision = model, dims, B, precision
 
     def step(self, x, y, e):
         return self.tr.step(x, y, e)
+
+    def finish(self):
+        """The last step's optimizer update (deferred into the next step's first kernel when there is one): applied now.  bench.py calls
+        this INSIDE its timed region, so K timed steps contain K updates."""
+        self.tr.flush()
 
     def kernel_profile(self, batches, steps):
         """Per-kernel device time over `steps` steps -> roofline dict for the dominant kernel."""

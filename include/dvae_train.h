@@ -116,6 +116,23 @@ int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, floa
                     const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
                     int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream);
 
+/* The same step in TWO launches (round 4): the optimizer update of step n is deferred into the opening of step n + 1's rows kernel, where
+ * the GEMM waves would otherwise wait for the x tile (csrc/apply_common.hpp), and a step's loss scalars are finalised by its own rows
+ * kernel.  After this call returns, losses3 (stream-ordered) holds step n's losses and the gradient slabs step n's gradient, but
+ * params / m / v and the weight copies still hold the state BEFORE step n's update: it is PENDING on `ws` until the next
+ * dvae_train_step_deferred on the same workspace or dvae_train_flush.  Every other entry point of this header flushes first by itself;
+ * a caller that reads or writes params / m / v directly must call dvae_train_flush before (dvae_train_repack refuses while an update is
+ * pending).  Results are bit-identical to dvae_train_step (same slab sums, same element arithmetic).  Falls back to dvae_train_step when
+ * the plan cannot defer (M2_info, the 4-wave rows kernel, grids smaller than the update's task list or larger than the CUs;
+ * DVAE_DEFER_APPLY=0).  The same params / m / v pointers and hyper-parameter semantics as dvae_train_step. */
+int dvae_train_step_deferred(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws,
+                             const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
+                             int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream);
+/* Apply the pending update of `ws`, if any (one apply launch on `stream`). */
+int dvae_train_flush(const dvae_train_plan_t* plan, void* ws, void* stream);
+/* 1 when an update is pending on `ws`. */
+int dvae_train_pending(const void* ws);
+
 /* Validation pass of the scripts (scripts/training_M2.py:176-193: forward + elbo, no backward, no update):
  * rows kernel + loss finalisation only.  losses3 as for dvae_train_apply. */
 int dvae_train_eval(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,

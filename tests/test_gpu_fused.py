@@ -15,6 +15,7 @@ from oracle import vae_oracle as vo
 
 pytestmark = pytest.mark.gpu
 trainer = importlib.import_module("disentangled-vae_amd.trainer")
+N = importlib.import_module("disentangled-vae_amd.native")
 
 FULL = [c for c in gu.CASES if c[0] in ("M1_full", "M2_full_y1", "M2_full_y513", "M2_full_y513_hot")]
 
@@ -908,6 +909,97 @@ def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_la
         for k in ga:
             np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
             np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+
+
+@pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M2", 1, 5000, "bf16x3"), ("M1", 0, 8192, "bf16"),
+                                                       ("M2", 513, 20000, "bf16x3"), ("M2", 513, 8192, "bf16"), ("M1", 0, 4096, "bf16x3")])
+def test_deferred_optimizer_step_equals_the_three_launch_step(model, y_dim, B, precision, monkeypatch):
+    """Round 4: dvae_train_step_deferred -- two launches per step; the Adam update of step n runs on the chain waves of step n + 1's rows
+    kernel (32 x 32 parameter tiles per wave, write-through stores, arrival counters, sc1 weight loads), the loss scalars come from the
+    rows kernel's last workgroup -- against the three-launch step (DVAE_DEFER_APPLY=0): losses, gradients, parameters and both Adam
+    moments equal bit for bit after every one of five steps (reading parameters flushes the pending update through apply_kernel, so
+    the in-kernel form AND the flush are both compared), including a batch of more tiles than workgroups and a ragged last tile."""
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 71)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    batches = [gu.make_batch(dims, B, 80 + i) for i in range(5)]
+    res = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("DVAE_DEFER_APPLY", defer)
+        tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+        out = []
+        for i, (x, y, e) in enumerate(batches):
+            losses = tr.step(t(x), t(y) if y_dim else None, t(e))
+            if defer == "1":
+                assert tr.lib.dvae_train_pending(N.ptr(tr.ws)) == 1, "the step did not defer its update"
+            if i in (1, 4):                                       # two of the five steps: parameters read after the step (= a flush)
+                out.append((losses.cpu().numpy().copy(), tr.grads_numpy(), tr.state_dict_numpy(), tr.m.cpu().numpy().copy(), tr.v.cpu().numpy().copy()))
+            else:                                                 # the others: the update stays pending and runs inside the next rows kernel
+                out.append((losses.cpu().numpy().copy(), tr.grads_numpy(), None, None, None))
+        res[defer] = out
+    for (la, ga, pa, ma, va), (lb, gb, pb, mb, vb) in zip(res["1"], res["0"]):
+        assert np.all(np.isfinite(la))
+        np.testing.assert_array_equal(la, lb)
+        for k in ga:
+            np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
+        if pa is not None:
+            np.testing.assert_array_equal(ma, mb)
+            np.testing.assert_array_equal(va, vb)
+            for k in pa:
+                np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
+
+
+def test_deferred_optimizer_step_with_forks_evaluation_and_state_dict():
+    """The pending update is applied before anything else looks at the parameters: a fork (another batch size over the same parameters)
+    stepping in between, evaluate(), load_state_dict() -- the sequence equals the same sequence without deferral bit for bit."""
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 72)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    bA = [gu.make_batch(dims, 8192, 90 + i) for i in range(3)]
+    bB = [gu.make_batch(dims, 1000, 95 + i) for i in range(2)]
+    res = {}
+    for defer in ("1", "0"):
+        os.environ["DVAE_DEFER_APPLY"] = defer
+        try:
+            tr = trainer.Trainer("M2", dims, params, batch=8192, precision="bf16x3")
+            fk = tr.fork(1000)
+            log = []
+            log.append(tr.step(*map(t, bA[0])).cpu().numpy().copy())
+            log.append(fk.step(*map(t, bB[0])).cpu().numpy().copy())            # small batch: cannot defer (falls back), must see A's update
+            log.append(tr.step(*map(t, bA[1])).cpu().numpy().copy())
+            log.append(tr.evaluate(*map(t, bA[2])).cpu().numpy().copy())
+            sd = tr.state_dict()
+            tr.load_state_dict(sd)
+            log.append(tr.step(*map(t, bA[2])).cpu().numpy().copy())
+            log.append(fk.evaluate(*map(t, bB[1])).cpu().numpy().copy())
+            res[defer] = (log, tr.state_dict_numpy(), tr.m.cpu().numpy().copy())
+        finally:
+            os.environ.pop("DVAE_DEFER_APPLY", None)
+    for a, b in zip(res["1"][0], res["0"][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res["1"][2], res["0"][2])
+    for k in res["1"][1]:
+        np.testing.assert_array_equal(res["1"][1][k], res["0"][1][k], err_msg=k)
+
+
+def test_deferred_optimizer_step_never_hangs_when_its_wait_runs_out(monkeypatch):
+    """The arrival wait in front of the first weight load is bounded by wall time: with a bound of zero a workgroup that polls before the
+    others have arrived gives up at once -- the launch completes, the sticky error word turns the loss into NaN (the trainer is to be
+    discarded), nothing waits forever.  (Every workgroup is resident, so with the default bound of 2 s the wait is microseconds.)"""
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 73)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x, y, e = gu.make_batch(dims, 8192, 99)
+    monkeypatch.setenv("DVAE_DEFER_TIMEOUT_MS", "0")
+    tr = trainer.Trainer("M2", dims, params, batch=8192, precision="bf16x3")
+    first = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()                     # nothing pending yet: no wait
+    assert np.all(np.isfinite(first))
+    seen_nan = False
+    for _ in range(4):
+        l = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+        seen_nan = seen_nan or bool(np.isnan(l[0]))
+    torch.cuda.synchronize()
+    assert seen_nan, "a zero bound must trip on a 256-workgroup grid"
 
 
 def test_folded_optimizer_tail_never_hangs_when_its_wait_runs_out(monkeypatch):
