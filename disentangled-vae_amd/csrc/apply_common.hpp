@@ -15,11 +15,23 @@ namespace fused {
 
 // torch.optim.Adam on one element (torch's op order: eps is added after the division by sqrt(bias_correction2))
 __device__ __forceinline__ void adam_element(const ApplyArgs& g, float& pi, float m_old, float v_old, float gi, float& mi, float& vi) {
-    gi *= g.gscale;
-    mi = m_old + g.one_minus_b1 * (gi - m_old);
-    vi = v_old * g.b2 + g.one_minus_b2 * (gi * gi);
+    // Every product and sum is its own correctly rounded operation -- contraction into fused multiply-adds is switched OFF for this body:
+    // the three callers inline it into different surroundings, and a contraction the compiler chose in one and not in another differs in the
+    // last bit (round 4: the in-kernel update and apply_kernel agreed on the first step, where m = v = 0, and differed by one ulp in a
+    // quarter of the elements of m on the second; __fmul_rn / __fadd_rn are plain operators in HIP's headers and do not prevent it).
+#pragma clang fp contract(off)
+    gi = gi * g.gscale;
+    const float dm = gi - m_old;
+    const float wm = g.one_minus_b1 * dm;
+    mi = m_old + wm;
+    const float g2 = gi * gi;
+    const float va = v_old * g.b2;
+    const float vb = g.one_minus_b2 * g2;
+    vi = va + vb;
     const float denom = sqrtf(vi) / g.bc2_sqrt + g.eps;
-    pi = pi - g.step_size * (mi / denom);
+    const float q = mi / denom;
+    const float st = g.step_size * q;
+    pi = pi - st;
 }
 
 // Adam update of parameter idx (gradient gi = the fixed-order slab sum) and the refresh of its kernel-layout weight copies
@@ -140,111 +152,116 @@ __device__ __forceinline__ void store16_sc1(void* base_uniform, int voff_bytes, 
 }
 
 constexpr int DEFER_LDT = 40;     // LDS tile row stride (elements): 32 columns + 8 (80 bytes: 16-byte aligned rows)
-template <typename T, int NP> struct DeferLds { static constexpr int wave_elems = NP * 32 * DEFER_LDT; static constexpr size_t bytes = (size_t)4 * wave_elems * sizeof(T); };
+template <typename T, int NP> struct DeferLds { static constexpr int wave_elems = NP * 8 * DEFER_LDT; static constexpr size_t bytes = (size_t)4 * wave_elems * sizeof(T); };
 
-// one task on one wave (EXEC all ones); `tile` = this wave's LDS scratch
-template <typename T, int NP>
-__device__ __forceinline__ void defer_task(const ApplyArgs& g, const DeferTask tk, T* tile, int lane) {
+// up to four consecutive floats at element `idx` of a wave-uniform array: one 16-byte store (rows of odd length are only 4-byte aligned:
+// gfx950 takes 16-byte accesses at dword alignment), single floats at the ragged end of a row; SC1: write-through
+template <bool SC1>
+__device__ __forceinline__ void store_f4(float* base_uniform, int64_t idx, const f32x4& v, int nv) {
+    if (nv >= 4) {
+        if constexpr (SC1) {
+            typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base_uniform, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, (int)(idx * 4), 0, 16);
+        } else reinterpret_cast<F4U*>(base_uniform + idx)->v = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < nv) {
+                if constexpr (SC1) __hip_atomic_store(base_uniform + idx + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else base_uniform[idx + j] = v[j];
+            }
+    }
+}
+
+// One UNIT of a task on one wave (EXEC all ones): rows r0 + 8 u .. + 7 of the task's 32 x 32 tile (flat tasks: elements 256 u ..), u = 0 .. 3.
+// Element mapping: lane = (rr = lane >> 3, p = lane & 7) = row rr of the unit, columns 4 p .. 4 p + 3 -- a wave instruction covers 8 rows x
+// 128 contiguous bytes, so every load and store of parameters, moments and slabs moves whole lines (a first version gave a lane 16
+// consecutive elements of one row: 64 lines per instruction, each fetched four times, and lone 4-byte stores: 11 us of stores and 7 us of
+// loads).  Units, not tasks, are dealt out to the waves of the grid: 4 x 323 units over 1024 waves is five or six per CU on every CU,
+// where whole tiles gave a quarter of the CUs two tiles and the rest one (the arrival wait ends with the slowest CU).
+// `tile` = this wave's LDS scratch ([planes][8][DEFER_LDT]).
+// COH: the consumers are other workgroups of THIS launch (the deferred form): parameters and copies leave as write-through (sc1) stores;
+// false: plain stores (apply_units_kernel: its own launch, the kernel boundary publishes them)
+template <typename T, int NP, bool COH = true>
+__device__ __forceinline__ void defer_unit(const ApplyArgs& g, const DeferTask tk, int u, T* tile, int lane, int diag = 0) {
     static_assert(sizeof(T) == 2, "deferred step: bf16 copies");
     typedef T Frag8 __attribute__((ext_vector_type(8)));
+    typedef T Frag4 __attribute__((ext_vector_type(4)));
     const TensorDesc d = g.tensors[tk.tensor];                   // wave-uniform
-    const int h = lane >> 5, row = lane & 31;
     const bool flat = tk.kind == 1;
-    const int r = flat ? 0 : tk.r0 + row;
-    const int c = flat ? tk.cbeg + 16 * lane : tk.cbeg + 16 * h;          // first of this lane's 16 consecutive elements
-    int nvalid = (flat || r < d.rows) ? tk.cend - c : 0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > 16 ? 16 : nvalid);
-    const int64_t base = nvalid > 0 ? d.off + (flat ? (int64_t)c : (int64_t)r * d.cols + c) : d.off;      // idle lanes read the tensor's first elements
-    float pn[16];
+    const int p = lane & 7, rr = lane >> 3;
+    const int r = flat ? 0 : tk.r0 + 8 * u + rr;
+    const int c = flat ? tk.cbeg + 4 * (lane + 64 * u) : tk.cbeg + 4 * p;
+    int nv = (flat || r < d.rows) ? tk.cend - c : 0;
+    nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+    const int64_t b4 = nv > 0 ? d.off + (flat ? (int64_t)c : (int64_t)r * d.cols + c) : d.off;       // idle lanes read the tensor's first elements
+    // every load first (rows of odd length are only 4-byte aligned: gfx950 takes 16-byte accesses at dword alignment)
+    const f32x4 pv = reinterpret_cast<const F4U*>(g.p + b4)->v;
+    const f32x4 mv = reinterpret_cast<const F4U*>(g.m + b4)->v;
+    const f32x4 vv = reinterpret_cast<const F4U*>(g.v + b4)->v;
+    constexpr int NSM = 12;
+    f32x4 sv[NSM];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int64_t b8 = nvalid > 8 * f ? base + 8 * f : d.off;
-        // every load first (26 x 16 bytes at <= 12 slabs); rows of odd length are only 4-byte aligned: gfx950 takes dwordx4 at dword alignment
-        f32x4 pv[2], mv[2], vv[2];
+    for (int k = 0; k < NSM; ++k) sv[k] = (diag & 16) ? pv : reinterpret_cast<const F4U*>(g.slabs + (int64_t)(k < g.nslabs ? k : 0) * g.slab_stride + b4)->v;
+    __builtin_amdgcn_sched_barrier(0);
+    float pn[4];
+    f32x4 po, mo, vo;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            pv[q] = reinterpret_cast<const F4U*>(g.p + b8 + 4 * q)->v;
-            mv[q] = reinterpret_cast<const F4U*>(g.m + b8 + 4 * q)->v;
-            vv[q] = reinterpret_cast<const F4U*>(g.v + b8 + 4 * q)->v;
-        }
-        constexpr int NSM = 12;
-        f32x4 sv[NSM][2];
+    for (int j = 0; j < 4; ++j) {
+        float gi = sv[0][j];
 #pragma unroll
-        for (int k = 0; k < NSM; ++k)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) sv[k][q] = reinterpret_cast<const F4U*>(g.slabs + (int64_t)(k < g.nslabs ? k : 0) * g.slab_stride + b8 + 4 * q)->v;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float gi = sv[0][j >> 2][j & 3];
-#pragma unroll
-            for (int k = 1; k < NSM; ++k) if (k < g.nslabs) gi += sv[k][j >> 2][j & 3];       // slab order: apply_kernel's additions
-            float pi = pv[j >> 2][j & 3], mi, vi;
-            adam_element(g, pi, mv[j >> 2][j & 3], vv[j >> 2][j & 3], gi, mi, vi);
-            const bool ok = 8 * f + j < nvalid;
-            if (ok) {
-                __hip_atomic_store(g.p + b8 + j, pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: biases are read by this launch
-                g.m[b8 + j] = mi; g.v[b8 + j] = vi;
-            }
-            pn[8 * f + j] = ok ? pi : 0.f;
-        }
+        for (int k = 1; k < NSM; ++k) if (k < g.nslabs) gi += sv[k][j];                   // slab order: apply_kernel's additions
+        float pi = pv[j], mi, vi;
+        adam_element(g, pi, mv[j], vv[j], gi, mi, vi);
+        po[j] = pi; mo[j] = mi; vo[j] = vi;
+        pn[j] = j < nv ? pi : 0.f;
     }
-    if (flat) return;                                                // wave-uniform
+    if (nv > 0 && !(diag & 8)) {
+        store_f4<COH>(g.p, b4, po, nv);                                                   // sc1: biases are read by this launch
+        store_f4<false>(g.m, b4, mo, nv);
+        store_f4<false>(g.v, b4, vo, nv);
+    }
+    if (flat || (diag & 32)) return;                                 // wave-uniform
     T* const wc = (T*)g.wcopy;
-    Frag8 fh[2], fl[2];
+    Frag4 fh, fl;
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const T ph = (T)pn[8 * f + j];
-            fh[f][j] = ph;
-            fl[f][j] = (T)(pn[8 * f + j] - (float)ph);
-        }
-    if (d.sf_off >= 0) {
-        // forward copy: the lane's 16 parameters are k-step cc / 16 of row rr, its two 8-element fragments the k-step's two halves
-        const int cc = c < d.sf_split ? c : c + d.sf_gap;            // (a tile never straddles the split: cbeg is the start of a column block + a multiple of 32)
-        const int rr = r + d.sf_roff;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            if (nvalid > 8 * f) {
-                const int64_t o = d.sf_off + ((int64_t)((cc >> 4) * d.sf_nt + (rr >> 5)) * 64 + f * 32 + (rr & 31)) * 8;
-                store16_sc1(wc, (int)(o * (int64_t)sizeof(T)), fh[f]);
-                if constexpr (NP == 2) store16_sc1(wc, (int)((o + g.wpl) * (int64_t)sizeof(T)), fl[f]);
-            }
-        }
+    for (int j = 0; j < 4; ++j) {
+        const T ph = (T)pn[j];
+        fh[j] = ph;
+        fl[j] = (T)(pn[j] - (float)ph);
+    }
+    if (d.sf_off >= 0 && nv > 0) {
+        // forward copy: columns 4 p .. 4 p + 3 of the tile are elements 4 (p & 1) .. of fragment half (p >> 1) & 1 of k-step cc / 16:
+        // 8-byte stores, two lanes per 16-byte fragment, 8 rows per 128 contiguous bytes
+        const int cc = (tk.cbeg < d.sf_split ? tk.cbeg : tk.cbeg + d.sf_gap) + 4 * p;   // (a tile never straddles the split: cbeg = start of a column block + a multiple of 32)
+        const int rr2 = r + d.sf_roff;
+        const int64_t o = d.sf_off + ((int64_t)((cc >> 4) * d.sf_nt + (rr2 >> 5)) * 64 + ((cc >> 3) & 1) * 32 + (rr2 & 31)) * 8 + (cc & 4);
+        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wc, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, fh), rs, (int)(o * (int64_t)sizeof(T)), 0, COH ? 16 : 0);
+        if constexpr (NP == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, fl), rs, (int)((o + g.wpl) * (int64_t)sizeof(T)), 0, COH ? 16 : 0);
     }
     if (d.st_off >= 0 && tk.cbeg < d.st_cmax) {                      // wave-uniform
-        // transposed copy: tile[r local][c local] in LDS, read back as 8 consecutive r of one c (ds_read_b64_tr_b16)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            *reinterpret_cast<Frag8*>(tile + row * DEFER_LDT + 16 * h + 8 * f) = fh[f];
-            if constexpr (NP == 2) *reinterpret_cast<Frag8*>(tile + 32 * DEFER_LDT + row * DEFER_LDT + 16 * h + 8 * f) = fl[f];
-        }
+        // transposed copy: the unit's [8 r][32 c] in LDS, read back as the 8 consecutive r of one c (ds_read_b64_tr_b16): lanes 0 .. 31 the
+        // hi plane, lanes 32 .. 63 the lo plane
+        *reinterpret_cast<Frag4*>(tile + rr * DEFER_LDT + 4 * p) = fh;
+        if constexpr (NP == 2) *reinterpret_cast<Frag4*>(tile + 8 * DEFER_LDT + rr * DEFER_LDT + 4 * p) = fl;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave's own writes (LDS operations of one wave complete in order)
-        const int l31 = lane & 31, i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
-        const T* blk = tile + q * DEFER_LDT + 16 * cg + 4 * pp;
-        const int ct = tk.cbeg + l31;                                 // this lane's row of the transposed matrix
-        const bool okc = ct < tk.cend && ct < d.st_cmax;
+        const int h = lane >> 5, l31 = lane & 31, i16 = l31 & 15, q = i16 >> 2, pp = i16 & 3, cg = l31 >> 4;
+        const T* bp = tile + (NP == 2 ? h : 0) * 8 * DEFER_LDT + q * DEFER_LDT + 16 * cg + 4 * pp;
         typedef short s16x8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gq = h + 2 * i;                                 // rows 8 gq .. 8 gq + 7 of the tile
-            Frag8 tf[NP];
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) {
-                const T* bp = blk + pl * 32 * DEFER_LDT;
-                const s16x4 r0v = lds_tr16(bp + (8 * gq) * DEFER_LDT), r1v = lds_tr16(bp + (8 * gq + 4) * DEFER_LDT);
-                const s16x8 raw = {r0v[0], r0v[1], r0v[2], r0v[3], r1v[0], r1v[1], r1v[2], r1v[3]};
-                tf[pl] = __builtin_bit_cast(Frag8, raw);
-            }
-            const int colT = tk.r0 + 8 * gq + d.st_roff;
-            if (okc && tk.r0 + 8 * gq < d.rows) {
-                const int64_t o = d.st_off + ((int64_t)((colT >> 4) * d.st_nt + (ct >> 5)) * 64 + ((colT >> 3) & 1) * 32 + (ct & 31)) * 8;
-                store16_sc1(wc, (int)(o * (int64_t)sizeof(T)), tf[0]);
-                if constexpr (NP == 2) store16_sc1(wc, (int)((o + g.wpl) * (int64_t)sizeof(T)), tf[1]);
-            }
+        const s16x4 r0v = lds_tr16(bp), r1v = lds_tr16(bp + 4 * DEFER_LDT);
+        const s16x8 raw = {r0v[0], r0v[1], r0v[2], r0v[3], r1v[0], r1v[1], r1v[2], r1v[3]};
+        const Frag8 tf = __builtin_bit_cast(Frag8, raw);
+        const int ct = tk.cbeg + l31;                                 // this lane's row of the transposed matrix
+        const int colT = tk.r0 + 8 * u + d.st_roff;
+        if (ct < tk.cend && ct < d.st_cmax && tk.r0 + 8 * u < d.rows && (NP == 2 || h == 0)) {
+            const int64_t o = d.st_off + ((int64_t)((colT >> 4) * d.st_nt + (ct >> 5)) * 64 + ((colT >> 3) & 1) * 32 + (ct & 31)) * 8 + (NP == 2 && h ? g.wpl : 0);
+            if constexpr (COH) store16_sc1(wc, (int)(o * (int64_t)sizeof(T)), tf);
+            else *reinterpret_cast<Frag8*>(wc + o) = tf;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the tile is free for the wave's next task
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the tile is free for the wave's next unit
     }
 }
 

@@ -32,12 +32,13 @@ struct ApplyArgs {
 struct DeferTask { int32_t tensor, r0, cbeg, cend, kind, pad0, pad1, pad2; };   // kind 0: rows r0.., parameter columns cbeg.. (< cend) of `tensor`; kind 1: elements cbeg.. (< cend)
 constexpr int DEFER_SHARDS = 32;
 struct DeferArgs {
-    int on;                       // 1: this launch finalises its own loss scalars (the deferred protocol); 0: off
+    int on;                       // 1: the deferred protocol (the loss scalars come from an extra workgroup of the weight-gradient launch); 0: off
     int have;                     // a pending update exists: run the tasks and the arrival protocol
+    int diag;                     // timing diagnostics (wrong results): bit 0 skip the tasks, bit 1 skip the arrival wait, bit 2 skip the loss finalisation
     ApplyArgs a;
     const DeferTask* tasks; int ntasks;
     unsigned* shard;              // DEFER_SHARDS counters, 32 words (128 bytes) apart
-    unsigned* done;               // arrivals of finished workgroups (loss finalisation)
+    unsigned* done;               // (unused)
     unsigned* err;                // sticky error word (a bounded wait ran out)
     unsigned seq_arrive;          // number of this launch among the workspace's deferred launches that carry an update (1, 2, ...)
     unsigned seq_done;            // ... among all its deferred launches

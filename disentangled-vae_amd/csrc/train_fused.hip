@@ -1346,10 +1346,18 @@ template <typename P>
 __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
                                                         int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride,
                                                         const RawIn ri, int use_raw, const unsigned* __restrict__ ylo_epoch, unsigned launch_id,
-                                                        const ApplyArgs fold_apply, const FoldArgs fold) {
+                                                        const ApplyArgs fold_apply, const FoldArgs fold, int fin_block, const unsigned* fin_err) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // deferred optimizer step (apply_common.hpp): the step's loss scalars no longer come from an optimizer launch -- ONE extra workgroup of
+    // this launch (it follows the rows kernel, whose partial sums are complete) reduces them, on a CU the weight-gradient blocks leave free
+    if (fin_block >= 0 && (int)blockIdx.x == fin_block) {
+        finalize_losses(fold_apply, reinterpret_cast<double (*)[4]>(wsm));
+        if (threadIdx.x == 0 && fin_err != nullptr && __hip_atomic_load(fin_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            fold_apply.losses3[0] = __builtin_nanf("");              // a bounded wait of the rows kernel ran out: the update was not complete
+        return;
+    }
     // Workgroup -> (slice, block), XCD-aware (workgroup i runs on XCD i % 8).  The first 8 * (ksplit / 8) slices are "pure": slice s lives
     // on XCD s % 8 with all of its blocks, so every stash line of it crosses the fabric once.  The ksplit % 8 remaining slices are
     // dealt out block-wise, `per` consecutive blocks (neighbours share their A tiles) of them per XCD: a few lines are fetched by
@@ -1465,6 +1473,26 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     if (t == 255) return;
     const TensorDesc d = g.tensors[t];
     apply_element<T, ADAM, NP>(g, idx, d, pi, m_old, v_old, gi);
+}
+
+// The optimizer step by UNITS (apply_common.hpp: defer_unit -- 8 rows x 32 columns of one weight matrix per wave, whole-line loads of
+// parameters / moments / slabs, the kernel-layout copies as whole 8- and 16-byte pieces through the transposing LDS read): the same
+// element arithmetic as apply_kernel on the same slab sums (bit-identical, tested), a quarter of its instructions, no lone 2-byte stores.
+// One unit per wave; the block after the last unit block finalises the loss scalars.  bf16 / bf16x3 copies.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void apply_units_kernel(const ApplyArgs g, const DeferTask* __restrict__ tasks, int nunits) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * DeferLds<T, NP>::wave_elems * sizeof(T) > 128 ? 4 * DeferLds<T, NP>::wave_elems * sizeof(T) : 128];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (g.losses3 == nullptr) return;
+        finalize_losses(g, reinterpret_cast<double (*)[4]>(sm));
+        return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // unit un of the launch: consecutive units of a tile on different workgroups (a tile's four units share lines at odd row lengths)
+    const int un = wave * ((int)gridDim.x - 1) + (int)blockIdx.x;
+    if (un >= nunits) return;
+    T* const tile = reinterpret_cast<T*>(sm) + wave * DeferLds<T, NP>::wave_elems;
+    defer_unit<T, NP, false>(g, tasks[un >> 2], un & 3, tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1890,6 +1918,21 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
                         bool adam, int step, double lr, double beta1, double beta2, double adam_eps, double grad_scale,
                         float* losses3, hipStream_t s) {
     const ApplyArgs a = make_apply_args(plan, L, params, m, v, ws, n_slabs, adam, step, lr, beta1, beta2, adam_eps, grad_scale, losses3);
+    // DVAE_APPLY=units (opt-in; bf16 copies, at most 12 slabs): the unit form of the deferred step as its own launch.  Measured (M2 y513,
+    // 8192 frames, bf16x3, same box, alternating): 10.8 against 9.4 us gross for the one-thread-per-parameter kernel below -- a quarter of the
+    // instructions and no lone 2-byte stores, but 324 workgroups instead of 1183 on a launch that is one load round trip, one store round
+    // trip and its own start-up either way: the flat kernel stays the default.
+    const int ntasks = defer_state_get(ws).ntasks;
+    const char* ak = getenv("DVAE_APPLY");
+    if (adam && is_bf(plan->precision) && n_slabs <= 12 && ntasks > 0 && ntasks <= DEFER_MAX_TASKS && ak && strcmp(ak, "units") == 0) {
+        const int nunits = 4 * ntasks;
+        const dim3 gu((unsigned)((nunits + 3) / 4 + 1));
+        const DeferTask* tasks = (const DeferTask*)(ws + L.o_defer);
+        if (plan->precision == DVAE_PREC_BF16X3) hipLaunchKernelGGL((apply_units_kernel<__bf16, 2>), gu, dim3(256), 0, s, a, tasks, nunits);
+        else hipLaunchKernelGGL((apply_units_kernel<__bf16, 1>), gu, dim3(256), 0, s, a, tasks, nunits);
+        DVAE_LAUNCH_OK("apply_units_kernel");
+        return 0;
+    }
     const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
     if (plan->precision == DVAE_PREC_BF16X3) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true, 2>), grid, dim3(256), 0, s, a);
@@ -2020,9 +2063,18 @@ static bool defer_possible(const dvae_train_plan_t* plan, const void* ws) {
     (void)hipGetDevice(&dev);
     const int nt = defer_state_get(ws).ntasks;
     if (nt <= 0 || nt > DEFER_MAX_TASKS) return false;
-    if (plan->rows_grid > device_cu_count(dev) || 8 * plan->rows_grid < nt) return false;
+    if (plan->rows_grid > device_cu_count(dev) || 8 * plan->rows_grid < 4 * nt) return false;      // at most two 8-row units per chain wave
+    if (wgrad_form(getenv("DVAE_WGRAD")) != 4 || plan->Bp <= 128) return false;      // the loss scalars come from an extra workgroup of wgrad4_kernel
     const int64_t kper = kper_of(plan);
     return (plan->Bp + kper - 1) / kper <= 12;
+}
+
+extern "C" int dvae_train_can_defer(const dvae_train_plan_t* plan, const void* ws) {
+    if (!plan || !ws) return 0;
+    // OPT-IN (DVAE_DEFER_APPLY=1): bit-identical and, on the MI355X, not faster -- see DESIGN.md (round 4, item 3) for the ablation
+    const char* de = getenv("DVAE_DEFER_APPLY");
+    if (!(de && atoi(de) == 1) || getenv("DVAE_FOLD_APPLY") != nullptr) return 0;
+    return defer_possible(plan, ws) ? 1 : 0;
 }
 
 extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
@@ -2069,6 +2121,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     if (g_defer_req.on) {
         const PendingUpdate& u = g_defer_req.u;
         a.defer.on = 1; a.defer.have = g_defer_req.have ? 1 : 0;
+        { const char* e = getenv("DVAE_DEFER_DIAG"); a.defer.diag = e ? atoi(e) : 0; }
         a.defer.a = g_defer_req.have ? make_apply_args(plan, L, u.params, u.m, u.v, w, u.n_slabs, true, u.step, u.lr, u.beta1, u.beta2, u.adam_eps, 1.0, g_defer_req.losses3)
                                      : make_apply_args(plan, L, const_cast<float*>(params), nullptr, nullptr, w, 1, false, 1, 0, 0, 0, 0, 0, g_defer_req.losses3);
         a.defer.tasks = (const DeferTask*)(w + L.o_defer); a.defer.ntasks = defer_state_get(ws).ntasks;
@@ -2190,9 +2243,17 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             { const char* e = getenv("DVAE_FOLD_MAX_POLLS"); if (e) fold.max_polls = (unsigned)strtoul(e, nullptr, 10); }
             g_fold.done = true;
         }
-        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id, fa_apply, fold);
-        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold);
-        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold);
+        int fin_block = -1;
+        const unsigned* fin_err = nullptr;
+        dim3 g3l = g3;
+        if (a.defer.on) {                                             // + one workgroup that turns the rows kernel's partial sums into the loss scalars
+            fa_apply = a.defer.a;
+            fin_block = (int)g3.x; fin_err = a.defer.err;
+            g3l = dim3(g3.x + 1);
+        }
+        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3l, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id, fa_apply, fold, fin_block, fin_err);
+        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3l, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
+        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3l, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
         DVAE_LAUNCH_OK("wgrad4_kernel");
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
@@ -2281,8 +2342,7 @@ extern "C" int dvae_train_step_deferred(const dvae_train_plan_t* plan, float* pa
                                         const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
                                         int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream) {
     DVAE_CHECK_ARG(plan && params && m && v && ws && step >= 1 && losses3, "train_step_deferred: bad argument");
-    const char* de = getenv("DVAE_DEFER_APPLY");
-    if ((de && atoi(de) == 0) || getenv("DVAE_FOLD_APPLY") != nullptr || !defer_possible(plan, ws))
+    if (!dvae_train_can_defer(plan, ws))
         return dvae_train_step(plan, params, m, v, ws, x, ldx, y, ldy, eps_noise, elbo_eps, step, lr, beta1, beta2, adam_eps, losses3, stream);   // flushes first
     DeferState st = defer_state_get(ws);
     g_defer_req = DeferRequest();

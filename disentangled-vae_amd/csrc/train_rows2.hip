@@ -189,7 +189,10 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         constexpr int D = OFFL ? P::PDO : P::PD;
         typedef Sched<P, YP, YENC, D, INFO> SC;
         typedef HSched<P, YP, YENC, DH, INFO> HS;
-        typedef WStream<P, SC, D, DEFER ? 16 : R2_WAUX> WS;
+#ifndef R2_DEFER_WAUX
+#define R2_DEFER_WAUX 0
+#endif
+        typedef WStream<P, SC, D, DEFER ? R2_DEFER_WAUX : R2_WAUX> WS;
         constexpr unsigned FBB = SC::FBB;
         WS ws;
         ws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
@@ -219,22 +222,23 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             // ---- the previous step's optimizer update (apply_common.hpp): this wave's tasks, then the arrival of every wave of the grid
             if (g.defer.have) {
                 T* const tile = reinterpret_cast<T*>(keep) + cw * DeferLds<T, NP>::wave_elems;      // `keep` is free until the first epilogue
-                for (int task = cw * (int)gridDim.x + (int)blockIdx.x; task < g.defer.ntasks; task += 4 * (int)gridDim.x)
-                    defer_task<T, NP>(g.defer.a, g.defer.tasks[task], tile, lane);
+                if (!(g.defer.diag & 1))
+                for (int un = cw * (int)gridDim.x + (int)blockIdx.x; un < 4 * g.defer.ntasks; un += 4 * (int)gridDim.x)      // units: consecutive ones on different CUs
+                    defer_unit<T, NP>(g.defer.a, g.defer.tasks[un >> 2], un & 3, tile, lane, g.defer.diag);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's write-through stores have left
                 if (lane == 0)
                     __hip_atomic_fetch_add(g.defer.shard + 32 * (((int)blockIdx.x * 4 + cw) & (DEFER_SHARDS - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cw == 0) {
+                if (cw == 0 && !(g.defer.diag & 2)) {
                     // waves (b, w) with (4 b + w) mod 32 == s add to shard s: its value after this launch is seq_arrive x that count
                     const int nw = 4 * (int)gridDim.x, sh = lane & (DEFER_SHARDS - 1);
                     const unsigned want = g.defer.seq_arrive * (unsigned)((nw - sh + DEFER_SHARDS - 1) / DEFER_SHARDS);
                     const unsigned long long deadline = wall_clock64() + g.defer.timeout_ticks;
                     bool ok = true;
-                    for (;;) {
+                    for (unsigned it_ = 0;; ++it_) {
                         const unsigned have = __hip_atomic_load(g.defer.shard + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__ballot((int)(have - want) < 0) == 0ull) break;
-                        if (wall_clock64() >= deadline) { ok = false; break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        if ((it_ & 15u) == 15u && wall_clock64() >= deadline) { ok = false; break; }      // (the clock read is a scalar memory operation: not every lap)
+                        __builtin_amdgcn_s_sleep(1);
                     }
                     if (!ok && lane == 0) __hip_atomic_store(g.defer.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -643,38 +647,6 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
         }
         R2_STAMP(15);
         if (g.dbg && tid == 0) g.dbg[(size_t)blockIdx.x * 32 + 31] = clock64();
-        if constexpr (DEFER) {
-            // loss scalars by the workgroup whose partial sums arrive last (apply_kernel's reduction shape: 256 strided threads, wave sums,
-            // four wave totals in order).  Partial sums leave as sc1 stores and are read back with sc1 loads.
-            double* const pr = g.partials + 4 * (size_t)blockIdx.x;
-            if (tid == 0) {
-                __hip_atomic_store(pr, tot_rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pr + 1, tot_kl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pr + 2, tot_bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pr + 3, tot_ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned old = __hip_atomic_fetch_add(g.defer.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                flags[1] = old + 1u == g.defer.seq_done * gridDim.x ? 1 : 0;
-            }
-            wg_barrier();                                                   // BFIN1
-            if (__builtin_amdgcn_readfirstlane(flags[1]) != 0) {
-                double (*redd)[4] = reinterpret_cast<double (*)[4]>(keep);
-                double a = 0.0, k = 0.0, c = 0.0, x = 0.0;
-                for (int i = tid; i < g.defer.a.npartials; i += 256) {
-                    a += __hip_atomic_load(g.defer.a.partials + 4 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    k += __hip_atomic_load(g.defer.a.partials + 4 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    c += __hip_atomic_load(g.defer.a.partials + 4 * i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x += __hip_atomic_load(g.defer.a.partials + 4 * i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                a = wave_sum(a); k = wave_sum(k); c = wave_sum(c); x = wave_sum(x);
-                if (lane == 0) { redd[cw][0] = a; redd[cw][1] = k; redd[cw][2] = c; redd[cw][3] = x; }
-                wg_barrier();                                               // BFIN2
-                if (tid == 0) {
-                    write_losses(g.defer.a, redd);
-                    if (__hip_atomic_load(g.defer.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) g.defer.a.losses3[0] = __builtin_nanf("");
-                }
-            }
-        } else
         if (tid == 0) {
             g.partials[4 * blockIdx.x] = tot_rec;
             g.partials[4 * blockIdx.x + 1] = tot_kl;
@@ -1144,10 +1116,6 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 } else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
             }
             wg_barrier();                                               // BRED
-        }
-        if constexpr (DEFER) {
-            wg_barrier();                                                   // BFIN1
-            if (__builtin_amdgcn_readfirstlane(flags[1]) != 0) wg_barrier();   // BFIN2
         }
     }
 }

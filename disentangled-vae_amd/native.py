@@ -66,6 +66,7 @@ SIGNATURES = {
     "dvae_train_step_deferred": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_d, c_d, c_d, c_d, c_vp, c_vp]),
     "dvae_train_flush": (c_i, [c_vp, c_vp, c_vp]),
     "dvae_train_pending": (c_i, [c_vp]),
+    "dvae_train_can_defer": (c_i, [c_vp, c_vp]),
     "dvae_train_eval": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_vp, c_vp]),
     "dvae_train_noise": (c_i, [c_vp, ctypes.c_uint64, c_vp, c_vp]),
     "dvae_module_forward": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_i, c_vp]),

@@ -80,9 +80,10 @@ class Trainer:
         self.precision = precision
         self.lr, self.betas, self.adam_eps, self.elbo_eps = lr, betas, adam_eps, elbo_eps
         self.pg, self.world = process_group, int(world)
-        # two launches per step (the optimizer update deferred into the next step's rows kernel) unless DVAE_DEFER_APPLY=0; single-GPU only:
-        # the data-parallel step puts the gradient exchange between the weight-gradient kernel and the update
-        self._defer = int(world) == 1 and os.environ.get("DVAE_DEFER_APPLY", "1") != "0"
+        # DVAE_DEFER_APPLY=1 (opt-in): two launches per step, the optimizer update deferred into the next step's rows kernel -- bit-identical,
+        # measured NOT faster on the MI355X; single-GPU only: the data-parallel step puts the gradient exchange
+        # between the weight-gradient kernel and the update
+        self._defer = int(world) == 1 and os.environ.get("DVAE_DEFER_APPLY", "0") == "1"
         self.y_dim = 0 if model == "M1" else int(dims["y_dim"])
         self.plan = TrainPlan()
         N.check(self.lib.dvae_train_plan(MODEL_CODE[model], self.y_dim, PREC_CODE[precision], self.B, ksplit, ctypes.byref(self.plan)),

@@ -123,8 +123,8 @@ int dvae_train_step(const dvae_train_plan_t* plan, float* params, float* m, floa
  * dvae_train_step_deferred on the same workspace or dvae_train_flush.  Every other entry point of this header flushes first by itself;
  * a caller that reads or writes params / m / v directly must call dvae_train_flush before (dvae_train_repack refuses while an update is
  * pending).  Results are bit-identical to dvae_train_step (same slab sums, same element arithmetic).  Falls back to dvae_train_step when
- * the plan cannot defer (M2_info, the 4-wave rows kernel, grids smaller than the update's task list or larger than the CUs;
- * DVAE_DEFER_APPLY=0).  The same params / m / v pointers and hyper-parameter semantics as dvae_train_step. */
+ * the plan cannot defer (M2_info, the 4-wave rows kernel, grids smaller than the update's task list or larger than the CUs) and unless
+ * DVAE_DEFER_APPLY=1 is set: measured on the MI355X the two-launch step is bit-identical and NOT faster, so it is opt-in.  The same params / m / v pointers and hyper-parameter semantics as dvae_train_step. */
 int dvae_train_step_deferred(const dvae_train_plan_t* plan, float* params, float* m, float* v, void* ws,
                              const float* x, int ldx, const float* y, int ldy, const float* eps_noise, float elbo_eps,
                              int step, double lr, double beta1, double beta2, double adam_eps, float* losses3, void* stream);
@@ -132,6 +132,8 @@ int dvae_train_step_deferred(const dvae_train_plan_t* plan, float* params, float
 int dvae_train_flush(const dvae_train_plan_t* plan, void* ws, void* stream);
 /* 1 when an update is pending on `ws`. */
 int dvae_train_pending(const void* ws);
+/* 1 when dvae_train_step_deferred would defer on this plan / workspace / device / environment (otherwise it is dvae_train_step). */
+int dvae_train_can_defer(const dvae_train_plan_t* plan, const void* ws);
 
 /* Validation pass of the scripts (scripts/training_M2.py:176-193: forward + elbo, no backward, no update):
  * rows kernel + loss finalisation only.  losses3 as for dvae_train_apply. */
