@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdvae_hip.so")
 ARCH = "gfx950"
+# per-file flags (the reason stands at the top of the file named)
+FILE_FLAGS = {"mcem_mstep.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -42,7 +44,7 @@ def build(force=False, verbose=True):
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in deps if p.endswith((".hpp", ".h"))]):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"] + os.environ.get("DVAE_CFLAGS", "").split()
+               "-Wall", "-Wno-unused-function"] + FILE_FLAGS.get(os.path.basename(src), []) + os.environ.get("DVAE_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -536,16 +536,20 @@ __global__ __launch_bounds__(FT) void mstep_frames_kernel(const float* __restric
     }
 }
 
+// (the register-resident form of this kernel, mstep_frames_reg_kernel, lives in mcem_mstep.hip: it is compiled without SLP vectorisation)
+namespace mstep { int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
+                                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s); }
+
 // per utterance: W = Wun / norm (mcem.py:132), cost = mean over (R, F, N_u) of the tile partials
 __global__ __launch_bounds__(256) void mstep_finish_kernel(const float* __restrict__ Wun, const float* __restrict__ norms, int K, float* __restrict__ W,
                                                            const double* __restrict__ partial, int R, int64_t N,
                                                            const int* __restrict__ seg_start, const int* __restrict__ seg_count,
-                                                           float* __restrict__ cost) {
+                                                           float* __restrict__ cost, int tile_frames) {
     const int u = blockIdx.x;
     const int64_t o = (int64_t)u * XD * K;
     for (int i = threadIdx.x; i < XD * K; i += 256) W[o + i] = Wun[o + i] / norms[u * KMAX + i % K];
     const int64_t nbeg = seg_start ? seg_start[u] : 0, cnt = seg_count ? seg_count[u] : N;
-    const int t0 = (int)(nbeg / 32), t1 = (int)((nbeg + cnt + 31) / 32);
+    const int t0 = (int)(nbeg / tile_frames), t1 = (int)((nbeg + cnt + tile_frames - 1) / tile_frames);
     __shared__ double red[4];
     double c = 0.0;
     for (int i = t0 + threadIdx.x; i < t1; i += 256) c += partial[i];
@@ -692,7 +696,7 @@ extern "C" int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weight
 static size_t mstep_ws_layout(int64_t N, int K, int U, size_t* o_norms, size_t* o_partial) {
     size_t o = ((size_t)U * XD * K * sizeof(float) + 255) / 256 * 256;
     *o_norms = o; o += ((size_t)U * KMAX * sizeof(float) + 255) / 256 * 256;
-    *o_partial = o; o += ((size_t)((N + 31) / 32) * sizeof(double) + 255) / 256 * 256;
+    *o_partial = o; o += ((size_t)((N + 15) / 16) * sizeof(double) + 255) / 256 * 256;      // one cost partial per 16-frame tile
     return o;
 }
 
@@ -720,6 +724,16 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     const int ntiles = (int)((N + 31) / 32);
     hipLaunchKernelGGL(mstep_w_kernel, dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun, seg_start, seg_count);
     DVAE_LAUNCH_OK("mstep_w_kernel");
+    // DVAE_MSTEP=3pass keeps the round-1 kernel (three reads of Vs); R > 10 samples always take it
+    const char* mk = getenv("DVAE_MSTEP");
+    const bool reg_form = R <= 10 && K == 10 && (int64_t)R * XD * N * 4 < (int64_t)0x7fffffff && !(mk && strcmp(mk, "3pass") == 0);      // (rank 10: mcem.py / scripts/evaluate_ntcd_M2.py:66)
+    if (reg_form) {
+        const int rcf = mstep::launch_frames_reg(X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, s);
+        if (rcf) return rcf;
+        hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost, 16);
+        DVAE_LAUNCH_OK("mstep_finish_kernel");
+        return 0;
+    }
     const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + 16 * 2 * K * 32 + 2 * K * 32) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -730,7 +744,7 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     }
     hipLaunchKernelGGL(mstep_frames_kernel, dim3(ntiles), dim3(FT), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
     DVAE_LAUNCH_OK("mstep_frames_kernel");
-    hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost);
+    hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost, 32);
     DVAE_LAUNCH_OK("mstep_finish_kernel");
     return 0;
 }

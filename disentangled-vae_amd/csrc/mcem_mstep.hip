@@ -1,0 +1,196 @@
+// M-step of the MCEM loop (EM.M_step, packages/models/mcem.py:91-153), H / g / cost part with the sample variances held in registers.
+// Own translation unit: built with -fno-slp-vectorize (disentangled-vae_amd/build.py).  Under plain -O3 hipcc pairs the 170 register-resident
+// values of a thread into 64-bit tuples for packed fp32 arithmetic (v_pk_fma_f32), defines the halves of a tuple at different times and
+// spills 300 - 500 registers around the loads; the packed forms are no faster on gfx950 either (MI355X_MICROARCH.md, cycle constants).
+#include <stdlib.h>
+#include "common.hpp"
+#include "fused_tiles.hpp"
+
+namespace dvae {
+namespace fused {
+
+constexpr int KMAX = 16;
+
+// 1 / x for the positive, normal variances of the M-step: the hardware reciprocal (1 ulp).  The IEEE division sequence (v_div_scale x 2,
+// v_rcp, four v_fma, v_div_fmas, v_div_fixup) and even one Newton step on top of v_rcp_f32 tip hipcc's allocation of this kernel from 20
+// to 150 spilled registers (170 of a thread's 256 hold the sample variances); sums of ten such terms per bin are compared with the
+// reference at 1e-5 (tests/test_gpu_mcem.py), three orders above the reciprocal's error.
+__device__ __forceinline__ float rcp_pos(float x) { return __builtin_amdgcn_rcpf(x); }
+
+constexpr int FT16 = 512, FJ16 = 17;
+template <int RR, int K>
+__global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int,
+                                                                const float* __restrict__ Wun_all, float* __restrict__ H, float* __restrict__ g,
+                                                                float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial,
+                                                                const int* __restrict__ seg_start, const int* __restrict__ seg_count,
+                                                                const int* __restrict__ tile_seg) {
+    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [8][2K][16], then sums [2K][16]
+    float* wpart = lw + (XD * K + 3) / 4 * 4;
+    float* sums = wpart + 8 * 2 * K * 16;
+    __shared__ float nrm[KMAX];
+    __shared__ double redc[8];
+    const int tid = threadIdx.x, fr = tid & 15, grp = tid >> 4, lane = tid & 63, wave = tid >> 6;
+    const int u = tile_seg ? tile_seg[blockIdx.x >> 1] : 0;        // the segment table is per 32 frames
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int64_t nend = seg_start ? (int64_t)seg_start[u] + seg_count[u] : N;
+    const bool live = n0 + fr < nend;
+    const bool any_live = n0 < nend;                               // (the second half of a segment's last 32 frames may be all padding)
+    const int64_t n = live ? n0 + fr : (any_live ? nend - 1 : n0); // padding frames read a valid column
+    const int64_t FN = (int64_t)XD * N;
+    const float* Wun = Wun_all + (int64_t)u * XD * K;
+    // Vs of this thread's (bin, frame) pairs: requested first
+    // Buffer accesses throughout: ONE per-lane byte offset (bin grp, frame n) for Vs, X2 and Vb, everything else -- the sample r, the bin
+    // step 32 j -- in the scalar offset.  With plain 64-bit addresses hipcc computes the 170 + 17 + 17 of them ahead of the loads, keeps
+    // them live through the three passes and spills 500 registers.  The host takes this kernel only while R F N floats stay below 2 GB;
+    // bins past 512 (j = 16, grp > 0) read inside the buffer or get the buffer's out-of-range zero and are never used.
+    float vs[FJ16][RR];
+    const int voff = (int)(((int64_t)grp * N + n) * 4);
+    const unsigned jstep = (unsigned)(32 * N * 4);
+    const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, (int)((int64_t)R * FN * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, (int)(FN * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(Vb, 0, (int)(FN * 4), 0x00020000);
+    auto x2_at = [&](int j) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, (int)(jstep * (unsigned)j), 0)); };
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const unsigned soff = jstep * (unsigned)j + (unsigned)((int64_t)(r < R ? r : 0) * FN * 4);
+            vs[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, voff, (int)soff, 0));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = tid; i < XD * K; i += FT16) lw[i] = Wun[i];
+    __syncthreads();
+    if (tid < 16 * K) {                                            // column norms of the un-normalised W (mcem.py:130): 16 threads per column
+        const int k = tid >> 4, q = tid & 15;
+        float s = 0.f;
+        for (int f = q; f < XD; f += 16) s += fabsf(lw[f * K + k]);
+        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+        if (q == 0) { nrm[k] = s; if (n0 == (seg_start ? seg_start[u] : 0)) norms_out[u * KMAX + k] = s; }
+    }
+    float hk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) hk[k] = H[(int64_t)k * N + n];
+    const float gn = g[n];
+
+    // sum over the 32 bin groups of `cnt` per-thread values: wave shuffles (4 groups per wave), LDS (8 waves)
+    auto group_sums = [&](auto& v, int cnt) {
+        constexpr int M = (int)(sizeof(v) / sizeof(float));
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i < cnt) {
+                float a = v[i];
+                a += __shfl_xor(a, 16, 64);
+                a += __shfl_xor(a, 32, 64);
+                if (lane < 16) wpart[(wave * cnt + i) * 16 + fr] = a;
+            }
+        }
+        __syncthreads();
+        if (grp < cnt) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += wpart[(w * cnt + grp) * 16 + fr];
+            sums[grp * 16 + fr] = a;
+        }
+        __syncthreads();
+    };
+
+    // ---- H update (mcem.py:118-123) with Vb = Wun H ----
+    float acc[2 * K];
+#pragma unroll
+    for (int k = 0; k < 2 * K; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j) {
+        const int f = grp + 32 * j;
+        if (f < XD) {
+            float vb = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) vb = fmaf(lw[f * K + k], hk[k], vb);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) { if (r < R) { const float inv = rcp_pos(fmaf(gn, vs[j][r], vb)); a1 += inv; a2 += inv * inv; } if (r & 1) __builtin_amdgcn_sched_barrier(0); }   // (two divisions in flight: ten interleaved IEEE sequences hold 80 temporaries)
+            const float p2 = x2_at(j) * a2;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const float w = lw[f * K + k]; acc[2 * k] = fmaf(w, p2, acc[2 * k]); acc[2 * k + 1] = fmaf(w, a1, acc[2 * k + 1]); }
+        }
+        __builtin_amdgcn_sched_barrier(0);        // one bin at a time: hoisting every bin's W row above the loop costs 110 more registers
+    }
+    group_sums(acc, 2 * K);
+#pragma unroll
+    for (int k = 0; k < K; ++k) hk[k] = hk[k] * sqrtf(sums[(2 * k) * 16 + fr] / sums[(2 * k + 1) * 16 + fr]);
+    __syncthreads();
+
+    // ---- new Vb = Wun Hnew (mcem.py:126); g update (mcem.py:137-143) ----
+    float gv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j) {
+        const int f = grp + 32 * j;
+        if (f < XD) {
+            float vb = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) vb = fmaf(lw[f * K + k], hk[k], vb);
+            if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vb), rs_vb, voff, (int)(jstep * (unsigned)j), 0);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) { if (r < R) { const float v = vs[j][r]; const float inv = rcp_pos(fmaf(gn, v, vb)); s1 = fmaf(v, inv, s1); s2 = fmaf(v, inv * inv, s2); } if (r & 1) __builtin_amdgcn_sched_barrier(0); }
+            gv[0] = fmaf(x2_at(j), s2, gv[0]); gv[1] += s1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    group_sums(gv, 2);
+    const float gnew = gn * sqrtf(sums[fr] / sums[16 + fr]);
+
+    // ---- cost (mcem.py:69-71) with the updated g; H is stored normalised (mcem.py:134).  log through the hardware log2 (~1 ulp of log2) ----
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j) {
+        const int f = grp + 32 * j;
+        if (f < XD) {
+            float vb = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) vb = fmaf(lw[f * K + k], hk[k], vb);
+            const float x2 = x2_at(j);
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) { if (r < R) { const float vx = fmaf(gnew, vs[j][r], vb); s += __builtin_amdgcn_logf(vx) * 0.693147180559945309f + x2 * rcp_pos(vx); } if (r & 1) __builtin_amdgcn_sched_barrier(0); }
+            c += (double)s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!live) c = 0.0;
+    c = wave_sum(c);
+    if (lane == 0) redc[wave] = c;
+    if (grp == 0 && live) {
+        g[n] = gnew;
+#pragma unroll
+        for (int k = 0; k < K; ++k) H[(int64_t)k * N + n] = hk[k] * nrm[k];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 8; ++w) t += redc[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+
+namespace mstep {
+int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
+                      float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
+    const int nt16 = (int)((N + 15) / 16);
+    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + 8 * 2 * K * 16 + 2 * K * 16) * sizeof(float);
+    static bool attr_done16 = false;
+    if (!attr_done16) {
+        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + 8 * 2 * KMAX * 16 + 2 * KMAX * 16) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_reg_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
+        attr_done16 = true;
+    }
+    hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10>), dim3(nt16), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    DVAE_LAUNCH_OK("mstep_frames_reg_kernel");
+    return 0;
+}
+}  // namespace mstep
+
+}  // namespace fused
+}  // namespace dvae
