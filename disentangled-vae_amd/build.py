@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdvae_hip.so")
+DIAG_LIB = os.path.join(HERE, "libdvae_hip_diag.so")     # --diag: product kernels + the measured-slower alternates (csrc/common.hpp: DVAE_DIAG)
 ARCH = "gfx950"
 # per-file flags (the reason stands at the top of the file named)
 FILE_FLAGS = {"mcem_mstep.hip": ["-fno-slp-vectorize"]}
@@ -22,29 +23,36 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _newer_than_lib(paths):
+def _newer_than_lib(paths, LIB=LIB):
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in paths)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, diag=False):
+    """diag=True: the diagnostic library (-DDVAE_DIAG) as libdvae_hip_diag.so beside the product one; load it with DVAE_LIB=<path>."""
+    if diag:
+        return _build(DIAG_LIB, os.path.join(HERE, "build", "diag"), ["-DDVAE_DIAG"], force, verbose)
+    return _build(LIB, os.path.join(HERE, "build"), [], force, verbose)
+
+
+def _build(LIB, objdir, extra, force, verbose):
     deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    if not force and not _newer_than_lib(deps):
+    if not force and not _newer_than_lib(deps, LIB):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
                 [os.path.getmtime(src)] + [os.path.getmtime(p) for p in deps if p.endswith((".hpp", ".h"))]):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"] + FILE_FLAGS.get(os.path.basename(src), []) + os.environ.get("DVAE_CFLAGS", "").split()
+               "-Wall", "-Wno-unused-function"] + FILE_FLAGS.get(os.path.basename(src), []) + extra + os.environ.get("DVAE_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
@@ -59,4 +67,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))

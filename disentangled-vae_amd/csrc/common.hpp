@@ -43,6 +43,16 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWave = 64;
 
+// -DDVAE_DIAG (python disentangled-vae_amd/build.py --diag -> libdvae_hip_diag.so): the default library holds PRODUCT kernels only; the
+// measured-slower alternates that earlier rounds built and kept for A/B runs and equality tests -- the 4-wave rows kernel under the bf16
+// policies, the LDS-staged weight-gradient kernel, the optimizer step in the weight-gradient kernel's tail or in the next rows kernel's
+// opening, the unit-mapped apply kernel, the staged ISTFT on frame-major input -- exist in the diagnostic build alone.
+#ifdef DVAE_DIAG
+constexpr bool kDiagBuild = true;
+#else
+constexpr bool kDiagBuild = false;
+#endif
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case DVAE_ACT_TANH: return tanhf(v);

@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int dvae_abi_version(void) { return DVAE_ABI_VERSION; }
 extern "C" const char* dvae_last_error(void) { return dvae::g_err; }
+extern "C" int dvae_build_has_diag(void) { return dvae::kDiagBuild ? 1 : 0; }
 extern "C" int dvae_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

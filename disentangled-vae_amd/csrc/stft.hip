@@ -914,10 +914,15 @@ static int istft_run(const void* S, int64_t T, int64_t ld, bool tf, const double
             DVAE_LAUNCH_OK("istft1024_walk_kernel");
             return 0;
         }
-        if (tf) {
+        if (tf) {                                                                // frame-major input through the staged kernel: diagnostic builds (DVAE_ISTFT_STAGED)
+#ifdef DVAE_DIAG
             if (T <= 5 * 512) return launch_istft_fused<8, 1, true>((const float2*)S, T, ld, window, start, y, out_len, s);
             if (T <= 13 * 512) return launch_istft_fused<16, 1, true>((const float2*)S, T, ld, window, start, y, out_len, s);
             return launch_istft_fused<16, 2, true>((const float2*)S, T, ld, window, start, y, out_len, s);
+#else
+            set_error("istft: DVAE_ISTFT_STAGED on frame-major input exists in the diagnostic build only (build.py --diag)");
+            return DVAE_E_UNSUPPORTED;
+#endif
         }
         if (T <= 5 * 512) return launch_istft_fused<8, 1, false>((const float2*)S, T, ld, window, start, y, out_len, s);
         if (T <= 13 * 512) return launch_istft_fused<16, 1, false>((const float2*)S, T, ld, window, start, y, out_len, s);

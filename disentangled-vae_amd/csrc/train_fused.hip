@@ -772,6 +772,7 @@ struct BlockDesc {
     GroupDesc g[4];          // per wave (wr * 2 + wc): destinations of its 2 x 2 group; A[0] == null: nothing to do
 };
 
+#ifdef DVAE_DIAG
 template <typename P> struct WgLds {
     static constexpr int KPS = 2;                                   // k-steps per stage
     static constexpr int NSTG = 4;
@@ -882,6 +883,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_lds_kernel(const BlockDesc* __re
         }
     }
 }
+#endif  // DVAE_DIAG
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradients, third form (default): one 256-thread workgroup = one 4 x 4 block of 32 x 32 tiles (128 output x 128 input
@@ -1246,6 +1248,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 constexpr int FOLD_MAXB = 120;
 struct FoldArgs { unsigned* cnt; unsigned target; unsigned max_polls; };
 
+#ifdef DVAE_DIAG
 template <typename T, int NP>
 __device__ __forceinline__ void fold_tail(const ApplyArgs& g, const FoldArgs& fa, const Block4& bd, const Block4* __restrict__ bdg, int bi, int slice,
                                           int ks, int lane, int wave, char* wsm) {
@@ -1341,6 +1344,7 @@ __device__ __forceinline__ void fold_tail(const ApplyArgs& g, const FoldArgs& fa
     }
     if (!ok && threadIdx.x == 0 && g.losses3 != nullptr) g.losses3[0] = __builtin_nanf("");
 }
+#endif  // DVAE_DIAG
 
 template <typename P>
 __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
@@ -1408,9 +1412,15 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
     }
 #undef W4_GO
 #ifndef W4_FOLD
+#ifdef DVAE_DIAG
 #define W4_FOLD 1      // 0: the folded optimizer tail compiled out (A/B of what its presence costs the main loop)
+#else
+#define W4_FOLD 0      // product build: no folded tail
 #endif
-    if (W4_FOLD && fold.cnt != nullptr) fold_tail<typename P::T, P::NP>(fold_apply, fold, bd, blocks + bi, bi, slice, ksplit, lane, wave, wsm);
+#endif
+#if W4_FOLD
+    if (fold.cnt != nullptr) fold_tail<typename P::T, P::NP>(fold_apply, fold, bd, blocks + bi, bi, slice, ksplit, lane, wave, wsm);
+#endif
 }
 
 // sum of up to NS slabs at element i: every load issued before the first addition (a run-time loop makes each addition wait for
@@ -1475,6 +1485,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs g) {
     apply_element<T, ADAM, NP>(g, idx, d, pi, m_old, v_old, gi);
 }
 
+#ifdef DVAE_DIAG
 // The optimizer step by UNITS (apply_common.hpp: defer_unit -- 8 rows x 32 columns of one weight matrix per wave, whole-line loads of
 // parameters / moments / slabs, the kernel-layout copies as whole 8- and 16-byte pieces through the transposing LDS read): the same
 // element arithmetic as apply_kernel on the same slab sums (bit-identical, tested), a quarter of its instructions, no lone 2-byte stores.
@@ -1494,6 +1505,7 @@ __global__ __launch_bounds__(256) void apply_units_kernel(const ApplyArgs g, con
     T* const tile = reinterpret_cast<T*>(sm) + wave * DeferLds<T, NP>::wave_elems;
     defer_unit<T, NP, false>(g, tasks[un >> 2], un & 3, tile, lane);
 }
+#endif  // DVAE_DIAG
 
 // ---------------------------------------------------------------------------------------------
 // host-side planning
@@ -1653,6 +1665,10 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     int want = 2;
     if (rk && (atoi(rk) == 1 || atoi(rk) == 2)) want = atoi(rk);
     plan->rows_kernel = (want == 2 && rows2_supported(precision, model)) ? 2 : 1;
+    if (!kDiagBuild && plan->rows_kernel == 1 && is_bf(precision)) {
+        set_error("train_plan: DVAE_ROWS=1 (the 4-wave rows kernel) under the bf16 policies needs the diagnostic build (build.py --diag)");
+        return DVAE_E_UNSUPPORTED;
+    }
     if (model == DVAE_MODEL_M2_DEC && plan->rows_kernel != 2) {
         set_error("train_plan: M2_DEC exists in the 8-wave rows kernel only (bf16 / bf16x3 operands, DVAE_ROWS unset)");
         return DVAE_E_UNSUPPORTED;
@@ -1924,6 +1940,7 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
     // trip and its own start-up either way: the flat kernel stays the default.
     const int ntasks = defer_state_get(ws).ntasks;
     const char* ak = getenv("DVAE_APPLY");
+#ifdef DVAE_DIAG
     if (adam && is_bf(plan->precision) && n_slabs <= 12 && ntasks > 0 && ntasks <= DEFER_MAX_TASKS && ak && strcmp(ak, "units") == 0) {
         const int nunits = 4 * ntasks;
         const dim3 gu((unsigned)((nunits + 3) / 4 + 1));
@@ -1933,6 +1950,9 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
         DVAE_LAUNCH_OK("apply_units_kernel");
         return 0;
     }
+#else
+    (void)ntasks; (void)ak;
+#endif
     const dim3 grid((unsigned)((plan->n_params + 255) / 256 + 1));   // + 1: loss finalisation block
     if (plan->precision == DVAE_PREC_BF16X3) {
         if (adam) hipLaunchKernelGGL((apply_kernel<__bf16, true, 2>), grid, dim3(256), 0, s, a);
@@ -2073,7 +2093,7 @@ extern "C" int dvae_train_can_defer(const dvae_train_plan_t* plan, const void* w
     if (!plan || !ws) return 0;
     // OPT-IN (DVAE_DEFER_APPLY=1): bit-identical and, on the MI355X, not faster -- see DESIGN.md (round 4, item 3) for the ablation
     const char* de = getenv("DVAE_DEFER_APPLY");
-    if (!(de && atoi(de) == 1) || getenv("DVAE_FOLD_APPLY") != nullptr) return 0;
+    if (!kDiagBuild || !(de && atoi(de) == 1) || getenv("DVAE_FOLD_APPLY") != nullptr) return 0;      // (the deferred rows kernel exists in -DDVAE_DIAG builds only)
     return defer_possible(plan, ws) ? 1 : 0;
 }
 
@@ -2180,6 +2200,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         ProfScope ps(s, 0);
         if (plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model)) {
             rc = launch_rows2(plan->precision, plan->model, plan->y_dim, a, grid, s);
+#ifdef DVAE_DIAG
         } else if (x3) {
             if (L.info) rc = launch_rows<PolX3, 16, false, true>(a, grid, s);
             else if (!m2) rc = launch_rows<PolX3, 0, false>(a, grid, s);
@@ -2190,6 +2211,11 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             else if (!m2) rc = launch_rows<PolBF16, 0, false>(a, grid, s);
             else if (plan->y_dim == 1) rc = launch_rows<PolBF16, 16, true>(a, grid, s);
             else rc = launch_rows<PolBF16, 528, true>(a, grid, s);
+#else
+        } else if (x3 || bf) {
+            set_error("train_grads: the 4-wave rows kernel under the bf16 policies exists in the diagnostic build only (build.py --diag)");
+            rc = DVAE_E_UNSUPPORTED;
+#endif
         } else {
             if (L.info) rc = launch_rows<PolF32, 16, false, true>(a, grid, s);
             else if (!m2) rc = launch_rows<PolF32, 0, false>(a, grid, s);
@@ -2255,6 +2281,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3l, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
         else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3l, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
         DVAE_LAUNCH_OK("wgrad4_kernel");
+#ifdef DVAE_DIAG
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
         const dim3 g3((unsigned)(L.nblocks * ks));
@@ -2270,6 +2297,11 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             hipLaunchKernelGGL((wgrad_lds_kernel<PolBF16>), g3, dim3(256), WgLds<PolBF16>::BYTES, s, (const BlockDesc*)(w + L.o_blocks), L.nblocks, ks, plan->Bp, a.spl, kper, slabs, plan->n_params);
         }
         DVAE_LAUNCH_OK("wgrad_lds_kernel");
+#else
+    } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
+        set_error("train_grads: DVAE_WGRAD=lds exists in the diagnostic build only (build.py --diag)");
+        return DVAE_E_UNSUPPORTED;
+#endif
     } else {
     int GPW = 2;                                            // groups (waves) per workgroup
     { const char* e = getenv("DVAE_GPW"); if (e) { GPW = atoi(e); if (GPW < 1 || GPW > 4) GPW = 2; } }   // diagnostic override
@@ -2323,7 +2355,7 @@ extern "C" int dvae_train_step(const dvae_train_plan_t* plan, float* params, flo
     // (First attempt with release / acquire fences instead of write-through stores + coherent loads: 75 us -- every fence writes back
     // or invalidates the XCD's whole L2 under the workgroups that are still multiplying.)
     const char* fe = getenv("DVAE_FOLD_APPLY");                       // read per call (tests flip it)
-    const bool fold_on = fe && atoi(fe) != 0;
+    const bool fold_on = kDiagBuild && fe && atoi(fe) != 0;      // (the folded tail exists in -DDVAE_DIAG builds only)
     g_fold = FoldRequest();
     g_fold.want = fold_on; g_fold.params = params; g_fold.m = m; g_fold.v = v; g_fold.step = step; g_fold.lr = lr; g_fold.beta1 = beta1;
     g_fold.beta2 = beta2; g_fold.adam_eps = adam_eps; g_fold.losses3 = losses3;

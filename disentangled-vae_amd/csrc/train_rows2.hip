@@ -1141,7 +1141,11 @@ template <typename P, int YP, bool YENC>
 static int launch_rows2_t(const RowsArgs& a, int grid, hipStream_t s) {
     if (a.mode == 1) return launch_rows2_m<P, YP, YENC, 1>(a, grid, s);
     if (a.mode == 2) return launch_rows2_m<P, YP, YENC, 2>(a, grid, s);
+#ifdef DVAE_DIAG
     if (a.defer.on) return launch_rows2_m<P, YP, YENC, 0, false, true>(a, grid, s);
+#else
+    if (a.defer.on) { set_error("rows2 kernel: the deferred optimizer step exists in the diagnostic build only (build.py --diag)"); return DVAE_E_UNSUPPORTED; }
+#endif
     return launch_rows2_m<P, YP, YENC, 0>(a, grid, s);
 }
 

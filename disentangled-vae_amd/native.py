@@ -23,6 +23,7 @@ c_vp, c_i, c_i64, c_f, c_d, c_sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int6
 
 # name -> (restype, argtypes); mirrors include/dvae.h, include/dvae_train.h and include/dvae_mcem.h
 SIGNATURES = {
+    "dvae_build_has_diag": (c_i, []),
     "dvae_abi_version": (c_i, []),
     "dvae_last_error": (ctypes.c_char_p, []),
     "dvae_device_count": (c_i, []),

@@ -36,6 +36,8 @@ enum { DVAE_ACT_NONE = 0, DVAE_ACT_TANH = 1, DVAE_ACT_RELU = 2, DVAE_ACT_SIGMOID
 
 int         dvae_abi_version(void);
 const char* dvae_last_error(void);
+/* 1 for the diagnostic build (-DDVAE_DIAG: product kernels + the measured-slower alternates behind their A/B switches), 0 for the default one. */
+int dvae_build_has_diag(void);
 /* number of HIP devices visible to the library (0 when none): lets the host fail loudly */
 int         dvae_device_count(void);
 

@@ -17,6 +17,18 @@ pytestmark = pytest.mark.gpu
 trainer = importlib.import_module("disentangled-vae_amd.trainer")
 N = importlib.import_module("disentangled-vae_amd.native")
 
+
+def _has_diag():
+    try:
+        return bool(N.load().dvae_build_has_diag())
+    except Exception:
+        return False
+
+
+# tests of the measured-slower alternates: they exist in the diagnostic library only (python disentangled-vae_amd/build.py --diag, then
+# DVAE_LIB=disentangled-vae_amd/libdvae_hip_diag.so python -m pytest ...); the default library holds product kernels only
+needs_diag = pytest.mark.skipif(not _has_diag(), reason="alternate kernels: diagnostic build only (build.py --diag, DVAE_LIB=...)")
+
 FULL = [c for c in gu.CASES if c[0] in ("M1_full", "M2_full_y1", "M2_full_y513", "M2_full_y513_hot")]
 
 
@@ -174,13 +186,14 @@ def test_workgroup_blocked_wgrad_kernel_equals_the_default(precision, monkeypatc
     x, y, e = gu.make_batch(dims, 3000, 9)                       # 94 tiles: ragged last tile, partial last k-slice
     t = lambda a: torch.from_numpy(a).cuda()
     got = {}
-    for kind in ("wg4", "ring", "lds"):
+    kinds = ("wg4", "ring", "lds") if _has_diag() else ("wg4", "ring")       # the LDS-staged form: diagnostic builds only
+    for kind in kinds:
         monkeypatch.setenv("DVAE_WGRAD", kind)
         tr = trainer.Trainer("M2", dims, params, batch=3000, precision=precision)
         tr.step(t(x), t(y), t(e))
         got[kind] = tr.grads_numpy()
     for k in got["wg4"]:
-        for kind in ("ring", "lds"):
+        for kind in kinds[1:]:
             assert _relmax(got[kind][k], got["wg4"][k].astype(np.float64)) < 2e-6, (kind, k)
 
 
@@ -881,26 +894,36 @@ def test_label_lo_plane_on_demand_equals_always(y_dim, B, monkeypatch):
         assert _relmax(res[False][0][1][k], np.asarray(grads[k], np.float64).reshape(res[False][0][1][k].shape)) < x3_grad_bound(k), k
 
 
+@needs_diag
 @pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M2", 513, 3000, "fp32"), ("M2", 1, 5000, "bf16x3"),
                                                        ("M1", 0, 8192, "bf16"), ("M2_info", 1, 8192, "bf16x3"), ("M2", 513, 20000, "bf16x3")])
 def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_launch(model, y_dim, B, precision, monkeypatch):
-    """dvae_train_step runs Adam + the weight-copy refresh + the loss scalars in the tail of the weight-gradient kernel (two launches per
-    step) whenever that kernel's grid is one resident round of workgroups; DVAE_FOLD_APPLY=0 keeps the third launch.  Same slab sums
-    in the same order, same element arithmetic: losses, gradients, parameters and both Adam moments are equal bit for bit over a run
-    of steps (the counters of the tail must come back to zero after every launch; ragged last tiles and partial k-slices included)."""
+    """Diagnostic builds, opt-in (DVAE_FOLD_APPLY=1; measured slower): dvae_train_step runs Adam + the weight-copy refresh +
+    the loss scalars in the tail of the weight-gradient kernel (two launches per step) whenever that kernel's grid is one resident
+    round of workgroups; unset or 0 = the three-launch step.  Same slab sums in the same order, same element arithmetic: losses,
+    gradients, parameters and both Adam moments are equal bit for bit over a run of steps (ragged last tiles and partial k-slices
+    included).  Whether the tail really ran is read off the profile (no apply launch); cases whose grid cannot fold are named."""
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     params = gu.make_params(model, dims, 71)
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
     batches = [gu.make_batch(dims, B, 80 + i) for i in range(4)]
     res = {}
+    applies = {}
     for fold in ("1", "0"):
         monkeypatch.setenv("DVAE_FOLD_APPLY", fold)
         tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+        tr.profile(True)
         out = []
         for x, y, e in batches:
             losses = tr.step(t(x), t(y) if y_dim else None, t(e)).cpu().numpy().copy()
             out.append((losses, tr.grads_numpy(), tr.state_dict_numpy(), tr.m.cpu().numpy().copy(), tr.v.cpu().numpy().copy()))
+        applies[fold] = tr.profile_read()["apply"][1]
+        tr.profile(False)
         res[fold] = out
+    assert applies["0"] == len(batches)
+    folded = applies["1"] == 0
+    # the tail needs ks > 1, a grid within the CU count and <= 120 blocks: the fp32 policy's 16 slices x 22 blocks do not fit the CUs
+    assert folded == ((model, precision) != ("M2", "fp32")), (model, y_dim, B, precision, applies)
     for (la, ga, pa, ma, va), (lb, gb, pb, mb, vb) in zip(res["1"], res["0"]):
         assert np.all(np.isfinite(la))
         np.testing.assert_array_equal(la, lb)
@@ -911,6 +934,7 @@ def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_la
             np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
 
 
+@needs_diag
 @pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M2", 1, 5000, "bf16x3"), ("M1", 0, 8192, "bf16"),
                                                        ("M2", 513, 20000, "bf16x3"), ("M2", 513, 8192, "bf16"), ("M1", 0, 4096, "bf16x3")])
 def test_deferred_optimizer_step_equals_the_three_launch_step(model, y_dim, B, precision, monkeypatch):
@@ -952,6 +976,7 @@ def test_deferred_optimizer_step_equals_the_three_launch_step(model, y_dim, B, p
                 np.testing.assert_array_equal(pa[k], pb[k], err_msg=k)
 
 
+@needs_diag
 def test_deferred_optimizer_step_with_forks_evaluation_and_state_dict():
     """The pending update is applied before anything else looks at the parameters: a fork (another batch size over the same parameters)
     stepping in between, evaluate(), load_state_dict() -- the sequence equals the same sequence without deferral bit for bit."""
@@ -985,6 +1010,7 @@ def test_deferred_optimizer_step_with_forks_evaluation_and_state_dict():
         np.testing.assert_array_equal(res["1"][1][k], res["0"][1][k], err_msg=k)
 
 
+@needs_diag
 def test_deferred_optimizer_step_never_hangs_when_its_wait_runs_out(monkeypatch):
     """The arrival wait in front of the first weight load is bounded by wall time: with a bound of zero a workgroup that polls before the
     others have arrived gives up at once -- the launch completes, the sticky error word turns the loss into NaN (the trainer is to be
@@ -1006,6 +1032,7 @@ def test_deferred_optimizer_step_never_hangs_when_its_wait_runs_out(monkeypatch)
     assert seen_nan, "a zero bound must trip on a 256-workgroup grid"
 
 
+@needs_diag
 def test_folded_optimizer_tail_never_hangs_when_its_wait_runs_out(monkeypatch):
     """The wait of the folded tail (a workgroup waiting for the other slices of its parameter block) is bounded: with a bound of zero
     polls every workgroup that arrives early gives up at once -- the launch completes, the sticky error word turns the step's loss

@@ -211,9 +211,11 @@ def test_istft_of_frame_major_input_equals_bin_major_bitwise(T):
     ref = H.istft_device(S_ft, w, 1024, 256, T, 0, ntot + 300)
     rows = torch.from_numpy(np.ascontiguousarray(S.T)).cuda()              # [T, 513]
     got = H.istft_device(rows.T, w, 1024, 256, T, 0, ntot + 300)                  # register-resident walk (one wave per run of frames)
+    N_ = importlib.import_module("disentangled-vae_amd.native")
+    diag = bool(N_.load().dvae_build_has_diag())      # the staged kernel on frame-major rows exists in the diagnostic library only
     os.environ["DVAE_ISTFT_STAGED"] = "1"
     try:
-        got_staged = H.istft_device(rows.T, w, 1024, 256, T, 0, ntot + 300)       # the LDS-staged kernel reading frame-major rows
+        got_staged = H.istft_device(rows.T, w, 1024, 256, T, 0, ntot + 300) if diag else got   # the LDS-staged kernel reading frame-major rows
         ref_staged = H.istft_device(S_ft, w, 1024, 256, T, 0, ntot + 300)         # ... and bin-major rows (T >= 1024 otherwise transposes + walks)
     finally:
         del os.environ["DVAE_ISTFT_STAGED"]
