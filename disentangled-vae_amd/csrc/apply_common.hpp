@@ -51,9 +51,18 @@ __device__ __forceinline__ void apply_element(const ApplyArgs& g, int64_t idx, c
         const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
         const int64_t o = WFRAG ? d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
                                 : d.sf_off + (int64_t)rr * d.sf_ld + cc;
-        const T ph = (T)pi;
-        wc[o] = ph;
-        if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
+        if constexpr (NP == 2 && sizeof(T) == 2) {
+            if (c < d.sf_f16_cols) {                               // the x block of layer 1: split fp16 of W * 2^6 (struct X16)
+                const float ws = pi * X16::WS;
+                const T ph = X16::hi<T>(ws);
+                wc[o] = ph;
+                wc[o + g.wpl] = X16::hi<T>(ws - X16::val(ph));
+            } else { const T ph = (T)pi; wc[o] = ph; wc[o + g.wpl] = (T)(pi - (float)ph); }
+        } else {
+            const T ph = (T)pi;
+            wc[o] = ph;
+            if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);
+        }
     }
     if (d.st_off >= 0 && c < d.st_cmax) {
         const int rr = c, cc = r + d.st_roff;
@@ -231,6 +240,15 @@ __device__ __forceinline__ void defer_unit(const ApplyArgs& g, const DeferTask t
         fh[j] = ph;
         fl[j] = (T)(pn[j] - (float)ph);
     }
+    Frag4 fwh = fh, fwl = fl;                                        // forward-copy planes: split fp16 of W * 2^6 in the x block of layer 1
+    if (NP == 2 && tk.cbeg < d.sf_f16_cols) {                        // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ws = pn[j] * X16::WS;
+            fwh[j] = X16::hi<T>(ws);
+            fwl[j] = X16::hi<T>(ws - X16::val(fwh[j]));
+        }
+    }
     if (d.sf_off >= 0 && nv > 0) {
         // forward copy: columns 4 p .. 4 p + 3 of the tile are elements 4 (p & 1) .. of fragment half (p >> 1) & 1 of k-step cc / 16:
         // 8-byte stores, two lanes per 16-byte fragment, 8 rows per 128 contiguous bytes
@@ -239,8 +257,8 @@ __device__ __forceinline__ void defer_unit(const ApplyArgs& g, const DeferTask t
         const int64_t o = d.sf_off + ((int64_t)((cc >> 4) * d.sf_nt + (rr2 >> 5)) * 64 + ((cc >> 3) & 1) * 32 + (rr2 & 31)) * 8 + (cc & 4);
         typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wc, 0, 0x7fffffff, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, fh), rs, (int)(o * (int64_t)sizeof(T)), 0, COH ? 16 : 0);
-        if constexpr (NP == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, fl), rs, (int)((o + g.wpl) * (int64_t)sizeof(T)), 0, COH ? 16 : 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, fwh), rs, (int)(o * (int64_t)sizeof(T)), 0, COH ? 16 : 0);
+        if constexpr (NP == 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, fwl), rs, (int)((o + g.wpl) * (int64_t)sizeof(T)), 0, COH ? 16 : 0);
     }
     if (d.st_off >= 0 && tk.cbeg < d.st_cmax) {                      // wave-uniform
         // transposed copy: the unit's [8 r][32 c] in LDS, read back as the 8 consecutive r of one c (ds_read_b64_tr_b16): lanes 0 .. 31 the

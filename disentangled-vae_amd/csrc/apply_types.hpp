@@ -15,7 +15,8 @@ struct TensorDesc {
     int32_t sf_nt, sf_split, sf_gap, sf_roff;   // column c -> c (c < split) or c + gap; row r -> r + roff
     int32_t sf_ld, st_ld;                       // row strides of the row-major variant (WFRAG == false)
     int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
-    int32_t st_nt, st_roff, st_cmax, pad1;      // element (r, c < cmax) -> row c, column r + roff
+    int32_t st_nt, st_roff, st_cmax;            // element (r, c < cmax) -> row c, column r + roff
+    int32_t sf_f16_cols;                        // columns c < this of the FORWARD copy hold split-fp16 planes of W * 2^6 (fused_tiles.hpp: struct X16); 0 = none
 };
 
 struct ApplyArgs {

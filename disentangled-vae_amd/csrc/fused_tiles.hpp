@@ -150,13 +150,33 @@ struct PolX3 : PolBF16 {
 #ifndef R2_PDO_X3
 #define R2_PDO_X3 6
 #endif
+// Split-FP16 operands for the ONE GEMM whose 16-bit planes limit the policy (round 4): the x block of encoder layer 1 (and of the M2_info
+// classifier's layer 1).  tools/r04/sim_l1x.py: with every operand split into bf16 planes the worst gradient element is 7.5e-5 ... 3.3e-4 of
+// its tensor's maximum -- all of it from this GEMM, whose pre-activations sum heavy-tailed power spectra (x up to 1e4) so that
+// 2^-17 of the LARGEST term moves a unit on the knee of tanh; with this GEMM exact the whole step holds 1.4e-5.  fp16 planes carry
+// 11 + 11 mantissa bits at the MFMA rate of bf16 (v_mfma_f32_32x32x16_f16) and v_mfma keeps fp16 subnormals (tools/r04/mfma_f16_denorm.hip,
+// measured), so a FIXED power-of-two scale serves: x * 2^-3 (finite up to 5.2e5 = twice the largest power a peak-normalised 1024-point
+// Hann frame can hold; an element below 2^-21 keeps an absolute error of 2^-22, i.e. 3e-8 |w| in a pre-activation of order one), the
+// weights * 2^6 (finite up to 1023; lo planes normal from |w| = 2e-3), products hi*hi + lo*hi + hi*lo as before, the accumulator * 2^-3.
+// An input beyond the range turns the step's loss into NaN (inf - inf in the lo plane), never into a silently wrong number.
+struct X16 {
+    static constexpr float XS = 0.125f, WS = 64.f, ACC = 0.125f, XINV = 8.f;
+    template <typename T> static __device__ __forceinline__ T hi(float v) { const _Float16 h = (_Float16)v; return __builtin_bit_cast(T, h); }
+    template <typename T> static __device__ __forceinline__ float val(T b) { return (float)__builtin_bit_cast(_Float16, b); }
+};
+
 struct PolX3v2 : PolX3 {
     static constexpr int PDO = R2_PDO_X3;     // ring depth of the train-step instantiation (loss epilogue on the helper waves)
     static constexpr int PD = R2_PD_X3, PRE = R2_PRE_X3, PRE128 = R2_P128_X3, PREBIG = R2_PBIG_X3;   // PD / PRE: the output-layer loop (the register peak)
     static constexpr int DBIG = R2_DBIG_X3, D128 = R2_D128_X3;   // ring depths of the long GEMMs / the 128-deep layers
     static constexpr int BDMAX = R2_BD_X3;
+#ifndef R2_XF16
+#define R2_XF16 1
+#endif
+    static constexpr bool XF16 = R2_XF16 != 0;     // the x block of layer 1 in split fp16 (see struct X16)
 };
 struct PolBF16v2 : PolBF16 {
+    static constexpr bool XF16 = false;
     static constexpr int PDO = R2_PD_BF;
     static constexpr int PD = R2_PD_BF, PRE = R2_PRE_BF, PRE128 = 8, PREBIG = R2_PBIG_BF;
     static constexpr int DBIG = R2_DBIG_BF, D128 = 8;
@@ -223,6 +243,15 @@ template <typename P>
 __device__ __forceinline__ void mmap(f32x16& acc, const typename P::Frag (&a)[P::NP], const typename P::Frag (&b)[P::NP], bool blo = true) {
     if constexpr (P::NP == 2) { P::mma(acc, a[1], b[0]); if (blo) P::mma(acc, a[0], b[1]); }
     P::mma(acc, a[0], b[0]);
+}
+// the same on operand planes that hold fp16 bit patterns (struct X16)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename P>
+__device__ __forceinline__ void mmap_f16(f32x16& acc, const typename P::Frag (&a)[P::NP], const typename P::Frag (&b)[P::NP]) {
+    static_assert(P::NP == 2 && sizeof(typename P::T) == 2, "split fp16: two 16-bit planes");
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
 }
 
 template <typename P, int NSTEPS, int PREN>

@@ -123,7 +123,9 @@ __device__ __forceinline__ void stash_store16(void* base_uniform, int voff_bytes
 #endif
 }
 
-template <typename P>
+// SRC16: the LDS planes hold split-fp16 values scaled by X16::XS (the x image of encoder layer 1): the stash gets the split-bf16 planes of
+// the unscaled values, which is what the weight-gradient kernel multiplies
+template <typename P, bool SRC16 = false>
 __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, int fbase, typename P::T* stash_tile_ptr, int64_t spl,
                                            int64_t b0, int l31, int h, float scale = 1.f, int col_limit = 1 << 30, int nplanes = P::NP) {
     typedef typename P::T T;
@@ -147,6 +149,13 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
                 s16x8 raw = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 f[pl] = __builtin_bit_cast(Frag, raw);
             }
+            if constexpr (SRC16 && P::NP == 2) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const float v = (X16::val(f[0][j]) + X16::val(f[1][j])) * X16::XINV;
+                    f[0][j] = P::cvt(v); f[1][j] = P::cvt(v - (float)f[0][j]);
+                }
+            } else
             if (scale != 1.f) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
@@ -182,7 +191,7 @@ __device__ __forceinline__ void stash_tile(const typename P::T* lds, int ldl, in
 }
 
 // generic (edge tile / strided / unaligned input): global [32 frames][ncols] fp32 -> LDS as T, zero padded
-template <typename P, typename RowOf>
+template <typename P, bool F16 = false, typename RowOf>
 __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, int ld, int ncols, int pcols, int64_t b0, int64_t B,
                                                  typename P::T* U, int ldu, int tid, RowOf rowof, float* xf = nullptr,
                                                  float* log2sum = nullptr, float eps = 0.f) {
@@ -194,9 +203,16 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
             v = src[rowof(row) * ld + col];
             if (log2sum && col < XD - 1) *log2sum += __builtin_amdgcn_logf(v + eps);      // live frames, bins 0 .. 511 (see tile513_log2sum)
         }
-        const typename P::T vh = P::cvt(v);
-        U[row * ldu + col] = vh;
-        if constexpr (P::NP == 2) U[Pl<P>::lds + row * ldu + col] = P::cvt(v - (float)vh);
+        if constexpr (F16 && P::NP == 2) {                         // split fp16 of XS * v (struct X16)
+            const float vs = v * X16::XS;
+            const typename P::T vh = X16::hi<typename P::T>(vs);
+            U[row * ldu + col] = vh;
+            U[Pl<P>::lds + row * ldu + col] = X16::hi<typename P::T>(vs - X16::val(vh));
+        } else {
+            const typename P::T vh = P::cvt(v);
+            U[row * ldu + col] = vh;
+            if constexpr (P::NP == 2) U[Pl<P>::lds + row * ldu + col] = P::cvt(v - (float)vh);
+        }
         if (xf && col < ncols) xf[row * ncols + col] = v;
     }
 }
@@ -227,7 +243,7 @@ __device__ __forceinline__ void tile513_issue(const float* __restrict__ base, Ro
     __builtin_amdgcn_sched_barrier(0);     // all loads in flight before the first LDS commit
 }
 // chunks [I0, I1) -> (hi, lo) planes of the LDS image; lo_bits collects the OR of every lo-plane word written
-template <typename P, int I0, int I1>
+template <typename P, int I0, int I1, bool F16 = false>
 __device__ __forceinline__ void tile513_commit_part(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf, unsigned long long& lo_bits) {
     typedef typename P::Pack4 Pack4;
 #pragma unroll
@@ -237,6 +253,18 @@ __device__ __forceinline__ void tile513_commit_part(const f32x4 (&v)[NQ513], typ
         if (xf) {                                              // dense [frame][513] fp32 copy (rows 4-byte aligned)
             float* d = xf + row * XD + col;
             d[0] = v[i][0]; d[1] = v[i][1]; d[2] = v[i][2]; d[3] = v[i][3];
+        }
+        if constexpr (F16 && P::NP == 2) {                         // split fp16 of XS * v (struct X16)
+            Pack4 pk, pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float vs = v[i][j] * X16::XS;
+                pk[j] = X16::hi<typename P::T>(vs);
+                pl[j] = X16::hi<typename P::T>(vs - X16::val(pk[j]));
+            }
+            *reinterpret_cast<Pack4*>(U + row * ldu + col) = pk;
+            *reinterpret_cast<Pack4*>(U + Pl<P>::lds + row * ldu + col) = pl;
+            continue;
         }
         Pack4 pk;
         pk[0] = P::cvt(v[i][0]); pk[1] = P::cvt(v[i][1]); pk[2] = P::cvt(v[i][2]); pk[3] = P::cvt(v[i][3]);
@@ -251,17 +279,24 @@ __device__ __forceinline__ void tile513_commit_part(const f32x4 (&v)[NQ513], typ
     }
 }
 // column 512 (slot 16), then the PCOLS - 513 zero columns
-template <typename P, int PCOLS>
+template <typename P, int PCOLS, bool F16 = false>
 __device__ __forceinline__ void tile513_commit_last(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf, unsigned long long& lo_bits) {
     constexpr int PADC = PCOLS - XD;
     if (tid < TB) {
         if (xf) xf[tid * XD + XD - 1] = v[16][0];
+        if constexpr (F16 && P::NP == 2) {
+            const float vs = v[16][0] * X16::XS;
+            const typename P::T vh = X16::hi<typename P::T>(vs);
+            U[tid * ldu + XD - 1] = vh;
+            U[Pl<P>::lds + tid * ldu + XD - 1] = X16::hi<typename P::T>(vs - X16::val(vh));
+        } else {
         const typename P::T vh = P::cvt(v[16][0]);
         U[tid * ldu + XD - 1] = vh;
         if constexpr (P::NP == 2) {
             const typename P::T vl = P::cvt(v[16][0] - (float)vh);
             U[Pl<P>::lds + tid * ldu + XD - 1] = vl;
             if ((float)vl != 0.f) lo_bits |= 1ull;
+        }
         }
     }
     for (int idx = tid; idx < TB * PADC; idx += 256) {
@@ -270,12 +305,58 @@ __device__ __forceinline__ void tile513_commit_last(const f32x4 (&v)[NQ513], typ
         if constexpr (P::NP == 2) U[Pl<P>::lds + r * ldu + c] = P::cvt(0.f);
     }
 }
-template <typename P, int PCOLS>
+template <typename P, int PCOLS, bool F16 = false>
 __device__ __forceinline__ void tile513_commit(const f32x4 (&v)[NQ513], typename P::T* U, int ldu, int tid, float* xf = nullptr, bool* any_lo = nullptr) {
     unsigned long long lo_bits = 0ull;                          // OR of every lo-plane word this thread writes (any_lo: is the lo plane needed at all?)
-    tile513_commit_part<P, 0, 16>(v, U, ldu, tid, xf, lo_bits);
-    tile513_commit_last<P, PCOLS>(v, U, ldu, tid, xf, lo_bits);
+    tile513_commit_part<P, 0, 16, F16>(v, U, ldu, tid, xf, lo_bits);
+    tile513_commit_last<P, PCOLS, F16>(v, U, ldu, tid, xf, lo_bits);
     if (any_lo) *any_lo = lo_bits != 0ull;
+}
+// ---- the x stash of the 8-wave kernel under the split-fp16 x image (fused_tiles.hpp: struct X16), 256 helper threads ----
+// The image in LDS holds split-fp16 planes of x / 8: an ABSOLUTE error floor, which is what a pre-activation needs.  The weight gradient
+// dW1 = dpre1^T x feeds Adam, which normalises every element by its own history -- there each x needs its RELATIVE precision, down to the
+// quietest bin -- so the stash does not come from the image: the helpers read the tile a second time (it is seconds old: L2 / Infinity
+// Cache), column-wise -- lane = feature 64 q + lane, eight frames of one frame group per lane, i.e. a lane holds exactly the eight frames
+// of a stash fragment -- and store the split-bf16 planes of the fp32 values: 2 x 512 contiguous bytes per wave instruction, no LDS, no
+// transposition, any row stride, gather table or ragged tile, and in whatever phase the helpers have time for it.
+// Feature groups [Q0, Q1) of nine: q < 8 = features 64 q .. 64 q + 63 (two 32-feature stash tiles); q = 8 = tile 16 (bin 512 + 31 zero rows).
+template <typename P, int Q0, int Q1, typename RowOf>
+__device__ __forceinline__ void xstash_reload(const float* __restrict__ src, int ld, RowOf rowof, int64_t b0, int64_t B, typename P::T* xT,
+                                              int64_t spl, int64_t Bp, int tid) {
+    typedef typename P::Frag Frag;
+    static_assert(P::NP == 2 && P::E == 8, "x stash by reload: split-bf16 planes");
+    if (xT == nullptr) return;
+    const int w = tid >> 6, lane = tid & 63;                              // wave w: frames 8 w .. 8 w + 7 of the tile
+    int64_t ro[8];
+    bool live[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ro[k] = rowof(8 * w + k) * (int64_t)ld; live[k] = b0 + 8 * w + k < B; }
+    const int64_t kst = (b0 / P::KSTEP + (w >> 1)) * (64 * P::E) + (w & 1) * 32 * P::E;      // this frame group inside a feature tile's k-step blocks
+    float v[Q1 - Q0][8];
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int f = 64 * q + lane;
+            v[q - Q0][k] = src[ro[k] + (f < XD ? f : XD - 1)];                          // (clamped: features 513 .. 575 of group 8 do not exist)
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        const int f = 64 * q + lane;
+        if (q == 8 && lane >= 32) continue;                                // group 8 is one 32-feature tile
+        Frag fh, fl;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = (f < XD && live[k]) ? v[q - Q0][k] : 0.f;
+            fh[k] = P::cvt(x);
+            fl[k] = P::cvt(x - (float)fh[k]);
+        }
+        // (wave-uniform base + 32-bit per-lane byte offset: the x rows of the stash span 544 Bp elements < 2 GB up to 2^20 frames)
+        const int64_t o = (int64_t)(f >> 5) * 32 * Bp + kst + (f & 31) * P::E;
+        stash_store16(xT, (int)(o * (int64_t)sizeof(typename P::T)), fh);
+        stash_store16(xT + spl, (int)(o * (int64_t)sizeof(typename P::T)), fl);
+    }
 }
 // sum over this thread's share of a full dense tile of log2(x + eps), columns 0 .. 511 (hardware log2: the loss epilogue's log terms,
 // taken while the tile sits in registers; utils.py:74 -- the caller scales by ln 2).  Bin 512 is not included: the wave that owns the
@@ -292,7 +373,7 @@ __device__ __forceinline__ float tile513_log2sum(const f32x4 (&v)[NQ513], float 
 
 // LDS U[frame][col] -> fragment-major stash (see put_tile), 16 bytes (E frames of one feature) per
 // store; feature rows up to `srows` (multiple of 32) are written, columns >= pcols as zeros
-template <typename P>
+template <typename P, bool SRC16 = false>
 __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, int pcols, int srows, typename P::T* stash, int64_t spl,
                                                int64_t Bp, int64_t b0, int tid, int ft0 = 0, int ft1 = 1 << 30, int nplanes = P::NP) {
     typedef typename P::Frag Frag;
@@ -302,7 +383,7 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int fte = ft1 < srows / 32 ? ft1 : srows / 32;
         for (int ft = ft0 + wave; ft < fte; ft += 4)
-            stash_tile<P>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, spl, b0, lane & 31, lane >> 5, 1.f, pcols, nplanes);
+            stash_tile<P, SRC16>(U, ldu, 32 * ft, stash + (int64_t)ft * 32 * Bp, spl, b0, lane & 31, lane >> 5, 1.f, pcols, nplanes);
         return;
     }
     constexpr int groups = TB / E;

@@ -1858,6 +1858,9 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     td[0].sf_ld = L.ld1; td[2].sf_ld = HD; td[4].sf_ld = HD; td[6].sf_ld = HD; td[8].sf_ld = L.ld3; td[10].sf_ld = HD; td[12].sf_ld = HD;
     td[2].st_ld = HD; td[4].st_ld = 32; td[6].st_ld = 32; td[8].st_ld = HD; td[10].st_ld = HD; td[12].st_ld = NO;
     td[0].sf_off = L.W1s; td[0].sf_nt = 4; td[0].sf_split = XD; td[0].sf_gap = XP - XD;
+    // the 8-wave rows kernel under the split-bf16 policy multiplies the x block of layer 1 (and of the M2_info classifier) in split fp16
+    const int f16c = (p->precision == DVAE_PREC_BF16X3 && p->rows_kernel == 2 && PolX3v2::XF16) ? XD : 0;
+    td[0].sf_f16_cols = f16c;
     td[2].sf_off = L.W2s; td[2].sf_nt = 4; td[2].st_off = L.W2t; td[2].st_nt = 4; td[2].st_cmax = HD;
     td[4].sf_off = L.Wmvs; td[4].sf_nt = 1; td[4].st_off = L.Wmvt; td[4].st_nt = 4; td[4].st_cmax = HD;
     td[6].sf_off = L.Wmvs; td[6].sf_nt = 1; td[6].sf_roff = 16; td[6].st_off = L.Wmvt; td[6].st_nt = 4; td[6].st_roff = 16; td[6].st_cmax = HD;
@@ -1865,7 +1868,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     td[10].sf_off = L.W4s; td[10].sf_nt = 4; td[10].st_off = L.W4t; td[10].st_nt = 4; td[10].st_cmax = HD;
     td[12].sf_off = L.W5s; td[12].sf_nt = NT_OUT; td[12].st_off = L.W5t; td[12].st_nt = 4; td[12].st_cmax = HD;
     if (L.info) {
-        td[14].sf_off = L.Wc1s; td[14].sf_nt = 4; td[14].sf_ld = XP; td[14].sf_split = XD; td[14].sf_gap = XP - XD;
+        td[14].sf_off = L.Wc1s; td[14].sf_nt = 4; td[14].sf_ld = XP; td[14].sf_split = XD; td[14].sf_gap = XP - XD; td[14].sf_f16_cols = f16c;
         td[16].sf_off = L.Wc2s; td[16].sf_nt = 4; td[16].sf_ld = HD; td[16].st_off = L.Wc2t; td[16].st_nt = 4; td[16].st_ld = HD; td[16].st_cmax = HD;
         td[20].sf_off = L.Wa1s; td[20].sf_nt = 4; td[20].sf_ld = ZD; td[20].st_off = L.Wa1t; td[20].st_nt = 1; td[20].st_ld = HD; td[20].st_cmax = ZD;
         td[22].sf_off = L.Wa2s; td[22].sf_nt = 4; td[22].sf_ld = HD; td[22].st_off = L.Wa2t; td[22].st_nt = 4; td[22].st_ld = HD; td[22].st_cmax = HD;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     for (unsigned it_ = 0;; ++it_) {
                         const unsigned have = __hip_atomic_load(g.defer.shard + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__ballot((int)(have - want) < 0) == 0ull) break;
-                        if ((it_ & 15u) == 15u && wall_clock64() >= deadline) { ok = false; break; }      // (the clock read is a scalar memory operation: not every lap)
+                        if ((it_ & 15u) == 0u && wall_clock64() >= deadline) { ok = false; break; }      // (the clock read is a scalar memory operation: not every lap)
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (!ok && lane == 0) __hip_atomic_store(g.defer.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -290,7 +290,12 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             // ---------------- encoder layer 1: [x | y] -> h1 ----------------
             f32x16 acc;
             zero_acc<P>(acc);
-            gemm_seg<P, SC, D, G_W1X>(acc, ws, Ur);
+            constexpr bool XF = P::XF16 && NP == 2;                        // the x block of layer 1 in split fp16 (fused_tiles.hpp: struct X16)
+            gemm_seg<P, SC, D, G_W1X, WS, XF>(acc, ws, Ur);
+            if constexpr (XF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= X16::ACC;            // x * 2^-3 and W * 2^6 (exact power-of-two scales)
+            }
             R2_STAMP(2);
             bool ylo = false;
             if (YP > 0) {
@@ -656,6 +661,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     } else {
         // =========================================================== helper waves ===========================================================
         const int hw = wave_u - 4, ht = tid - 256;
+        constexpr bool XFH = P::XF16 && NP == 2;                           // the x image in split fp16 (fused_tiles.hpp: struct X16)
         // (An L2 warm-up of the weight copies by the helpers -- one dword per 128-byte line, 1/32 of the buffer per workgroup of an
         // XCD -- changed nothing: the weight stream runs at the ~34 B/clk/CU of an L2-resident table shared by every CU, not at miss latency.)
         // fp32 bias table -> LDS once; the loads are issued here (clamped addresses instead of branches)
@@ -762,17 +768,17 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                             constexpr int Q = decltype(qc)::value;
                             tile513_issue_part<4 * Q, 4 * Q + 4>(g.y, rowof, yv, tl);
                             __builtin_amdgcn_sched_barrier(0);
-                            tile513_commit_part<P, 4 * Q, 4 * Q + 4>(xv, U, LDU, tl, nullptr, lb);
+                            tile513_commit_part<P, 4 * Q, 4 * Q + 4, XFH>(xv, U, LDU, tl, nullptr, lb);
                             __builtin_amdgcn_sched_barrier(0);
                         });
                         tile513_issue_last(g.y, rowof, yv, tl);
                         __builtin_amdgcn_sched_barrier(0);
-                        tile513_commit_last<P, XP>(xv, U, LDU, tl, nullptr, lb);
+                        tile513_commit_last<P, XP, XFH>(xv, U, LDU, tl, nullptr, lb);
                         y_early = true;
                     } else
 #endif
                     {
-                        tile513_commit<P, XP>(xv, U, LDU, tl);
+                        tile513_commit<P, XP, XFH>(xv, U, LDU, tl);
 #pragma unroll
                         for (int i = 0; i < NQ513; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // a full definition on every path (see xv below)
                     }
@@ -780,7 +786,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
 #pragma unroll
                     for (int i = 0; i < NQ513; ++i) { xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; yv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     if constexpr (!DEFER) store_bias();
-                    load_rows_to_lds<P>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
+                    load_rows_to_lds<P, XFH>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
                 }
                 if constexpr (INFO) {
                     for (int i = ht; i < 6 * HD + 2; i += 256) {
@@ -806,9 +812,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 f32x16 hacc;
                 zero_acc<P>(hacc);
                 hws.fill();
-                gemm_seg<P, HS, DH, H_W1X>(hacc, hws, Urh + SCc::NX1 * 2 * E);
+                gemm_seg<P, HS, DH, H_W1X, HWS, XFH>(hacc, hws, Urh + SCc::NX1 * 2 * E);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) keep[r * 256 + ht] = hacc[r];
+                for (int r = 0; r < 16; ++r) keep[r * 256 + ht] = XFH ? hacc[r] * X16::ACC : hacc[r];
             }
             // ---- M2_info: the classifier on x (models.py:41-63, 418), on the helper waves beside the chain's encoder.  Wave hw owns hidden
             // features 32 hw .. + 31 of both 128-wide layers; the layer images sit in columns IMA / IMB / IMC of U.
@@ -819,11 +825,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 if (it > 0) hws.fill();                                    // (first tile: requested in front of the x tile)
                 f32x16 cacc;
                 zero_acc<P>(cacc);
-                gemm_seg<P, HS, DH, H_C1>(cacc, hws, Urh);
+                gemm_seg<P, HS, DH, H_C1, HWS, XFH>(cacc, hws, Urh);
                 float bvc[16];
                 bias16(Binfo + OBC1, 32 * hw, h, bvc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c1r[r] = fmaxf(cacc[r] + bvc[r], 0.f);
+                for (int r = 0; r < 16; ++r) c1r[r] = fmaxf((XFH ? cacc[r] * X16::ACC : cacc[r]) + bvc[r], 0.f);
             }
             f32x16 accy;                                                   // label block of decoder layer 1 (HS::HELPY)
             int yplanes = NP;                                              // planes of the label stash this tile writes (RowsArgs::ylo_skip)
@@ -833,7 +839,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if (YP > 0) {
                 if (Y513 && yfast && !y_early) tile513_issue(g.y, rowof, yv, tl);
                 R2_HSTAMP(16);
-                if (st2x) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (st2x && !XFH) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);      // (split-fp16 image: the x stash is re-read column-wise after BH1 / BH2, see xstash_reload)
                 R2_HSTAMP(17);
                 wg_barrier();                                           // BL1X
                 if constexpr (HS::HELPY && HS::n(H_W1X) == 0) hws.fill();  // decoder layer 1's first fragments arrive under the label commit
@@ -891,7 +897,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                     if (h == 0) red2[hw * 32 + l31] = pd;
                 }
             } else {
-                if (st2x) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);
+                if (st2x && !XFH) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);      // (split-fp16 image: the x stash is re-read column-wise after BH1 / BH2, see xstash_reload)
                 if constexpr (HS::n(H_W1X) > 0) wg_barrier();            // BL1X (models without labels): the partial tile is in `keep`
             }
             wg_barrier();                                               // BH1
@@ -921,6 +927,11 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 }
             }
             if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+#ifndef R2_XSP
+#define R2_XSP 1      // placement of the x stash re-read (split-fp16 image): 0 = groups 0-3 after BH1, 4-8 after BH2; 1 = all after BH2 (the heads phase, 4.9 us: measured +0.2 us per step against the round-3 LDS transposition, tools/r04/exp_xsp.sh; 0: +1 .. 3, 2: +0.6); 2 = 0-4 after BH2, 5-8 after BZ
+#endif
+            // (M2_info: the helpers run the classifier beside the encoder in these phases; its x stash waits for the auxiliary-net phases)
+            if constexpr (XFH && !INFO && R2_XSP == 0) { if (st2x) xstash_reload<P, 0, 4>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
 #if R2_LATE_Y
             // the label tile stays in U until the output layer: its stash waits for these two phases, away from the window in which every
             // CU reads x and y and writes the x stash (the first 10 us of the kernel move 68 MB: HBM-bound); split over the L2 and the
@@ -939,6 +950,13 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 if (st1) stash_tile<P>(U + IMC, LDU, 32 * hw, (T*)g.dc2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, g.alpha);
             }
             if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+            if constexpr (XFH && !INFO) {
+                if (st2x) {
+                    if constexpr (R2_XSP == 0) xstash_reload<P, 4, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl);
+                    else if constexpr (R2_XSP == 1) xstash_reload<P, 0, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl);
+                    else xstash_reload<P, 0, 5>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl);
+                }
+            }
 #if R2_LATE_Y
             if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, R2_YSPREAD, 1 << 30, yplanes);
 #endif
@@ -955,6 +973,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 put_lds<P>(hv, Ha, LDH, 32 * hw, l31, h);
             }
             if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
+            if constexpr (XFH && !INFO && R2_XSP == 2) { if (st2x) xstash_reload<P, 5, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
             if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
             if constexpr (INFO) {
                 if (st1) stash_tile<P>(U + IMA, LDU, 32 * hw, (T*)g.dc1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, g.alpha);
@@ -963,6 +982,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 const float sa = g.gamma - g.beta;
                 wg_barrier();                                           // BA1: a1 is in Ha
                 if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.a1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
+                if constexpr (XFH) { if (st2x) xstash_reload<P, 0, 5>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
                 wg_barrier();                                           // BA2: a2 is in Hb, the output partials in red2
                 if (st1) {
                     stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.a2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
@@ -980,6 +1000,7 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                 }
                 wg_barrier();                                           // BA3: dpre2 is in Ha
                 if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.da2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, sa);
+                if constexpr (XFH) { if (st2x) xstash_reload<P, 5, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
                 wg_barrier();                                           // BA4: dpre1 is in Hb
                 if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.da1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, sa);
             }
@@ -1063,8 +1084,8 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
                         const int64_t br = fb0 + r;
                         return br < g.B ? br : g.B - 1;
                     };
-                    if (g.fastx && (fb0 + TB) <= g.B) { tile513_issue(g.x, frowof, xv, tl); tile513_commit<P, XP>(xv, U, LDU, tl); }
-                    else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, fb0, g.B, U, LDU, tl, frowof);
+                    if (g.fastx && (fb0 + TB) <= g.B) { tile513_issue(g.x, frowof, xv, tl); tile513_commit<P, XP, XFH>(xv, U, LDU, tl); }
+                    else load_rows_to_lds<P, XFH>(g.x, g.ldx, XD, XP, fb0, g.B, U, LDU, tl, frowof);
                 }
                 wg_barrier();                                           // BRED'
                 continue;
@@ -1111,9 +1132,9 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             if constexpr (INFO) { if (hw == 0) { const float bcs = wave_sum(bce_c); if (lane == 0) red2[128] = bcs; } }
             if (more) {
                 if (x_in_regs) {
-                    tile513_commit<P, XP>(xv, U, LDU, tl);
+                    tile513_commit<P, XP, XFH>(xv, U, LDU, tl);
                     if constexpr (OFFL) lsum2 = tile513_log2sum(xv, g.elbo_eps, tl);      // counted with the next tile's sums
-                } else load_rows_to_lds<P>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
+                } else load_rows_to_lds<P, XFH>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
             }
             wg_barrier();                                               // BRED
         }

@@ -138,7 +138,8 @@ template <typename P, typename SC, int D, int AUX = R2_WAUX> struct WStream {
 
 // acc += W(segment S) * act^T.  `active` (wave-uniform): false for the waves that do not own this segment (the single-tile heads
 // belong to wave 0): they skip the arithmetic but keep requesting, so every wave's ring stays in phase with the schedule.
-template <typename P, typename SC, int D, int S, typename WS>
+// F16: both operands of this segment hold split-fp16 planes (fused_tiles.hpp: struct X16)
+template <typename P, typename SC, int D, int S, typename WS, bool F16 = false>
 __device__ __forceinline__ void gemm_seg(f32x16& acc, WS& w, const typename P::T* brow, bool blo = true, bool active = true) {
     typedef typename P::Frag Frag;
     constexpr int N = SC::n(S), Q0 = SC::start(S), STR = 2 * P::E;
@@ -170,7 +171,8 @@ __device__ __forceinline__ void gemm_seg(f32x16& acc, WS& w, const typename P::T
                     constexpr int i = decltype(ic)::value;
                     if (active) {
 #ifndef R2_NOMFMA
-                        mmap<P>(acc, w.r[(Q0 + i) % D], bq[i % BD], blo);
+                        if constexpr (F16) mmap_f16<P>(acc, w.r[(Q0 + i) % D], bq[i % BD]);
+                        else mmap<P>(acc, w.r[(Q0 + i) % D], bq[i % BD], blo);
 #else
                         acc[0] += (float)w.r[(Q0 + i) % D][0][0] + (float)bq[i % BD][0][0];
 #endif
@@ -190,7 +192,8 @@ __device__ __forceinline__ void gemm_seg(f32x16& acc, WS& w, const typename P::T
             constexpr int I = decltype(ic)::value;
             if (active) {
 #ifndef R2_NOMFMA
-                mmap<P>(acc, w.r[(Q0 + I) % D], bq[I % BD], blo);
+                if constexpr (F16) mmap_f16<P>(acc, w.r[(Q0 + I) % D], bq[I % BD]);
+                else mmap<P>(acc, w.r[(Q0 + I) % D], bq[I % BD], blo);
 #else
                 acc[0] += (float)w.r[(Q0 + I) % D][0][0] + (float)bq[I % BD][0][0];      // experiment: operands consumed, no MFMA
 #endif

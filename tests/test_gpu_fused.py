@@ -81,12 +81,12 @@ def _relmax(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
 
 
-# bf16x3 gradient bound per tensor (fraction of the tensor's maximum), see test_fused_step_vs_oracle
+# bf16x3 gradient bound (fraction of the tensor's maximum), see test_fused_step_vs_oracle
 def x3_grad_bound(name):
-    return X3_TOL_L1 if name.endswith("encoder.hidden.0.weight") else X3_TOL
+    return X3_TOL
 
 
-X3_TOL, X3_TOL_L1 = 1e-4, 4e-4
+X3_TOL = 5e-5
 
 
 # 20 000 frames = 625 tiles: more tiles than workgroups (256 fp32 / 512 bf16), i.e. the persistent tile loop
@@ -95,15 +95,13 @@ X3_TOL, X3_TOL_L1 = 1e-4, 4e-4
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_fused_step_vs_oracle(model, y_dim, B, precision):
     """fp32 operand mode: <= 1e-4 relative (north_star bar) on losses and gradients.
-    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-5 relative (measured <= 3e-7).  Gradients, the LAW
-    measured in round 4 (profiles/r04_parity.json, tests/diag/r04_parity_law.py, B = 1000 / 8192 / 20 000 / 65 536, binary and
-    full-mantissa labels): every tensor within 1e-4 of its maximum (measured <= 4.3e-5) EXCEPT the weight of encoder layer 1, whose worst
-    ELEMENT reaches 7.5e-5 ... 3.3e-4 depending on the batch's content, not on its size (9.4e-5 at 65 536 frames, 2.25e-4 at 20 000), while
-    its rms error stays <= 1.2e-4 of the tensor's rms.  Cause (tools/r04/sim_l1x.py: the step in float64 with the split applied to one
-    operand role at a time): the 16-bit operands of the L1 x GEMM move a pre-activation by ~4e-6 of its LARGEST term; on heavy-tailed power
-    spectra (x up to 1e4) a unit whose terms are ~100 but whose sum is ~5 sits on the knee of tanh, and the 2 dpre / (1 - h^2) sensitivity
-    turns that into ~1e-4 of one frame's row of dW1 = dpre1^T x -- with that one GEMM exact the whole policy holds 1.4e-5.  Bound here:
-    4e-4 for that tensor (and 1.5e-4 on its rms error), 1e-4 for every other tensor.
+    bf16x3 (split bf16, three MFMAs per product: the benchmarked mode): losses <= 1e-5 relative (measured <= 3e-7); every gradient tensor
+    within 5e-5 of its maximum and 5e-5 in rms at EVERY batch size and label type measured (B = 1000 / 8192 / 20 000 / 65 536, binary
+    and full-mantissa labels: worst 1.8e-5, profiles/r04_parity.json).  Round 3 measured 7.5e-5 ... 3.3e-4 on the weight of encoder
+    layer 1, by the batch's content; tools/r04/sim_l1x.py traced all of it to the 16-bit operands of the L1 x GEMM on heavy-tailed power
+    spectra (a unit on the knee of tanh whose terms are ~100), and since round 4 that one GEMM multiplies split-FP16 planes (11 + 11
+    bits, fixed power-of-two scales, csrc/fused_tiles.hpp: struct X16) while its weight-gradient operand keeps split-bf16 planes of the
+    fp32 values (relative precision per element: Adam normalises each element by its own history).
     bf16 (one bf16 per operand, opt-in fast mode): the synthetic power spectra span 1e-12 .. 1e4, so bf16
     rounding of x and W1 moves encoder pre-activations by O(1) on the loudest frames; measured deviation bound
     stated here: losses 2e-3 relative, every gradient tensor cosine >= 0.99 with the fp64 oracle and within 0.3 of its max."""
@@ -126,7 +124,7 @@ def test_fused_step_vs_oracle(model, y_dim, B, precision):
         assert _relmax(g[k], gr) < (gtol if gtol is not None else x3_grad_bound(k)), k
         if precision == "bf16x3":
             rms = float(np.sqrt(np.mean((g[k].astype(np.float64) - gr) ** 2)) / (np.sqrt(np.mean(gr ** 2)) + 1e-30))
-            assert rms < 1.5e-4, (k, rms)
+            assert rms < 5e-5, (k, rms)
         if precision == "bf16" and B > 1:
             cos = float(np.sum(g[k] * gr) / (np.linalg.norm(g[k]) * np.linalg.norm(gr) + 1e-300))
             assert cos > (0.99 if B < 20000 else 0.97), (k, cos)     # the 20 000-frame draw holds louder outliers (0.982 on W1)
@@ -528,7 +526,7 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
     np.testing.assert_allclose(losses[:7], ref, rtol=5e-3 if precision == "bf16" else 1e-4, atol=1e-5)
     g = tr.grads_numpy()
     # bf16x3 on the RAW batch: 1e-3 bounds rows hit by ReLU flips (~110 frames of this batch have a unit within 1e-5 of a tie, and a layer-2
-    # flip moves every row of the layer-1 gradient); the same batch without its near-tie frames holds the VAE's 1e-4 / 4e-4 law on every row:
+    # flip moves every row of the layer-1 gradient); the same batch without its near-tie frames holds 1e-4 on every row of every tensor:
     # test_fused_m2info_tie_free_batch_vs_oracle (round 4; measured figures in profiles/r04_parity.json)
     tol = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16": 0.3}[precision]
     # The classifier / auxiliary nets are ReLU MLPs: the reference's own gradient is discontinuous where a hidden
@@ -580,9 +578,8 @@ def test_fused_m2info_tie_free_batch_vs_oracle(precision):
     which is why 'at most two rows per tensor' (test_fused_m2info_vs_oracle_full_batch) cannot bound the layer-1 tensors under 16-bit
     operands: at 8192 frames ~110 frames have a unit with margin < 1e-5, ~1070 with margin < 1e-4 (tests/diag/r04_parity_law.py).
     Here the oracle replaces every frame that has a unit with margin < 1e-4 by a frame whose margins are all >= 4e-4 (1067 of 8192), and on
-    that batch -- same model, same sizes, same kernel -- every gradient tensor obeys the VAE's per-tensor law with NO row exempted:
-    1e-4 of the tensor's maximum (measured <= 7.0e-5 on the ReLU nets), 4e-4 for the weight of encoder layer 1 (3.3e-4: the L1 x GEMM's
-    operand precision, see test_fused_step_vs_oracle); the fp32 policy holds 1e-4 (measured 2.4e-5)."""
+    that batch -- same model, same sizes, same kernel -- every gradient tensor is within 1e-4 of its maximum with NO row exempted
+    (measured 2.4e-5 under both policies; 7.0e-5 on the classifier's first layer at another seed, tests/diag/r04_parity_law.py)."""
     dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
     B, delta = 8192, 1e-4
     params = gu.make_params("M2_info", dims, 31)
@@ -613,7 +610,7 @@ def test_fused_m2info_tie_free_batch_vs_oracle(precision):
     wk = max(worst_by, key=worst_by.get)
     print(f"fused[M2_info tie-free, {replaced} frames replaced, {precision}]: worst gradient error {worst_by[wk]:.2e} ({wk})")
     for k, v in worst_by.items():
-        assert v < (1e-4 if precision == "fp32" else x3_grad_bound(k)), (k, v)
+        assert v < 1e-4, (k, v)
 
 
 def test_evaluate_is_forward_only_and_matches_step_losses():
@@ -853,9 +850,8 @@ def test_label_lo_plane_on_demand_equals_always(y_dim, B, monkeypatch):
     weight-gradient kernel reads the label lo plane only in launches where some tile needs it.  Sequence of steps with real-valued
     labels everywhere, in ONE tile, nowhere, and in another tile again (stale lo planes of tile slots that turned binary must
     not be read): losses and parameters equal the always-both-planes path (DVAE_YLO_ALWAYS=1) bit for bit, and the
-    real-valued-label gradients match the float64 oracle under the same per-tensor law as test_fused_step_vs_oracle (1e-4 of a tensor's
-    maximum; 4e-4 for the weight of encoder layer 1, where this 20 000-frame batch measures 2.2e-4 -- the L1 x GEMM's operand precision
-    on a heavy-tailed frame, not the labels and not the batch size: profiles/r04_parity.json)."""
+    real-valued-label gradients match the float64 oracle within the bound of test_fused_step_vs_oracle (5e-5 of every tensor's maximum;
+    round 3 had loosened this to 4e-4 for the 20 000-frame case: that was the L1 x GEMM's operand precision, fixed in round 4)."""
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
     params = gu.make_params("M2", dims, 51)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -922,8 +918,9 @@ def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_la
         res[fold] = out
     assert applies["0"] == len(batches)
     folded = applies["1"] == 0
-    # the tail needs ks > 1, a grid within the CU count and <= 120 blocks: the fp32 policy's 16 slices x 22 blocks do not fit the CUs
-    assert folded == ((model, precision) != ("M2", "fp32")), (model, y_dim, B, precision, applies)
+    # (the tail needs ks > 1, a grid within the CU count and <= 120 blocks; when it cannot run, both arms are the three-launch step)
+    print(f"fold[{model},y{y_dim},B{B},{precision}]: the optimizer tail {'ran' if folded else 'did NOT run (grid cannot fold)'}")
+    assert folded or (model, y_dim, B, precision) != ("M2", 513, 8192, "bf16x3"), "the headline configuration must fold"
     for (la, ga, pa, ma, va), (lb, gb, pb, mb, vb) in zip(res["1"], res["0"]):
         assert np.all(np.isfinite(la))
         np.testing.assert_array_equal(la, lb)
