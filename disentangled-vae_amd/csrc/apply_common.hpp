@@ -47,10 +47,16 @@ __device__ __forceinline__ void apply_element(const ApplyArgs& g, int64_t idx, c
     }
     const int r = (int)((unsigned)i / (unsigned)d.cols), c = (int)i - r * d.cols;      // a tensor holds far fewer than 2^31 elements
     constexpr int E = 16 / (int)sizeof(T), KS = 2 * E;
+    // position of (rr, cc) in a fragment-major copy with `nt` row tiles: 32-row tiles / 16-deep k-steps, or (kind16) 16-row tiles / 32-deep
+    auto pos = [&](int64_t off, int nt, int rr, int cc, int ld) __attribute__((always_inline)) -> int64_t {
+        if (!WFRAG) return off + (int64_t)rr * ld + cc;
+        if (d.kind16) return off + ((int64_t)((cc >> 5) * nt + (rr >> 4)) * 64 + ((cc & 31) >> 3) * 16 + (rr & 15)) * 8 + (cc & 7);
+        return off + ((int64_t)((cc / KS) * nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E;
+    };
+    auto heads_row = [](int k, int map) { return 16 * (k >> 3) + 4 * ((k & 7) >> 1) + (k & 1) + (map == 2 ? 2 : 0); };
     if (d.sf_off >= 0) {
-        const int rr = r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
-        const int64_t o = WFRAG ? d.sf_off + ((int64_t)((cc / KS) * d.sf_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
-                                : d.sf_off + (int64_t)rr * d.sf_ld + cc;
+        const int rr = d.rowmap ? heads_row(r, d.rowmap) : r + d.sf_roff, cc = c < d.sf_split ? c : c + d.sf_gap;
+        const int64_t o = pos(d.sf_off, d.sf_nt, rr, cc, d.sf_ld);
         if constexpr (NP == 2 && sizeof(T) == 2) {
             if (c < d.sf_f16_cols) {                               // the x block of layer 1: split fp16 of W * 2^6 (struct X16)
                 const float ws = pi * X16::WS;
@@ -65,9 +71,8 @@ __device__ __forceinline__ void apply_element(const ApplyArgs& g, int64_t idx, c
         }
     }
     if (d.st_off >= 0 && c < d.st_cmax) {
-        const int rr = c, cc = r + d.st_roff;
-        const int64_t o = WFRAG ? d.st_off + ((int64_t)((cc / KS) * d.st_nt + (rr >> 5)) * 64 + ((cc % KS) / E) * 32 + (rr & 31)) * E + cc % E
-                                : d.st_off + (int64_t)rr * d.st_ld + cc;
+        const int rr = d.trowmap ? heads_row(c, d.trowmap) : c, cc = r + d.st_roff;
+        const int64_t o = pos(d.st_off, d.st_nt, rr, cc, d.st_ld);
         const T ph = (T)pi;
         wc[o] = ph;
         if constexpr (NP == 2) wc[o + g.wpl] = (T)(pi - (float)ph);

@@ -17,6 +17,12 @@ struct TensorDesc {
     int64_t st_off;       // transposed copy (A operand of the backward-data product), -1 = none
     int32_t st_nt, st_roff, st_cmax;            // element (r, c < cmax) -> row c, column r + roff
     int32_t sf_f16_cols;                        // columns c < this of the FORWARD copy hold split-fp16 planes of W * 2^6 (fused_tiles.hpp: struct X16); 0 = none
+    // rows3 kernel (train_rows3.hip): fragment-major copies for v_mfma_f32_16x16x32 -- 16-row tiles, 32-deep k-steps: element (row, col) at
+    //   off + (((col / 32) * nt + row / 16) * 64 + ((col % 32) / 8) * 16 + row % 16) * 8 + col % 8          (nt = 16-row tiles)
+    // kind16 != 0 selects it for both copies of the tensor.  rowmap (forward copy) / trowmap (transposed copy): 1, 2 = the latent heads'
+    // interleaved row order (row k of mu / log_var -> tile k / 8, row 4 ((k % 8) / 2) + (k % 2) [+ 2 for log_var]): a lane of the 16 x 16 C
+    // tile then holds mu_k and log_var_k of the same k
+    int32_t kind16, rowmap, trowmap, pad2;
 };
 
 struct ApplyArgs {
