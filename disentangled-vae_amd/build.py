@@ -38,7 +38,7 @@ def build(force=False, verbose=True, diag=False):
 
 
 def _build(LIB, objdir, extra, force, verbose):
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     if not force and not _newer_than_lib(deps, LIB):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -49,7 +49,7 @@ def _build(LIB, objdir, extra, force, verbose):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                [os.path.getmtime(src)] + [os.path.getmtime(p) for p in deps if p.endswith((".hpp", ".h"))]):
+                [os.path.getmtime(src)] + [os.path.getmtime(p) for p in deps if p.endswith((".hpp", ".h", ".inc"))]):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
                "-Wall", "-Wno-unused-function"] + FILE_FLAGS.get(os.path.basename(src), []) + extra + os.environ.get("DVAE_CFLAGS", "").split()

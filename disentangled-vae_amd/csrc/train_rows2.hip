@@ -108,81 +108,9 @@ template <typename P, int YP, bool YENC, int MODE, bool INFO = false, bool DEFER
 __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
     static_assert(!INFO || (MODE == 0 && YP == 16 && !YENC), "M2_info: train step, 1-dim label, encoder on x only");
     static_assert(!DEFER || (MODE == 0 && !INFO && sizeof(typename P::T) == 2), "deferred optimizer step: M1 / M2 train step, bf16 copies");
-    typedef typename P::T T;
-    typedef typename P::Frag Frag;
-    constexpr int E = P::E, KS = P::KSTEP, NP = P::NP;
-    constexpr int LDU = Ld<T>::u, LDH = Ld<T>::hh, LDZ = Ld<T>::z;
-    constexpr bool Y513 = (YP == XP);
-    // train step with two operand planes: the loss epilogue of the output layer runs on the helper waves (see put_raw4), which takes
-    // 64 registers (x prefetch, terms) off the chain waves' peak and pays for a deeper weight ring (PDO): the GEMM phases are
-    // latency-bound by that depth (k-step time = t0 + L / D: 207 / 132 / 100 ns at D = 2 / 4 / 6)
-#ifndef R2_OFFL
-#define R2_OFFL 1
-#endif
-#ifndef R2_LATE_Y
-#define R2_LATE_Y 1
-#endif
-#ifndef R2_EARLY_Y
-#define R2_EARLY_Y 1
-#endif
-#ifndef R2_DH
-#define R2_DH 6
-#endif
-#ifndef R2_HPRIO
-#define R2_HPRIO 0
-#endif
-#ifndef R2_YSPREAD
-#define R2_YSPREAD 8
-#endif
-#ifndef R2_YLOSEG
-#define R2_YLOSEG 0
-#endif
-#ifndef R2_STAGGER
-#define R2_STAGGER 0
-#endif
-    constexpr bool OFFL = R2_OFFL && MODE == 0 && NP == 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* const U = reinterpret_cast<T*>(smem);
-    T* const Ha = U + TB * LDU;
-    T* const Hb = Ha + TB * LDH;
-    T* const Zb = Hb + TB * LDH;
-    typedef Lds2<P, INFO> LD2;
-    float* const Bias = reinterpret_cast<float*>(smem + LD2::o_bias);
-    float* const red = reinterpret_cast<float*>(smem + LD2::o_red);
-    int* const flags = reinterpret_cast<int*>(smem + LD2::o_flags);          // [0]: the label tile has a non-zero lo plane
-    int64_t* const rowsrc = reinterpret_cast<int64_t*>(smem + LD2::o_rows);  // [2][TB] gather table, double buffered
-    // M2_info (DeepGenerativeModel_v5, models.py:390-444; loop body scripts/training_M2_info_vad.py:159-198): the classifier on x runs on
-    // the HELPER waves beside the chain's encoder (its layer images live in columns 32 .. 415 of U, which are free between the x image
-    // and the output layer when the label is one column wide); the auxiliary net on z is four extra chain phases after the heads.
-    float* const Binfo = reinterpret_cast<float*>(smem + LD2::o_info);
-    float* const red2 = reinterpret_cast<float*>(smem + LD2::o_red2);
-    float* const dzs = reinterpret_cast<float*>(smem + LD2::o_dzu);
-    constexpr int OBC1 = 0, OBC2 = HD, OWC3 = 2 * HD, OBA1 = 3 * HD, OBA2 = 4 * HD, OWA3 = 5 * HD, OS3 = 6 * HD;
-    constexpr int IMA = 32, IMB = 160, IMC = 288;                            // classifier layer images: first column in U
-    // Two waves per SIMD leave 256 registers per wave: the tanh outputs the backward pass needs again do not stay in
-    // registers.  h1 / h2 (needed ten phases later) wait in private fp32 LDS slots; d1 / d2 are re-read from their own
-    // operand planes (hi + lo), which the backward tiles then overwrite in place (same lane, same elements).
-    float* const keep = reinterpret_cast<float*>(smem + LD2::o_keep);
-    float* const keepz = reinterpret_cast<float*>(smem + LD2::o_keepz);
-    constexpr int OB1 = 0, OB2 = HD, OBMV = 2 * HD, OB3 = 2 * HD + 32, OB4 = 3 * HD + 32, OB5 = 4 * HD + 32;
-
-    constexpr int DH = R2_DH;                                                    // ring depth of the helper waves' own weight stream
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const bool gather = g.rows != nullptr;
-#ifndef R2_XCDMAP
-#define R2_XCDMAP 0
-#endif
-    // first tile of this workgroup.  R2_XCDMAP (diagnostic): workgroup b runs on XCD b % 8; with the map, XCD x takes the CONSECUTIVE
-    // tiles [x * grid / 8, (x + 1) * grid / 8) of a round, i.e. the frames of one slice of the weight-gradient kernel (which keeps slice
-    // s on XCD s % 8), so that a stash line is written and read through the same L2
-    int tile0 = (int)blockIdx.x;
-#if R2_XCDMAP
-    if ((gridDim.x & 7) == 0 && (g.ntiles % (int)gridDim.x) == 0) tile0 = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-#endif
-    const int ntl = (g.ntiles - tile0 + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1: grid <= ntiles)
-
+#define ROWS_XP XP
+#define ROWS_CHAIN_WAVES 4
+#include "rows_prologue.inc"
     if (wave_u < 4) {
         // =========================================================== chain waves ===========================================================
         const int cw = wave_u, fb = 32 * cw;
@@ -659,488 +587,12 @@ __global__ __launch_bounds__(512) void vae_rows2_kernel(const RowsArgs g) {
             g.partials[4 * blockIdx.x + 3] = tot_ba;
         }
     } else {
-        // =========================================================== helper waves ===========================================================
-        const int hw = wave_u - 4, ht = tid - 256;
-        constexpr bool XFH = P::XF16 && NP == 2;                           // the x image in split fp16 (fused_tiles.hpp: struct X16)
-        // (An L2 warm-up of the weight copies by the helpers -- one dword per 128-byte line, 1/32 of the buffer per workgroup of an
-        // XCD -- changed nothing: the weight stream runs at the ~34 B/clk/CU of an L2-resident table shared by every CU, not at miss latency.)
-        // fp32 bias table -> LDS once; the loads are issued here (clamped addresses instead of branches)
-        constexpr int NBT = Ld<T>::nbias;
-        constexpr int NB = (NBT + 255) / 256;
-        float bvv[NB];
-        auto load_bias = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                int i = ht + 256 * q;
-                i = i < NBT ? i : NBT - 1;
-                const float* src;
-                int k;
-                if (i < OB2) { src = g.b1; k = i; }
-                else if (i < OBMV) { src = g.b2; k = i - OB2; }
-                else if (i < OBMV + ZD) { src = g.bmu; k = i - OBMV; }
-                else if (i < OB3) { src = g.blv; k = i - OBMV - ZD; }
-                else if (i < OB4) { src = g.b3; k = i - OB3; }
-                else if (i < OB5) { src = g.b4; k = i - OB4; }
-                else if (i < OB5 + NO) { src = g.b5; k = i - OB5; k = k < XD ? k : XD - 1; }
-                else { src = g.w5last; k = i - OB5 - NO; }
-                // deferred step: the values were written by other workgroups of THIS launch (write-through stores): sc1 loads, after BARR
-                if constexpr (DEFER) bvv[q] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else bvv[q] = src[k];
-            }
-        };
-        auto store_bias = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                const int i = ht + 256 * q;
-                if (i < NBT) Bias[i] = (i >= OB5 + XD && i < OB5 + NO) ? 0.f : bvv[q];
-            }
-        };
-        if constexpr (!DEFER) load_bias();
-        // gather table of tile `tl_` into half `half` (threads 0..31 of the helper group); bad indices are clamped and counted
-        auto fill_rows = [&](int tl_, int half) {
-            if (ht < TB) {
-                const int64_t bf = (int64_t)tl_ * TB + ht;
-                const int64_t br = bf < g.B ? bf : g.B - 1;                 // frames past the batch repeat its last row (masked out later)
-                int64_t r = g.rows[br];
-                if (r < 0 || r >= g.n_rows) { r = 0; if (g.bad_rows && bf < g.B) atomicAdd(g.bad_rows, 1); }
-                rowsrc[half * TB + ht] = r;
-            }
-        };
-        // the helper waves' own weight stream (wstream.hpp: HSched): the rest of the x block of encoder layer 1 and, for 513-label
-        // models, decoder layer 1.  Row tile of helper wave hw = row tile of its partner chain wave.
-        typedef Sched<P, YP, YENC, (OFFL ? P::PDO : P::PD), INFO> SCc;
-        typedef HSched<P, YP, YENC, DH, INFO> HS;
-        typedef WStream<P, HS, DH> HWS;
-        HWS hws;
-        if constexpr (HS::any) {
-            hws.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
-            hws.voff = lane * 16;
-            hws.pl = g.wpl_bytes;
-            auto mo = [&](const void* Wp) { return (unsigned)((const char*)Wp - (const char*)g.wcopy); };
-            constexpr unsigned FBB = HS::FBB;
-            const unsigned tw = (unsigned)hw * FBB;
-            hws.sb[H_W1X] = mo(g.W1s) + tw + (unsigned)SCc::NX1 * 4u * FBB;
-            hws.sb[H_W3Y] = mo(g.W3s) + tw + (unsigned)(ZD / KS) * 4u * FBB;
-            hws.sb[H_W3Z] = mo(g.W3s) + tw;
-            hws.sb[H_PAD] = mo(g.W1s);
-            if constexpr (INFO) { hws.sb[H_C1] = mo(g.Wc1s) + tw;  hws.sb[H_C2] = mo(g.Wc2s) + tw;  hws.sb[H_C2T] = mo(g.Wc2t) + tw; }
-            else { hws.sb[H_C1] = hws.sb[H_C2] = hws.sb[H_C2T] = 0; }
-            if constexpr (INFO) hws.fill();                               // the classifier's first fragments: requested BEFORE the x tile (vmcnt retires in order)
-        }
-        const T* const Urh = U + l31 * LDU + h * E;
-        const T* const Zbrh = Zb + l31 * LDZ + h * E;
-        float lsum2 = 0.f;            // sum of log2(x + eps) over this thread's share of the x tiles it committed (loss epilogue, OFFL)
-        f32x4 xv[NQ513], yv[NQ513];
-        bool x_in_regs = false;       // the dense fast path holds the tile in registers between issue and commit
-        bool y_in_regs = false;       // persistent loop: the NEXT tile's label tile is requested during this tile's backward phases too
-        // forward-only launches stash nothing; stash_inputs: bit 0 = the x tile, bit 1 = the label tile (a cleared bit: the weight-gradient
-        // kernel reads that input from its fp32 matrix)
-        const bool st1 = MODE != 1 && !(g.ablate & 1), st2 = MODE != 1 && !(g.ablate & 2) && (g.stash_inputs & 2), st2x = MODE != 1 && !(g.ablate & 2) && (g.stash_inputs & 1);
-        for (int it = 0; it < ntl; ++it) {
-            const int tile = tile0 + it * (int)gridDim.x;
-            const int64_t b0 = (int64_t)tile * TB;
-            const bool full = (b0 + TB) <= g.B;
-            const int64_t* const rsrc = rowsrc + (it & 1) * TB;
-            auto rowof = [&](int r) -> int64_t {
-                if (gather) return rsrc[r];
-                const int64_t br = b0 + r;
-                return br < g.B ? br : g.B - 1;
-            };
-            // per-iteration opaque copy of the thread id: keeps the per-thread staging addresses out of loop-invariant hoisting
-            int tl = ht;
-            asm volatile("" : "+v"(tl));
-            const bool yfast = Y513 && g.fasty && full;
-            bool y_early = it > 0 && y_in_regs;
-            if (it == 0) {
-                if (gather) { fill_rows(tile, 0); wg_barrier(); }       // BROW
-                if (g.fastx && full) {
-                    tile513_issue(g.x, rowof, xv, tl);
-                    if constexpr (!DEFER) store_bias();
-#if R2_EARLY_Y
-                    if (YP > 0 && Y513 && g.fasty) {
-                        // The label tile is requested BEHIND the x tile, a quarter at a time, each quarter followed by the commit of
-                        // the x quarter that has arrived by then.  (A CU pulls ~30 GB/s from HBM while every CU does the same: the
-                        // 17 label requests of a thread take ~2.5 us to ISSUE.  Issued in one go in front of the x commit they delay
-                        // it by that much; issued after the BX barrier -- the previous form -- they arrive 3 us after the L1 x GEMM
-                        // has finished.  Interleaved, x is committed as it lands and the labels land during the L1 x GEMM.)
-                        unsigned long long lb = 0ull;
-                        static_for<0, 4>([&](auto qc) {
-                            constexpr int Q = decltype(qc)::value;
-                            tile513_issue_part<4 * Q, 4 * Q + 4>(g.y, rowof, yv, tl);
-                            __builtin_amdgcn_sched_barrier(0);
-                            tile513_commit_part<P, 4 * Q, 4 * Q + 4, XFH>(xv, U, LDU, tl, nullptr, lb);
-                            __builtin_amdgcn_sched_barrier(0);
-                        });
-                        tile513_issue_last(g.y, rowof, yv, tl);
-                        __builtin_amdgcn_sched_barrier(0);
-                        tile513_commit_last<P, XP, XFH>(xv, U, LDU, tl, nullptr, lb);
-                        y_early = true;
-                    } else
-#endif
-                    {
-                        tile513_commit<P, XP, XFH>(xv, U, LDU, tl);
-#pragma unroll
-                        for (int i = 0; i < NQ513; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // a full definition on every path (see xv below)
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NQ513; ++i) { xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; yv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                    if constexpr (!DEFER) store_bias();
-                    load_rows_to_lds<P, XFH>(g.x, g.ldx, XD, XP, b0, g.B, U, LDU, tl, rowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
-                }
-                if constexpr (INFO) {
-                    for (int i = ht; i < 6 * HD + 2; i += 256) {
-                        const int q = i / HD, k = i - q * HD;
-                        float v;
-                        if (q == 0) v = g.bc1[k]; else if (q == 1) v = g.bc2[k]; else if (q == 2) v = g.wc3[k];
-                        else if (q == 3) v = g.ba1[k]; else if (q == 4) v = g.ba2[k]; else if (q == 5) v = g.wa3[k];
-                        else v = k == 0 ? g.bc3[0] : g.ba3[0];
-                        Binfo[i] = v;
-                    }
-                }
-                if (ht == 0) flags[0] = 0;
-                if constexpr (DEFER) {
-                    wg_barrier();                                       // BARR: the optimizer update of the previous step has arrived from every workgroup
-                    load_bias();
-                    store_bias();
-                }
-                wg_barrier();                                           // BX
-                if constexpr (OFFL) { if (g.fastx && full) lsum2 += tile513_log2sum(xv, g.elbo_eps, tl); }   // the tile is still in registers
-            }
-            // ---- chain: L1 x GEMM (its NX1 k-steps); here: the other k-steps of the same row tile, partial tile -> keep
-            if constexpr (HS::n(H_W1X) > 0) {
-                f32x16 hacc;
-                zero_acc<P>(hacc);
-                hws.fill();
-                gemm_seg<P, HS, DH, H_W1X, HWS, XFH>(hacc, hws, Urh + SCc::NX1 * 2 * E);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) keep[r * 256 + ht] = XFH ? hacc[r] * X16::ACC : hacc[r];
-            }
-            // ---- M2_info: the classifier on x (models.py:41-63, 418), on the helper waves beside the chain's encoder.  Wave hw owns hidden
-            // features 32 hw .. + 31 of both 128-wide layers; the layer images sit in columns IMA / IMB / IMC of U.
-            float c1r[16], c2r[16], w3c[16];
-            float bce_c = 0.f, ylab = 0.f;
-            if constexpr (INFO) {
-                ylab = g.y[rowof(l31) * g.ldy];
-                if (it > 0) hws.fill();                                    // (first tile: requested in front of the x tile)
-                f32x16 cacc;
-                zero_acc<P>(cacc);
-                gemm_seg<P, HS, DH, H_C1, HWS, XFH>(cacc, hws, Urh);
-                float bvc[16];
-                bias16(Binfo + OBC1, 32 * hw, h, bvc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c1r[r] = fmaxf((XFH ? cacc[r] * X16::ACC : cacc[r]) + bvc[r], 0.f);
-            }
-            f32x16 accy;                                                   // label block of decoder layer 1 (HS::HELPY)
-            int yplanes = NP;                                              // planes of the label stash this tile writes (RowsArgs::ylo_skip)
-            int ydirty = 0;                                                // the tile slot's lo plane holds an earlier launch's non-zero values
-            if constexpr (NP == 2 && YP > 0) { if (g.ylo_skip && st2) ydirty = g.ylo_dirty[tile]; }
-            // ---- y loads in flight, x -> stash
-            if (YP > 0) {
-                if (Y513 && yfast && !y_early) tile513_issue(g.y, rowof, yv, tl);
-                R2_HSTAMP(16);
-                if (st2x && !XFH) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);      // (split-fp16 image: the x stash is re-read column-wise after BH1 / BH2, see xstash_reload)
-                R2_HSTAMP(17);
-                wg_barrier();                                           // BL1X
-                if constexpr (HS::HELPY && HS::n(H_W1X) == 0) hws.fill();  // decoder layer 1's first fragments arrive under the label commit
-                R2_HSTAMP(18);
-                bool any = false;                                          // does the label tile need its lo plane?  (found while committing)
-                if (Y513 && yfast) tile513_commit<P, XP>(yv, U, LDU, tl, nullptr, NP == 2 ? &any : nullptr);
-                else load_rows_to_lds<P>(g.y, g.ldy, g.ydim, YP, b0, g.B, U, LDU, tl, rowof);
-                R2_HSTAMP(19);
-                if constexpr (NP == 2) {
-                    if (Y513 && yfast) {
-                    } else {
-                        constexpr int YPD = YP > 0 ? YP : 1;
-                        for (int idx = tl; idx < TB * YP; idx += 256) any |= (float)U[Pl<P>::lds + (idx / YPD) * LDU + idx % YPD] != 0.f;
-                    }
-                    if (__ballot(any) != 0ull && lane == 0) atomicOr(&flags[0], 1);
-                }
-                R2_HSTAMP(20);
-                if constexpr (INFO) put_lds<P>(c1r, U + IMA, LDU, 32 * hw, l31, h);      // the x image is dead (BL1X)
-                wg_barrier();                                           // BY
-                if constexpr (NP == 2) {
-                    const bool ylo_t = __builtin_amdgcn_readfirstlane(flags[0]) != 0;
-                    if (g.ylo_skip && st2) {
-                        ydirty = __builtin_amdgcn_readfirstlane(ydirty);
-                        yplanes = (ylo_t || ydirty != 0) ? 2 : 1;
-                        if (ht == 0) {
-                            if (ylo_t) *g.ylo_epoch = g.launch_id;                           // every flagged tile stores the same value
-                            if ((ylo_t ? 1 : 0) != ydirty) g.ylo_dirty[tile] = ylo_t ? 1 : 0;
-                        }
-                    }
-                }
-#if !R2_LATE_Y
-                if (st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, 0, 1 << 30, yplanes);
-#endif
-                if constexpr (HS::HELPY) {
-                    // chain: L1 y GEMM (33 k-steps).  Here: the label block of decoder layer 1 (33 k-steps, independent of z), this
-                    // wave's row tile; it stays in registers until the z block joins it after BZ
-                    const bool ylo = NP == 2 && __builtin_amdgcn_readfirstlane(flags[0]) != 0;
-                    zero_acc<P>(accy);
-                    if (!R2_YLOSEG) gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, ylo);
-                    else if (ylo) gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, true);
-                    else gemm_seg<P, HS, DH, H_W3Y>(accy, hws, Urh, false);
-                }
-                if constexpr (INFO) {                                   // classifier layer 2 + this wave's share of the output dot product
-                    f32x16 a2c;
-                    zero_acc<P>(a2c);
-                    gemm_seg<P, HS, DH, H_C2>(a2c, hws, Urh + IMA);
-                    float bvc[16];
-                    bias16(Binfo + OBC2, 32 * hw, h, bvc);
-                    bias16(Binfo + OWC3, 32 * hw, h, w3c);
-                    float pd = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { c2r[r] = fmaxf(a2c[r] + bvc[r], 0.f); pd = fmaf(w3c[r], c2r[r], pd); }
-                    put_lds<P>(c2r, U + IMB, LDU, 32 * hw, l31, h);
-                    pd += __shfl_xor(pd, 32, 64);
-                    if (h == 0) red2[hw * 32 + l31] = pd;
-                }
-            } else {
-                if (st2x && !XFH) stash_from_lds<P>(U, LDU, XP, NO, (T*)g.xT, g.spl, g.Bp, b0, tl);      // (split-fp16 image: the x stash is re-read column-wise after BH1 / BH2, see xstash_reload)
-                if constexpr (HS::n(H_W1X) > 0) wg_barrier();            // BL1X (models without labels): the partial tile is in `keep`
-            }
-            wg_barrier();                                               // BH1
-            if constexpr (INFO) {
-                // sigmoid output, binary_cross_entropy against the frame label (utils.py:55-56) and the unit-scale backward to dpre2; the
-                // stashed pre-activation gradients carry alpha (classif_loss = alpha * BCE, training_M2_info_vad.py:165)
-                const bool live_h = (b0 + l31) < g.B;
-                const float logit = red2[l31] + red2[32 + l31] + red2[64 + l31] + red2[96 + l31] + Binfo[OS3];
-                const float p = 1.f / (1.f + P::exp_(-logit));
-                const float lp = P::log_(p + g.elbo_eps), lq = P::log_(1.f - p + g.elbo_eps);
-                bce_c = (live_h && h == 0 && hw == 0) ? -(ylab * lp + (1.f - ylab) * lq) : 0.f;
-                const float u = live_h ? -g.invB * (ylab / (p + g.elbo_eps) - (1.f - ylab) / (1.f - p + g.elbo_eps)) : 0.f;   // d BCE / d p
-                const float dpre3 = u * p * (1.f - p);
-                float dv2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dv2[r] = c2r[r] > 0.f ? w3c[r] * dpre3 : 0.f;                 // dpre2 (unit scale)
-                put_lds<P>(dv2, U + IMC, LDU, 32 * hw, l31, h);
-                if (st1) {
-                    stash_tile<P>(U + IMA, LDU, 32 * hw, (T*)g.c1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-                    stash_tile<P>(U + IMB, LDU, 32 * hw, (T*)g.c2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-                    if (hw == 0 && h == 0) {                               // output pre-activation gradient: feature row 0 of a 32-row stash tile
-                        T* d3 = (T*)g.dc3T + (b0 / KS) * (64 * E) + (l31 / E) * 32 * E + (l31 % E);
-                        const T d3h = P::cvt(dpre3 * g.alpha);
-                        *d3 = d3h;
-                        if constexpr (NP == 2) d3[g.spl] = P::cvt(dpre3 * g.alpha - (float)d3h);
-                    }
-                }
-            }
-            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.h1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-#ifndef R2_XSP
-#define R2_XSP 1      // placement of the x stash re-read (split-fp16 image): 0 = groups 0-3 after BH1, 4-8 after BH2; 1 = all after BH2 (the heads phase, 4.9 us: measured +0.2 us per step against the round-3 LDS transposition, tools/r04/exp_xsp.sh; 0: +1 .. 3, 2: +0.6); 2 = 0-4 after BH2, 5-8 after BZ
-#endif
-            // (M2_info: the helpers run the classifier beside the encoder in these phases; its x stash waits for the auxiliary-net phases)
-            if constexpr (XFH && !INFO && R2_XSP == 0) { if (st2x) xstash_reload<P, 0, 4>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
-#if R2_LATE_Y
-            // the label tile stays in U until the output layer: its stash waits for these two phases, away from the window in which every
-            // CU reads x and y and writes the x stash (the first 10 us of the kernel move 68 MB: HBM-bound); split over the L2 and the
-            // heads phase (feature tiles below / from R2_YSPREAD) so that neither phase waits for it
-            if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, 0, R2_YSPREAD, yplanes);
-#endif
-            wg_barrier();                                               // BH2
-            if constexpr (INFO) {                                          // classifier: backward through layer 2, dpre1 -> image A (c1 is stashed)
-                f32x16 a3c;
-                zero_acc<P>(a3c);
-                gemm_seg<P, HS, DH, H_C2T>(a3c, hws, Urh + IMC);
-                float dv1[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dv1[r] = c1r[r] > 0.f ? a3c[r] : 0.f;                          // dpre1 (unit scale)
-                put_lds<P>(dv1, U + IMA, LDU, 32 * hw, l31, h);
-                if (st1) stash_tile<P>(U + IMC, LDU, 32 * hw, (T*)g.dc2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, g.alpha);
-            }
-            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.h2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            if constexpr (XFH && !INFO) {
-                if (st2x) {
-                    if constexpr (R2_XSP == 0) xstash_reload<P, 4, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl);
-                    else if constexpr (R2_XSP == 1) xstash_reload<P, 0, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl);
-                    else xstash_reload<P, 0, 5>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl);
-                }
-            }
-#if R2_LATE_Y
-            if (YP > 0 && st2) stash_from_lds<P>(U, LDU, YP, (YP + 31) / 32 * 32, (T*)g.yT, g.spl, g.Bp, b0, tl, R2_YSPREAD, 1 << 30, yplanes);
-#endif
-            wg_barrier();                                               // BZ
-            if constexpr (HS::HELPY) {
-                // decoder layer 1 on the helper waves: the z block (one k-step) joins the label block; d1 -> Ha
-                f32x16 az;
-                zero_acc<P>(az);
-                gemm_seg<P, HS, DH, H_W3Z>(az, hws, Zbrh);
-                float hv[16], bv[16];
-                bias16(Bias + OB3, 32 * hw, h, bv);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hv[r] = P::tanh_(az[r] + accy[r] + bv[r]);
-                put_lds<P>(hv, Ha, LDH, 32 * hw, l31, h);
-            }
-            if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.zT, g.spl, b0, l31, h);
-            if constexpr (XFH && !INFO && R2_XSP == 2) { if (st2x) xstash_reload<P, 5, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
-            if (ht == 0) flags[0] = 0;                                     // read by the chain before BH1 of this tile; next written after BL1X of the next
-            if constexpr (INFO) {
-                if (st1) stash_tile<P>(U + IMA, LDU, 32 * hw, (T*)g.dc1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, g.alpha);
-                // the auxiliary net on the chain (four extra phases): its layer tiles go to the stash from here; pre-activation gradients
-                // carry gamma - beta (quirk Q4)
-                const float sa = g.gamma - g.beta;
-                wg_barrier();                                           // BA1: a1 is in Ha
-                if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.a1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-                if constexpr (XFH) { if (st2x) xstash_reload<P, 0, 5>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
-                wg_barrier();                                           // BA2: a2 is in Hb, the output partials in red2
-                if (st1) {
-                    stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.a2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-                    if (hw == 0 && h == 0) {
-                        const bool live_h = (b0 + l31) < g.B;
-                        const float logit = red2[l31] + red2[32 + l31] + red2[64 + l31] + red2[96 + l31] + Binfo[OS3 + 1];
-                        const float p = 1.f / (1.f + P::exp_(-logit));
-                        const float u = live_h ? -g.invB * (ylab / (p + g.elbo_eps) - (1.f - ylab) / (1.f - p + g.elbo_eps)) : 0.f;
-                        const float dpre3 = u * p * (1.f - p);
-                        T* d3 = (T*)g.da3T + (b0 / KS) * (64 * E) + (l31 / E) * 32 * E + (l31 % E);
-                        const T d3h = P::cvt(dpre3 * sa);
-                        *d3 = d3h;
-                        if constexpr (NP == 2) d3[g.spl] = P::cvt(dpre3 * sa - (float)d3h);
-                    }
-                }
-                wg_barrier();                                           // BA3: dpre2 is in Ha
-                if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.da2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, sa);
-                if constexpr (XFH) { if (st2x) xstash_reload<P, 5, 9>(g.x, g.ldx, rowof, b0, g.B, (T*)g.xT, g.spl, g.Bp, tl); }
-                wg_barrier();                                           // BA4: dpre1 is in Hb
-                if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.da1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h, sa);
-            }
-            wg_barrier();                                               // BD1
-            // loss epilogue of the output layer (OFFL): x of the first round's tile is requested HERE, a phase early.  Requested at BD2
-            // by every CU at once (the tile has long left the L2: 16.8 MB from the Infinity Cache / HBM within a microsecond) the burst
-            // doubled the time of the first epilogue round AND of the chain's GEMM beside it (its weight loads queue behind the misses).
-            // per-iteration opaque copy of the lane id: keeps this block's 40-odd LDS / global addresses out of loop-invariant hoisting
-            // (hoisted to the tile loop's preheader they stay live across every phase and spill)
-            int lo_ = lane;
-            asm volatile("" : "+v"(lo_));
-            const int l31o = lo_ & 31, ho = lo_ >> 5;
-            const float* const xrow_o = g.x + rowof(l31o) * g.ldx + 4 * ho;
-            f32x4 xo[4], xnx[4];                                            // this round's x, the next round's (requested a round ahead)
-            if constexpr (OFFL) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) xo[gq] = reinterpret_cast<const F4U*>(xrow_o + 32 * hw + 8 * gq)->v;
-            }
-            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.d1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            wg_barrier();                                               // BD2
-            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.d2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            float rec_h = 0.f;
-            if constexpr (OFFL) {
-                // tile hw + 4 I of round I
-                const bool live = (b0 + l31o) < g.B;
-                const float invB_l = live ? g.invB : 0.f;                  // frames past B contribute nothing
-                const float* const xrow = xrow_o;
-#pragma unroll 1
-                for (int I = 0; I < 4; ++I) {                               // rolled: unrolled, the scheduler interleaves the rounds and the block spills
-                    const int t = hw + 4 * I;
-                    if (I < 3) {
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) xnx[gq] = reinterpret_cast<const F4U*>(xrow + 32 * (t + 4) + 8 * gq)->v;
-                    }
-                    R2_HSTAMP(21 + 2 * I);
-                    wg_barrier();                                       // RB0 .. RB3
-                    R2_HSTAMP(22 + 2 * I);
-#if R2_HPRIO
-                    __builtin_amdgcn_s_setprio(R2_HPRIO);
-#endif
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float a4[4], da4[4];
-                        get_raw4<P>(a4, U, LDU, 32 * t + 8 * gq + 4 * ho, l31o);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // recon term x / r - log(x + eps) + log r - 1 with r = exp(a) (models.py:122, utils.py:74): x e^{-a} + a is
-                            // summed here; the log(x + eps) terms were summed while the x tile sat in registers (lsum2) and the -1's are a
-                            // count -- 6 VALU instructions per element instead of 13 (this loop is what the output layer waits for)
-                            const float xe = xo[gq][j] * __builtin_amdgcn_exp2f(a4[j] * -1.44269504088896341f);
-                            rec_h += xe;
-                            rec_h += a4[j];
-                            da4[j] = fmaf(-xe, invB_l, invB_l);                  // d recon / d a = (1 - x / r) / B
-                        }
-                        typename P::Pack4 ph, pl;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { ph[j] = P::cvt(da4[j]); pl[j] = P::cvt(da4[j] - (float)ph[j]); }
-                        *reinterpret_cast<typename P::Pack4*>(U + l31o * LDU + 32 * t + 8 * gq + 4 * ho) = ph;
-                        *reinterpret_cast<typename P::Pack4*>(U + Pl<P>::lds + l31o * LDU + 32 * t + 8 * gq + 4 * ho) = pl;
-                    }
-#if R2_HPRIO
-                    __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) xo[gq] = xnx[gq];
-                }
-                rec_h = live ? rec_h - 64.f : 0.f;                          // the -1 of each of this lane's 64 elements; frames past B contribute nothing
-            }
-            wg_barrier();                                               // BDA
-            for (int t = hw; t < NT_OUT; t += 4) if (st1) stash_tile<P>(U, LDU, 32 * t, (T*)g.daT + (int64_t)t * 32 * g.Bp, g.spl, b0, l31, h);
-            const bool more = it + 1 < ntl;
-            const int ntile = tile + (int)gridDim.x;
-            if (more && gather) fill_rows(ntile, (it + 1) & 1);
-            wg_barrier();                                               // BDD2: da consumed, U is free
-            if (MODE == 1) {                                             // forward only: stage the next tile's x right away
-                if (more) {
-                    const int64_t fb0 = (int64_t)ntile * TB;
-                    const int64_t* const fsrc = rowsrc + ((it + 1) & 1) * TB;
-                    auto frowof = [&](int r) -> int64_t {
-                        if (gather) return fsrc[r];
-                        const int64_t br = fb0 + r;
-                        return br < g.B ? br : g.B - 1;
-                    };
-                    if (g.fastx && (fb0 + TB) <= g.B) { tile513_issue(g.x, frowof, xv, tl); tile513_commit<P, XP, XFH>(xv, U, LDU, tl); }
-                    else load_rows_to_lds<P, XFH>(g.x, g.ldx, XD, XP, fb0, g.B, U, LDU, tl, frowof);
-                }
-                wg_barrier();                                           // BRED'
-                continue;
-            }
-            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dd2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            // next tile's x: requested now, committed three phases later
-            const int64_t nb0 = (int64_t)ntile * TB;
-            const bool nfull = more && (nb0 + TB) <= g.B;
-            const int64_t* const nsrc = rowsrc + ((it + 1) & 1) * TB;
-            auto nrowof = [&](int r) -> int64_t {
-                if (gather) return nsrc[r];
-                const int64_t br = nb0 + r;
-                return br < g.B ? br : g.B - 1;
-            };
-            x_in_regs = more && g.fastx && nfull;
-            if (x_in_regs) tile513_issue(g.x, nrowof, xv, tl);
-            else {                                                         // a full redefinition: without it the register image of the PREVIOUS tile
-#pragma unroll                                                             // stays live around the whole loop (conditional definition) -- 68 registers
-                for (int i = 0; i < NQ513; ++i) xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            wg_barrier();                                               // BDD1
-            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dd1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            wg_barrier();                                               // BDML
-            if constexpr (YP > 0 && Y513) {
-                // the next tile's labels: in flight from here to the next tile's BL1X (requested there, the 64 KB per CU take 4 us to
-                // arrive beside the weight stream and the chain waits for them)
-                y_in_regs = more && g.fasty && nfull;
-                if (y_in_regs) tile513_issue(g.y, nrowof, yv, tl);
-                else {
-#pragma unroll
-                    for (int i = 0; i < NQ513; ++i) yv[i] = f32x4{0.f, 0.f, 0.f, 0.f};     // full redefinition (see xv above)
-                }
-            }
-            if (hw == 0 && st1) stash_tile<P>(Zb, LDZ, 0, (T*)g.dmlvT, g.spl, b0, l31, h);
-            wg_barrier();                                               // BDH2
-            if (st1) stash_tile<P>(Hb, LDH, 32 * hw, (T*)g.dh2T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            wg_barrier();                                               // BDH1
-            if (st1) stash_tile<P>(Ha, LDH, 32 * hw, (T*)g.dh1T + (int64_t)hw * 32 * g.Bp, g.spl, b0, l31, h);
-            if constexpr (OFFL) {                                          // log terms of the tile(s) whose x this thread has committed so far
-                const float rs = wave_sum(rec_h), ls = wave_sum(lsum2);
-                if (lane == 0) { red[8 + hw] = rs; red[12 + hw] = ls; }
-                lsum2 = 0.f;
-            }
-            if constexpr (INFO) { if (hw == 0) { const float bcs = wave_sum(bce_c); if (lane == 0) red2[128] = bcs; } }
-            if (more) {
-                if (x_in_regs) {
-                    tile513_commit<P, XP, XFH>(xv, U, LDU, tl);
-                    if constexpr (OFFL) lsum2 = tile513_log2sum(xv, g.elbo_eps, tl);      // counted with the next tile's sums
-                } else load_rows_to_lds<P, XFH>(g.x, g.ldx, XD, XP, nb0, g.B, U, LDU, tl, nrowof, nullptr, OFFL ? &lsum2 : nullptr, g.elbo_eps);
-            }
-            wg_barrier();                                               // BRED
-        }
+#include "rows_helper.inc"
     }
 }
 
+#undef ROWS_XP
+#undef ROWS_CHAIN_WAVES
 template <typename P, int YP, bool YENC, int MODE, bool INFO = false, bool DEFER = false>
 static int launch_rows2_m(const RowsArgs& a, int grid, hipStream_t s) {
     const size_t lds = Lds2<P, INFO>::bytes;
