@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libdvae_hip.so")
 DIAG_LIB = os.path.join(HERE, "libdvae_hip_diag.so")     # --diag: product kernels + the measured-slower alternates (csrc/common.hpp: DVAE_DIAG)
 ARCH = "gfx950"
 # per-file flags (the reason stands at the top of the file named)
-FILE_FLAGS = {"mcem_mstep.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"mcem_mstep.hip": ["-fno-slp-vectorize"], "train_rows3.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -401,6 +401,9 @@ __device__ __forceinline__ void stash_from_lds(const typename P::T* U, int ldu, 
 // train_rows2.hip: the 8-wave chain + helper rows kernel (M1 / M2, bf16 and bf16x3 operand policies)
 int launch_rows2(int precision, int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s);
 bool rows2_supported(int precision, int model);
+// train_rows3.hip: 8 GEMM waves (16 x 16 x 32 MFMA, N-split) + 4 helper waves: M1 / M2 train step under the split-bf16 policy
+int launch_rows3(int model, int y_dim, const RowsArgs& a, int grid, hipStream_t s);
+bool rows3_supported(int precision, int model);
 
 }  // namespace fused
 }  // namespace dvae

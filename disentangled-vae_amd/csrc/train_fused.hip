@@ -1541,8 +1541,12 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.ye = p.model == DVAE_MODEL_M2 ? L.yp : 0;
     L.info = p.model == DVAE_MODEL_M2_INFO;
     L.yd = L.yp;
-    L.ld1 = XP + L.ye;
-    L.ld3 = ZD + L.yd;
+    // K extents of the weight copies: 16-deep k-steps (x 513 -> 528, labels -> multiple of 16, z 16), or -- rows3 kernel, 32-deep
+    // k-steps on 16 x 16 x 32 MFMA tiles -- x -> 544, labels -> multiple of 32, z -> 32
+    const bool r3 = p.rows_kernel == 3;
+    const int yk = p.y_dim == 0 ? 0 : (r3 ? (p.y_dim + 31) / 32 * 32 : L.yp);
+    L.ld1 = (r3 ? 544 : XP) + (L.ye ? yk : 0);
+    L.ld3 = (r3 ? 32 : ZD) + (L.yd ? yk : 0);
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t r = o; o += al(n, 128); return r; };
     L.W1s = take((int64_t)HD * L.ld1); L.W2s = take(HD * HD); L.Wmvs = take(32 * HD); L.W3s = take((int64_t)HD * L.ld3);
@@ -1663,8 +1667,8 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     // per 8192 frames under bf16x3, 31 vs 33 us under bf16); DVAE_ROWS=1 forces the 4-wave kernel
     const char* rk = getenv("DVAE_ROWS");
     int want = 2;
-    if (rk && (atoi(rk) == 1 || atoi(rk) == 2)) want = atoi(rk);
-    plan->rows_kernel = (want == 2 && rows2_supported(precision, model)) ? 2 : 1;
+    if (rk && (atoi(rk) == 1 || atoi(rk) == 2 || atoi(rk) == 3)) want = atoi(rk);
+    plan->rows_kernel = (want == 3 && rows3_supported(precision, model)) ? 3 : ((want >= 2 && rows2_supported(precision, model)) ? 2 : 1);
     if (!kDiagBuild && plan->rows_kernel == 1 && is_bf(precision)) {
         set_error("train_plan: DVAE_ROWS=1 (the 4-wave rows kernel) under the bf16 policies needs the diagnostic build (build.py --diag)");
         return DVAE_E_UNSUPPORTED;
@@ -1674,7 +1678,7 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
         return DVAE_E_UNSUPPORTED;
     }
     // workgroups resident at once: the 8-wave kernel holds one per CU; the 4-wave bf16 kernel two.  Beyond that: persistent tile loop
-    const int64_t maxg = plan->rows_kernel == 2 ? 256 : 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
+    const int64_t maxg = plan->rows_kernel >= 2 ? 256 : 256 * (precision == DVAE_PREC_BF16 ? 2 : 1);
     plan->rows_grid = ntiles < maxg ? ntiles : maxg;
     int ks = ksplit_hint;
     // bf16: 8 slices up to 8192 frames (more slices = more slabs for the apply pass to sum); 12 beyond: 80 groups x 12 = 960
@@ -1859,7 +1863,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     td[2].st_ld = HD; td[4].st_ld = 32; td[6].st_ld = 32; td[8].st_ld = HD; td[10].st_ld = HD; td[12].st_ld = NO;
     td[0].sf_off = L.W1s; td[0].sf_nt = 4; td[0].sf_split = XD; td[0].sf_gap = XP - XD;
     // the 8-wave rows kernel under the split-bf16 policy multiplies the x block of layer 1 (and of the M2_info classifier) in split fp16
-    const int f16c = (p->precision == DVAE_PREC_BF16X3 && p->rows_kernel == 2 && PolX3v2::XF16) ? XD : 0;
+    const int f16c = (p->precision == DVAE_PREC_BF16X3 && p->rows_kernel >= 2 && PolX3v2::XF16) ? XD : 0;
     td[0].sf_f16_cols = f16c;
     td[2].sf_off = L.W2s; td[2].sf_nt = 4; td[2].st_off = L.W2t; td[2].st_nt = 4; td[2].st_cmax = HD;
     td[4].sf_off = L.Wmvs; td[4].sf_nt = 1; td[4].st_off = L.Wmvt; td[4].st_nt = 4; td[4].st_cmax = HD;
@@ -1867,6 +1871,18 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     td[8].sf_off = L.W3s; td[8].sf_nt = 4; td[8].st_off = L.W3zt; td[8].st_nt = 1; td[8].st_cmax = ZD;
     td[10].sf_off = L.W4s; td[10].sf_nt = 4; td[10].st_off = L.W4t; td[10].st_nt = 4; td[10].st_cmax = HD;
     td[12].sf_off = L.W5s; td[12].sf_nt = NT_OUT; td[12].st_off = L.W5t; td[12].st_nt = 4; td[12].st_cmax = HD;
+    if (p->rows_kernel == 3) {
+        // rows3 kernel: 16-row tiles / 32-deep k-steps (apply_types.hpp: kind16); the heads' rows interleaved (rowmap), the backward-z
+        // matrix's rows likewise (trowmap)
+        for (int i = 0; i < 14; ++i) td[i].kind16 = 1;
+        td[0].sf_nt = 8; td[0].sf_gap = 544 - XD;
+        td[2].sf_nt = 8; td[2].st_nt = 8;
+        td[4].sf_nt = 2; td[4].rowmap = 1; td[4].st_nt = 8;
+        td[6].sf_nt = 2; td[6].rowmap = 2; td[6].sf_roff = 0; td[6].st_nt = 8;
+        td[8].sf_nt = 8; td[8].sf_split = ZD; td[8].sf_gap = 32 - ZD; td[8].st_nt = 2; td[8].trowmap = 1;
+        td[10].sf_nt = 8; td[10].st_nt = 8;
+        td[12].sf_nt = NO / 16; td[12].st_nt = 8;
+    }
     if (L.info) {
         td[14].sf_off = L.Wc1s; td[14].sf_nt = 4; td[14].sf_ld = XP; td[14].sf_split = XD; td[14].sf_gap = XP - XD; td[14].sf_f16_cols = f16c;
         td[16].sf_off = L.Wc2s; td[16].sf_nt = 4; td[16].sf_ld = HD; td[16].st_off = L.Wc2t; td[16].st_nt = 4; td[16].st_ld = HD; td[16].st_cmax = HD;
@@ -2164,7 +2180,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     // B = 262 144: 139.3 -> 143.2 M frames/s, B = 2^20: 137.0 -> 142.8 (x only: 143.3 / 139.1; profiles/r04_bigb_raw.txt).  Chosen
     // automatically from DVAE_RAW_AUTO_B frames on (131 072); DVAE_RAW_INPUTS=0 keeps the stash, =x / =1 force a variant at any size.
     const char* raw_env = getenv("DVAE_RAW_INPUTS");
-    const bool raw_possible = plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && a.rows == nullptr &&
+    const bool raw_possible = plan->rows_kernel >= 2 && rows2_supported(plan->precision, plan->model) && a.rows == nullptr &&
                               wgrad_form(getenv("DVAE_WGRAD")) == 4 && g_mode.mode != 1;
     int64_t raw_auto_b = 131072;
     { const char* e = getenv("DVAE_RAW_AUTO_B"); if (e) raw_auto_b = atoll(e); }
@@ -2182,7 +2198,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         a.ylo_dirty = (int*)(w + L.o_flags + 1024);
         a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);
         if (a.launch_id == 0) a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of a fresh workspace
-        a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model) && wg4 && !(raw_mask & 2) &&
+        a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel >= 2 && rows2_supported(plan->precision, plan->model) && wg4 && !(raw_mask & 2) &&
                       getenv("DVAE_YLO_ALWAYS") == nullptr) ? 1 : 0;
     }
     a.out_r = g_mode.out_r; a.out_mu = g_mode.out_mu; a.out_lv = g_mode.out_lv; a.out_z = g_mode.out_z; a.ld_r = g_mode.ld_r;
@@ -2201,7 +2217,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     int rc;
     {
         ProfScope ps(s, 0);
-        if (plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model)) {
+        if (plan->rows_kernel == 3 && rows3_supported(plan->precision, plan->model)) {
+            rc = launch_rows3(plan->model, plan->y_dim, a, grid, s);
+        } else if (plan->rows_kernel == 2 && rows2_supported(plan->precision, plan->model)) {
             rc = launch_rows2(plan->precision, plan->model, plan->y_dim, a, grid, s);
 #ifdef DVAE_DIAG
         } else if (x3) {

@@ -891,6 +891,36 @@ def test_label_lo_plane_on_demand_equals_always(y_dim, B, monkeypatch):
 
 
 @needs_diag
+@pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M1", 0, 8192), ("M2", 1, 1000), ("M2", 513, 33), ("M2", 513, 20000)])
+def test_twelve_wave_rows_kernel_vs_oracle(model, y_dim, B, monkeypatch):
+    """Diagnostic builds, opt-in (DVAE_ROWS=3; measured slower, csrc/train_rows3.hip): the layer chain N-split over eight GEMM waves on
+    16x16x32 MFMA tiles.  Same bars as the product kernel under the split-bf16 policy: losses 1e-5, every gradient tensor inside
+    x3_grad_bound; the plan names the kernel that ran."""
+    monkeypatch.setenv("DVAE_ROWS", "3")
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 11)
+    x, y, e = gu.make_batch(dims, B, 12)
+    out, grads, _ = _oracle_step(model, dims, params, x.astype(np.float64), None if y is None else y.astype(np.float64), e.astype(np.float64))
+    tr = trainer.Trainer(model, dims, params, batch=B, precision="bf16x3")
+    assert tr.plan.rows_kernel == 3
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    for _ in range(2):                                              # (the second step: the 16-row-tile weight copies after an Adam refresh)
+        losses = tr.step(t(x), t(y), t(e)).cpu().numpy()
+        assert np.all(np.isfinite(losses))
+        if _ == 0:
+            np.testing.assert_allclose(losses, [out["loss"], out["recon"], out["kl"]], rtol=1e-5)
+            g = tr.grads_numpy()
+            for k in grads:
+                assert _relmax(g[k], np.asarray(grads[k], np.float64).reshape(g[k].shape)) < x3_grad_bound(k), k
+    monkeypatch.setenv("DVAE_ROWS", "2")
+    tr2 = trainer.Trainer(model, dims, params, batch=B, precision="bf16x3")
+    assert tr2.plan.rows_kernel == 2
+    for _ in range(2):
+        l2 = tr2.step(t(x), t(y), t(e)).cpu().numpy()
+    np.testing.assert_allclose(losses, l2, rtol=2e-6)               # second-step losses: both kernels' parameter updates agree
+
+
+@needs_diag
 @pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M2", 513, 3000, "fp32"), ("M2", 1, 5000, "bf16x3"),
                                                        ("M1", 0, 8192, "bf16"), ("M2_info", 1, 8192, "bf16x3"), ("M2", 513, 20000, "bf16x3")])
 def test_optimizer_step_folded_into_the_weight_gradient_launch_equals_its_own_launch(model, y_dim, B, precision, monkeypatch):
