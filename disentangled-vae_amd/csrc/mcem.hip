@@ -14,32 +14,13 @@
 //   * the per-frame likelihood sum over 513 bins is accumulated in double.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include "fused_tiles.hpp"
+#include "mcem_types.hpp"
 #include "../../include/dvae_mcem.h"
 
 namespace dvae {
 namespace fused {
-
-struct MhArgs {
-    const float* Z0;      // (16, N)            initial latents                       [MH mode]
-    const float* y;       // (ydim, N) or null
-    const float* g;       // (N)
-    const float* Vb;      // (513, N)
-    const float* X2;      // (513, N)
-    const float* noise;   // (nit, 16, N)
-    const float* logu;    // (nit, N)
-    float* Zs;            // (N, R, 16)  MH mode: written (R = nit - burnin); decode mode: read
-    float* Vs;            // (R, 513, N) or null
-    float* accp;          // (nit, N) log acceptance ratios, optional
-    unsigned char* accd;  // (nit, N) decisions, optional
-    int ydim, nit, burnin, R, ntiles;
-    int64_t N;
-    float sd;
-    const void* wcopy; int64_t wcopy_bytes;
-    int64_t oW3, oW4, oW5;     // element offsets of the fragment-major copies
-    unsigned wpl;              // bytes between the hi and lo planes of the copies (split-bf16 policy)
-    const float* bias;         // b3[128] b4[128] b5[544]
-};
 
 template <typename T> struct MhLds {
     static constexpr int per16 = 16 / (int)sizeof(T);
@@ -613,7 +594,11 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
     const bool bf = plan->precision == DVAE_PREC_BF16;
     a.wpl = plan->precision == DVAE_PREC_BF16X3 ? (unsigned)(L.elems * 2) : 0u;
-    if (plan->precision == DVAE_PREC_BF16X3) {       // split bf16: streaming, like the fp32 chain
+    if (plan->precision == DVAE_PREC_BF16X3) {
+        // split bf16: the weight-stationary 8-wave chain (mcem_resident.hip) for label rows 0 / 1..16; DVAE_MCEM_CHAIN=stream (and the 513-row
+        // labels): the streaming kernel
+        static const bool stream_only = [] { const char* e = getenv("DVAE_MCEM_CHAIN"); return e && !strcmp(e, "stream"); }();
+        if (!stream_only && resident_chain_supported(plan->precision, L.yp) && (int64_t)XD * a.N * 4 < ((int64_t)1 << 31) && (int64_t)a.nit * ZD * a.N * 4 < ((int64_t)1 << 31)) return launch_resident_chain(L.yp, a, s);
         if (L.yp == 0) return launch_mh<PolX3M<0>, 0, 0>(a, s);
         if (L.yp == 16) return launch_mh<PolX3M<16>, 16, 0>(a, s);
         if (L.yp == 528) return launch_mh<PolX3M<528>, 528, 0>(a, s);

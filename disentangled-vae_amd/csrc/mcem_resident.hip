@@ -1,0 +1,446 @@
+// Metropolis-Hastings chain of the MCEM E-step, WEIGHT-STATIONARY form (round 4): sample_posterior + compute_Vs of
+// packages/models/mcem.py:207-290 for the split-bf16 policy, label rows 0 / 1..16.
+//
+// Why: the chain applies ONE small decoder ([16+y]-128-128-513) to the same 32 frames 41 times per E-step.  The streaming kernel
+// (mcem.hip) pulls the decoder's fragment copies (336 KB with both bf16 planes) plus the tile's X2 / Vb rows (131 KB) from L2 in every
+// chain step: 9.3 us per step at one workgroup per CU, bound by that stream, not by the 8 MMAC of MFMA work (1.7 us at peak).  A CU's
+// register file holds 512 KB.  Here ONE 256-thread workgroup per CU -- one wave per SIMD, all 512 registers of the lane (256 VGPRs + 256
+// AGPRs: MFMA reads its A operand from either) -- keeps the whole decoder in registers for the launch and the tile's X2 / Vb on chip for
+// the chain:
+//   * output layer (513 x 128, both planes, 262 KB): wave w owns bins 128 w .. 128 w + 127 as four 32-row tiles: 256 registers of
+//     resident fragments per lane;
+//   * bin 512 (the 17th row tile would hold this one row): its pre-activation is a 128-term dot product with h2; every wave adds the
+//     terms of the h2 features it has just produced (fp32, in the layer-2 epilogue), one LDS exchange, wave 3 finishes it;
+//   * layers 1 and 2: wave w owns features 32 w .. 32 w + 31 (64 + 8 registers of resident fragments);
+//   * the label part of layer 1 (constant along the chain) is a per-tile fp32 table in LDS; the tile's X2 sits in LDS in the order the
+//     epilogue reads it (wave-private, conflict-free), its Vb in 64 registers per lane.
+// Nothing but the draws (noise, logu) and the kept samples crosses the CU boundary inside the chain.  Per chain step: 4 workgroup barriers
+// (latents -> h1 -> h2 -> per-frame likelihood), exactly the phases of the streaming kernel and the same arithmetic per element (hardware
+// exp2 / log2 / rcp, likelihood sums in double); bin 512 is summed in fp32 instead of on split planes.
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "fused_tiles.hpp"
+#include "mcem_types.hpp"
+#include "../../include/dvae_mcem.h"
+
+namespace dvae {
+namespace fused {
+
+struct PolX3C : PolX3 {};
+constexpr int C8_LDH = HD + 8, C8_LDZ = 32 + 8, C8_LDC = HD + 4;
+constexpr int C8_PLANE = TB * (2 * C8_LDH + C8_LDZ);                      // elements of one operand plane: h1, h2, latents
+template <> struct Pl<PolX3C> { static constexpr int lds = C8_PLANE; };
+
+constexpr size_t C8_O_X2 = (size_t)C8_PLANE * 2 * sizeof(__bf16);
+constexpr size_t C8_O_VB = C8_O_X2 + (size_t)16 * 16 * 64 * sizeof(float);        // Vb of each wave's output tiles 2 and 3 (tiles 0, 1: registers)
+constexpr size_t C8_O_C1 = C8_O_VB + (size_t)8 * 16 * 64 * sizeof(float);
+constexpr size_t C8_O_BIAS = C8_O_C1 + (size_t)TB * C8_LDC * sizeof(float);
+constexpr size_t C8_O_W512 = C8_O_BIAS + (size_t)(2 * HD + NO) * sizeof(float);
+constexpr size_t C8_O_P512 = C8_O_W512 + (size_t)HD * sizeof(float);
+constexpr size_t C8_O_RED = C8_O_P512 + (size_t)4 * TB * sizeof(float);
+constexpr size_t C8_LDS = C8_O_RED + (size_t)4 * TB * sizeof(double);
+static_assert(C8_O_RED % 8 == 0 && C8_LDS <= 160 * 1024, "resident chain: LDS layout");
+
+// acc = W(resident fragments, hi / lo planes) * act^T over NSTEPS k-steps of 16, the weight operand read straight from ACCUMULATION registers.
+// hipcc never assigns an AGPR to an MFMA source by itself (it parks the fragments there and copies them to VGPRs in front of every MFMA: 340
+// v_accvgpr_read per chain step), so the MFMAs of the output layer are written out: "a" pins a fragment to the AGPR file for its whole life
+// (the buffer load that defines it writes the AGPR directly).  The compiler does not see into the statement: the chain starts from the
+// inline constant 0 (no VALU-written SrcC), every MFMA accumulates into the one before it (same opcode, back to back), and the s_nops behind
+// the last one cover the longest XDL-write -> VALU-read distance (19 wait states) before anything outside may touch `acc`.
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+
+// between(k-step i, j): independent work placed in program order behind the j-th MFMA of the k-step -- a wave issues in order and every MFMA of
+// the chain waits for the one before it (32 clocks), so whatever should overlap with the matrix pipe has to sit BETWEEN the MFMAs (here: the
+// likelihood terms of the previous tile, one bin behind each of the first two MFMAs, the next bins' LDS reads behind the third).
+// `acc` comes in holding the bias (read from LDS straight into the accumulator registers): no bias add per bin, no VALU-written SrcC.
+template <typename P, int NSTEPS, int NAG, typename Between>
+__device__ __forceinline__ void gemm_resident_agpr(f32x16& acc, const typename P::Frag (&w)[NSTEPS][2], const typename P::T* brow, Between&& between) {
+    typedef typename P::Frag Frag;
+    constexpr int STR = 2 * P::E;
+    constexpr int BD = NSTEPS < 2 ? NSTEPS : 2;
+    Frag bq[BD][2];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) bloadp<P>(bq[i], brow + i * STR);
+    // one MFMA of the chain; LAST carries the s_nops; AG: the weight fragment lives in an AGPR
+    auto mm = [&](auto last, auto ag, const Frag& a, const Frag& b) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last)::value, AG = decltype(ag)::value;
+        if constexpr (LAST) {
+            if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+        } else {
+            if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        }
+    };
+    sfor<0, NSTEPS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        typedef std::integral_constant<bool, (i < NAG)> Ag;
+        typedef std::integral_constant<bool, false> F;
+        mm(F{}, Ag{}, w[i][1], bq[i % BD][0]);
+        between(ic, std::integral_constant<int, 0>{});
+        mm(F{}, Ag{}, w[i][0], bq[i % BD][1]);
+        between(ic, std::integral_constant<int, 1>{});
+        mm(std::integral_constant<bool, i + 1 == NSTEPS>{}, Ag{}, w[i][0], bq[i % BD][0]);
+        if constexpr (i + BD < NSTEPS) bloadp<P>(bq[i % BD], brow + (i + BD) * STR);
+        between(ic, std::integral_constant<int, 2>{});
+    });
+}
+
+template <int YP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mcem_resident_kernel(const MhArgs g) {
+    typedef PolX3C P;
+    typedef __bf16 T;
+    typedef P::Frag Frag;
+    constexpr int LDH = C8_LDH, LDZ = C8_LDZ, LDC = C8_LDC;
+    constexpr int OB4 = HD, OB5 = 2 * HD;
+    constexpr int NTW = 4;                                                 // output tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const Ha = reinterpret_cast<T*>(smem);
+    T* const Hb = Ha + TB * LDH;
+    T* const Zb = Hb + TB * LDH;
+    float* const X2s = reinterpret_cast<float*>(smem + C8_O_X2);          // [out tile 0..15][r 0..15][lane]: this lane's bins of its wave's tiles
+    float* const Vbs = reinterpret_cast<float*>(smem + C8_O_VB);          // [wave][tile 2..3][r][lane]
+    float* const c1s = reinterpret_cast<float*>(smem + C8_O_C1);          // [frame][LDC]: b3 + W3[:, 16:] y
+    float* const Bias = reinterpret_cast<float*>(smem + C8_O_BIAS);
+    float* const w512s = reinterpret_cast<float*>(smem + C8_O_W512);      // row 512 of the output layer, fp32 (hi + lo)
+    float* const p512 = reinterpret_cast<float*>(smem + C8_O_P512);       // [wave][frame]: partial pre-activation of bin 512
+    double* const red = reinterpret_cast<double*>(smem + C8_O_RED);       // [wave][frame]: partial likelihood sums
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int l31 = lane & 31, h = lane >> 5;                             // the lane is the frame, h the k half / feature half
+    const int fb = 32 * wave_u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
+    auto ld16 = [&](unsigned byteoff) __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)byteoff, 0, 0);
+        return __builtin_bit_cast(Frag, v);
+    };
+
+    // ---- resident weight fragments (once per launch); copies: [k-step of 16][32-row tile][lane][8] ----
+    Frag w3zR[1][2], w4R[HD / 16][2], w5R[NTW][HD / 16][2];
+    {
+        const unsigned o3 = (unsigned)(g.oW3 * 2) + (unsigned)((wave_u * 64 + lane) * 16);      // k-step 0: the 16 latent columns
+        w3zR[0][0] = ld16(o3);
+        w3zR[0][1] = ld16(o3 + g.wpl);
+    }
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+        const unsigned o4 = (unsigned)(g.oW4 * 2) + (unsigned)(((ks * 4 + wave_u) * 64 + lane) * 16);
+        w4R[ks][0] = ld16(o4);
+        w4R[ks][1] = ld16(o4 + g.wpl);
+    }
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            const unsigned o5 = (unsigned)(g.oW5 * 2) + (unsigned)(((ks * NT_OUT + NTW * wave_u + tt) * 64 + lane) * 16);
+            w5R[tt][ks][0] = ld16(o5);
+            w5R[tt][ks][1] = ld16(o5 + g.wpl);
+        }
+    }
+    for (int i = tid; i < 2 * HD + NO; i += 256) Bias[i] = g.bias[i];
+    if (tid < HD) {                                                        // row 512 = tile 16, row 0 of the tile: lane' = (k half) * 32
+        const int k = tid;
+        const int64_t e = g.oW5 + ((int64_t)((k >> 4) * NT_OUT + 16) * 64 + ((k >> 3) & 1) * 32) * 8 + (k & 7);
+        const __bf16* const wc = reinterpret_cast<const __bf16*>(g.wcopy);
+        const __bf16 lo = *reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
+        w512s[k] = (float)wc[e] + (float)lo;
+    }
+    __syncthreads();
+    const float b512 = Bias[OB5 + 512];
+    const T* const Zbr = Zb + l31 * LDZ + h * 8;
+    const T* const Har = Ha + l31 * LDH + h * 8;
+    const T* const Hbr = Hb + l31 * LDH + h * 8;
+
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        const int64_t n0 = (int64_t)tile * TB;
+        const bool live = n0 + l31 < g.N;
+        const int64_t nf = live ? n0 + l31 : g.N - 1;                      // clamped frame index of this lane
+        const float g_n = g.g ? g.g[nf] : 1.f;
+
+        // ---- per tile: label part of decoder layer 1 (fp32, constant along the chain), X2 -> LDS, Vb -> registers ----
+        {
+            const int f = tid & (HD - 1), fg = tid >> 7;                   // feature, group of 16 frames
+            float wy[16];
+            if constexpr (YP > 0) {
+                const __bf16* const wc = reinterpret_cast<const __bf16*>(g.wcopy);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {                             // W3[f][16 + j]: k-step 1, k half j >> 3
+                    const int64_t e = g.oW3 + ((int64_t)(1 * 4 + (f >> 5)) * 64 + (j >> 3) * 32 + (f & 31)) * 8 + (j & 7);
+                    const __bf16 lo = *reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
+                    wy[j] = (float)wc[e] + (float)lo;
+                }
+            }
+            const float b3 = Bias[f];
+            for (int fr = 16 * fg; fr < 16 * fg + 16; ++fr) {
+                float c = b3;
+                if constexpr (YP > 0) {
+                    const bool in = n0 + fr < g.N;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float yv = (j < g.ydim && in) ? g.y[(int64_t)j * g.N + n0 + fr] : 0.f;
+                        c = fmaf(wy[j], yv, c);
+                    }
+                }
+                c1s[fr * LDC + f] = c;
+            }
+        }
+        // (F, N) matrices are addressed through buffer descriptors: bin 32 t + feat_of(r, h) of frame nf = ONE per-lane byte offset (bin 4 h)
+        // plus a wave-uniform offset -- with 64-bit pointers hipcc keeps the 64 addresses of a lane live across the chain (128 registers)
+        const int fn_bytes = (int)((int64_t)XD * g.N * 4);                 // < 2^31: checked by the launcher
+        const int voff = (int)(((int64_t)(4 * h) * g.N + nf) * 4);
+        const unsigned rowb = (unsigned)g.N * 4u;
+        auto soff = [&](int t, int r) __attribute__((always_inline)) { return (int)((unsigned)(32 * t + (r & 3) + 8 * (r >> 2)) * rowb); };
+        float vbR[2][16];
+        float x2_512 = 0.f, vb_512 = 0.f;
+        if (g.X2) {
+            const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X2), 0, fn_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Vb), 0, fn_bytes, 0x00020000);
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt) {
+                const int t = NTW * wave_u + tt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    X2s[(t * 16 + r) * 64 + lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, soff(t, r), 0));
+                    const float vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vb, voff, soff(t, r), 0));
+                    if (tt < 2) vbR[tt][r] = vb; else Vbs[((wave_u * 2 + tt - 2) * 16 + r) * 64 + lane] = vb;
+                }
+            }
+            if (wave_u == 3) { x2_512 = g.X2[(int64_t)512 * g.N + nf]; vb_512 = g.Vb[(int64_t)512 * g.N + nf]; }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vbR[tt][r] = 0.f;
+            }
+        }
+
+        float z[8], zp[8];
+        float prior_cur = 0.f;
+        double ll_cur = 0.0;
+        if (wave == 0 && g.nit > 0) {
+            const __amdgpu_buffer_rsrc_t rs_z0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Z0), 0, (int)((int64_t)ZD * g.N * 4), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                z[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z0, voff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * rowb), 0));
+        }
+
+        // one decoder pass over the latents in Zb: EPI_BEGIN(tt) / EPI(tt, tile t, r, pre-activation incl. bias) / EPI_END(tt) for this wave's output
+        // tiles (tt, r: compile-time constants), EPI512(pre-activation) on wave 3; ends BEHIND the output layer (no trailing barrier)
+        auto pass = [&](auto&& epi_begin, auto&& epi, auto&& epi_end, auto&& epi512) __attribute__((always_inline)) {
+            f32x16 acc;
+            float v[16], bv[16];
+            // layer 1: [z | y] -> h1
+            zero_acc<P>(acc);
+            gemm_resident_p<P, 1>(acc, w3zR, Zbr);
+            bias16(c1s + l31 * LDC, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(v, Ha, LDH, fb, l31, h);
+            __syncthreads();                                               // B1
+            // layer 2: h1 -> h2, and this wave's 32 terms of bin 512's pre-activation
+            zero_acc<P>(acc);
+            gemm_resident_p<P, HD / 16>(acc, w4R, Har);
+            bias16(Bias + OB4, fb, h, bv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
+            put_lds<P>(v, Hb, LDH, fb, l31, h);
+            {
+                bias16(w512s, fb, h, bv);
+                float p = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p = fmaf(v[r], bv[r], p);
+                p += __shfl_xor(p, 32, 64);
+                if (h == 0) p512[wave * TB + l31] = p;
+            }
+            __syncthreads();                                               // B2
+            // output layer: four resident 32-row tiles per wave; the epilogue of tile tt (two bins per k-step) runs between the MFMAs of tile tt + 1.
+            // 240 of the 256 AGPRs hold fragments (tiles 0-2 whole, 6 of tile 3's 8 k-steps); the rest of tile 3 sits in VGPRs
+            f32x16 accn;
+            auto bias_into = [&](f32x16& dst, int t) __attribute__((always_inline)) {
+                bias16(Bias + OB5, 32 * t, h, bv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[r] = bv[r];
+            };
+            bias_into(acc, NTW * wave_u);
+            gemm_resident_agpr<P, HD / 16, HD / 16>(acc, w5R[0], Hbr, [](auto, auto) {});
+            sfor<0, NTW>([&](auto tc) {
+                constexpr int tt = decltype(tc)::value;
+                const int t = NTW * wave_u + tt;
+                f32x16& cur = (tt & 1) ? accn : acc;
+                f32x16& nxt = (tt & 1) ? acc : accn;
+                float xq[16], vq[16];                                      // X2 / Vb of the tile's bins, read one k-step ahead of their use
+                auto loadxv = [&](auto rc) __attribute__((always_inline)) {
+                    constexpr int r = decltype(rc)::value;
+                    xq[r] = X2s[(t * 16 + r) * 64 + lane];
+                    if constexpr (tt < 2) vq[r] = vbR[tt][r]; else vq[r] = Vbs[((wave_u * 2 + tt - 2) * 16 + r) * 64 + lane];
+                };
+                loadxv(std::integral_constant<int, 0>{});
+                loadxv(std::integral_constant<int, 1>{});
+                epi_begin(tc);
+                if constexpr (tt + 1 < NTW) {
+                    bias_into(nxt, t + 1);
+                    gemm_resident_agpr<P, HD / 16, (tt + 1 < NTW - 1 ? HD / 16 : 6)>(nxt, w5R[tt + 1], Hbr, [&](auto ic, auto jc) {
+                        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+                        if constexpr (j < 2) epi(tc, t, std::integral_constant<int, 2 * i + j>{}, cur[2 * i + j], xq[2 * i + j], vq[2 * i + j]);
+                        else if constexpr (i + 1 < HD / 16) {
+                            loadxv(std::integral_constant<int, 2 * i + 2>{});
+                            loadxv(std::integral_constant<int, 2 * i + 3>{});
+                        }
+                    });
+                } else {
+                    sfor<2, 16>([&](auto rc) { loadxv(rc); });
+                    sfor<0, 16>([&](auto rc) { constexpr int r = decltype(rc)::value; epi(tc, t, rc, cur[r], xq[r], vq[r]); });
+                }
+                epi_end(tc);
+            });
+            if (wave_u == 3) {
+                const float a = b512 + ((p512[l31] + p512[TB + l31]) + (p512[2 * TB + l31] + p512[3 * TB + l31]));
+                epi512(a);
+            }
+        };
+
+        const int mstart = g.nit > 0 ? -1 : 0;
+        const int mend = g.nit > 0 ? g.nit : 0;
+        // the draws of chain step m + 1 are requested while step m runs (wave 0): a load waited for on the spot costs 1-2 us per step
+        float nzv[8], lu = 0.f;
+        // (one per-lane offset + wave-uniform offsets again: eight 64-bit row addresses would be spilled and reloaded one by one, each behind
+        // its own s_waitcnt vmcnt(0) -- measured 4 us per chain step)
+        const __amdgpu_buffer_rsrc_t rs_nz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.noise), 0, (int)((int64_t)g.nit * ZD * g.N * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_lu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.logu), 0, (int)((int64_t)g.nit * g.N * 4), 0x00020000);
+        auto load_draws = [&](int m) __attribute__((always_inline)) {
+            if (m < g.nit) {
+                const unsigned mb = (unsigned)m * (unsigned)ZD * rowb;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    nzv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_nz, voff, (int)(mb + (unsigned)((r & 3) + 8 * (r >> 2)) * rowb), 0));
+                lu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lu, (int)(nf * 4), (int)((unsigned)m * rowb), 0));
+            }
+        };
+        if (wave == 0 && g.nit > 0) load_draws(0);
+        for (int m = mstart; m < mend; ++m) {
+            float prior_p = 0.f, lu_cur = 0.f;
+            if (wave == 0) {
+                if (m >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) zp[r] = z[r] + g.sd * nzv[r];                     // mcem.py:244
+                    lu_cur = lu;
+                    load_draws(m + 1);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) zp[r] = z[r];
+                }
+                float zv[16];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { zv[r] = zp[r]; zv[r + 8] = 0.f; prior_p += zp[r] * zp[r]; }
+                put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+                prior_p += __shfl_xor(prior_p, 32, 64);
+            }
+            __syncthreads();                                               // B0
+            double ll = 0.0;
+            float slog = 0.f, sdiv = 0.f;                                  // sums of log2(vx) and x2 / vx over one tile
+            pass(
+                [&](auto) { slog = 0.f; sdiv = 0.f; },
+                [&](auto, int, auto, float a, float x2, float vb) {
+                    const float vx = fmaf(g_n, P::exp_(a), vb);                                   // mcem.py:248-249
+                    slog += __builtin_amdgcn_logf(vx);                                            // mcem.py:252-253: log(vx) + x2 / vx
+                    sdiv = fmaf(x2, __builtin_amdgcn_rcpf(vx), sdiv);
+                },
+                [&](auto) { ll += (double)fmaf(slog, 0.693147180559945309f, sdiv); },
+                [&](float a) {
+                    const float vx = fmaf(g_n, P::exp_(a), vb_512);
+                    const float term = P::log_(vx) + P::div_(x2_512, vx);
+                    if (h == 0) ll += (double)term;
+                });
+            ll += __shfl_xor(ll, 32, 64);
+            if (h == 0) red[wave * TB + l31] = ll;
+            __syncthreads();                                               // B3
+            if (wave == 0) {
+                const double ll_p = red[l31] + red[TB + l31] + red[2 * TB + l31] + red[3 * TB + l31];
+                if (m < 0) {
+                    ll_cur = ll_p; prior_cur = prior_p;
+                } else {
+                    const float acc_prob = (float)(ll_cur - ll_p) + 0.5f * (prior_cur - prior_p);   // mcem.py:252-254
+                    const bool is_acc = lu_cur < acc_prob;                                           // mcem.py:257
+                    if (is_acc) {
+                        ll_cur = ll_p; prior_cur = prior_p;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) z[r] = zp[r];
+                    }
+                    if (live && h == 0) {
+                        if (g.accp) g.accp[(int64_t)m * g.N + nf] = acc_prob;
+                        if (g.accd) g.accd[(int64_t)m * g.N + nf] = is_acc ? 1 : 0;
+                    }
+                    if (m >= g.burnin && live) {                                                    // mcem.py:271-273
+                        float* dst = g.Zs + ((int64_t)nf * g.R + (m - g.burnin)) * ZD;
+                        *reinterpret_cast<f32x4*>(dst + 4 * h) = f32x4{z[0], z[1], z[2], z[3]};
+                        *reinterpret_cast<f32x4*>(dst + 8 + 4 * h) = f32x4{z[4], z[5], z[6], z[7]};
+                    }
+                }
+            }
+            // red / p512 / Zb are next written behind the barriers of the following pass
+        }
+
+        // ---- speech variances of the kept samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
+        if (g.Vs != nullptr) {
+            for (int r_s = 0; r_s < g.R; ++r_s) {
+                __syncthreads();
+                if (wave == 0) {
+                    const float* src = g.Zs + ((int64_t)nf * g.R + r_s) * ZD;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(src + 4 * h);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(src + 8 + 4 * h);
+                    float zv[16];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { zv[r] = s0[r]; zv[4 + r] = s1[r]; zv[8 + r] = 0.f; zv[12 + r] = 0.f; }
+                    put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+                }
+                __syncthreads();
+                float* const vs_r = g.Vs + (int64_t)r_s * XD * g.N;
+                const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(vs_r, 0, fn_bytes, 0x00020000);
+                pass(
+                    [](auto) {},
+                    [&](auto, int t, auto rc, float a, float, float) {
+                        constexpr int r = decltype(rc)::value;
+                        if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, P::exp_(a)), rs_vs, voff, soff(t, r), 0);
+                    },
+                    [](auto) {},
+                    [&](float a) { if (live && h == 0) vs_r[(int64_t)512 * g.N + nf] = P::exp_(a); });
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int YP>
+static int launch_resident_t(const MhArgs& a, hipStream_t s) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)mcem_resident_kernel<YP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C8_LDS);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(mcem_resident_kernel, %zu B LDS): %s", C8_LDS, hipGetErrorString(e)); return (int)e; }
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((mcem_resident_kernel<YP>), dim3(a.ntiles), dim3(256), C8_LDS, s, a);
+    DVAE_LAUNCH_OK("mcem_resident_kernel");
+    return 0;
+}
+
+bool resident_chain_supported(int precision, int yp) { return precision == DVAE_PREC_BF16X3 && (yp == 0 || yp == 16); }
+
+int launch_resident_chain(int yp, const MhArgs& a, hipStream_t s) {
+    if (a.wpl == 0) { set_error("mcem resident chain: split-bf16 weight copies only"); return DVAE_E_UNSUPPORTED; }
+    if ((int64_t)XD * a.N * 4 >= ((int64_t)1 << 31) || (int64_t)a.nit * ZD * a.N * 4 >= ((int64_t)1 << 31)) { set_error("mcem resident chain: (F, N) matrices of 2 GB and more are not addressed"); return DVAE_E_UNSUPPORTED; }
+    if (yp == 0) return launch_resident_t<0>(a, s);
+    if (yp == 16) return launch_resident_t<16>(a, s);
+    set_error("mcem resident chain: label rows 0 or 1..16 only");
+    return DVAE_E_UNSUPPORTED;
+}
+
+}  // namespace fused
+}  // namespace dvae
