@@ -518,7 +518,9 @@ __global__ __launch_bounds__(FT) void mstep_frames_kernel(const float* __restric
 }
 
 // (the register-resident form of this kernel, mstep_frames_reg_kernel, lives in mcem_mstep.hip: it is compiled without SLP vectorisation)
-namespace mstep { int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
+namespace mstep { int launch_w_reg(const float* X2, const float* Vs, int R, int64_t N, int U, const float* W, const float* H, const float* g, const float* Vb,
+                                  float* Wun, const int* seg_start, const int* seg_count, hipStream_t s);
+                  int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
                                        float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s); }
 
 // per utterance: W = Wun / norm (mcem.py:132), cost = mean over (R, F, N_u) of the tile partials
@@ -594,11 +596,13 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
     const bool bf = plan->precision == DVAE_PREC_BF16;
     a.wpl = plan->precision == DVAE_PREC_BF16X3 ? (unsigned)(L.elems * 2) : 0u;
+    // bf16 policies, label rows 0 / 1..16: the weight-stationary chain (mcem_resident.hip); DVAE_MCEM_CHAIN=stream, the 513-row labels and
+    // (F, N) matrices of 2 GB and more: the streaming kernels below
+    static const bool stream_only = [] { const char* e = getenv("DVAE_MCEM_CHAIN"); return e && !strcmp(e, "stream"); }();
+    if (!stream_only && resident_chain_supported(plan->precision, L.yp) && (int64_t)XD * a.N * 4 < ((int64_t)1 << 31) &&
+        (int64_t)a.nit * ZD * a.N * 4 < ((int64_t)1 << 31))
+        return launch_resident_chain(L.yp, a, s);
     if (plan->precision == DVAE_PREC_BF16X3) {
-        // split bf16: the weight-stationary 8-wave chain (mcem_resident.hip) for label rows 0 / 1..16; DVAE_MCEM_CHAIN=stream (and the 513-row
-        // labels): the streaming kernel
-        static const bool stream_only = [] { const char* e = getenv("DVAE_MCEM_CHAIN"); return e && !strcmp(e, "stream"); }();
-        if (!stream_only && resident_chain_supported(plan->precision, L.yp) && (int64_t)XD * a.N * 4 < ((int64_t)1 << 31) && (int64_t)a.nit * ZD * a.N * 4 < ((int64_t)1 << 31)) return launch_resident_chain(L.yp, a, s);
         if (L.yp == 0) return launch_mh<PolX3M<0>, 0, 0>(a, s);
         if (L.yp == 16) return launch_mh<PolX3M<16>, 16, 0>(a, s);
         if (L.yp == 528) return launch_mh<PolX3M<528>, 528, 0>(a, s);
@@ -707,11 +711,17 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     float* norms = (float*)(ws + o_norms);
     double* partial = (double*)(ws + o_partial);
     const int ntiles = (int)((N + 31) / 32);
-    hipLaunchKernelGGL(mstep_w_kernel, dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun, seg_start, seg_count);
-    DVAE_LAUNCH_OK("mstep_w_kernel");
-    // DVAE_MSTEP=3pass keeps the round-1 kernel (three reads of Vs); R > 10 samples always take it
+    // DVAE_MSTEP=3pass keeps the round-1 kernels (three reads of Vs, one wave-step of loads in flight in the W update); R > 10 samples and
+    // ranks other than 10 always take them
     const char* mk = getenv("DVAE_MSTEP");
     const bool reg_form = R <= 10 && K == 10 && (int64_t)R * XD * N * 4 < (int64_t)0x7fffffff && !(mk && strcmp(mk, "3pass") == 0);      // (rank 10: mcem.py / scripts/evaluate_ntcd_M2.py:66)
+    if (reg_form) {
+        const int rcw = mstep::launch_w_reg(X2, Vs, R, N, U, W, H, g, Vb, Wun, seg_start, seg_count, s);
+        if (rcw) return rcw;
+    } else {
+        hipLaunchKernelGGL(mstep_w_kernel, dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun, seg_start, seg_count);
+        DVAE_LAUNCH_OK("mstep_w_kernel");
+    }
     if (reg_form) {
         const int rcf = mstep::launch_frames_reg(X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, s);
         if (rcf) return rcf;

@@ -174,6 +174,82 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
 }
 
 
+// W update (mcem.py:107-111): num[k] = sum_n X2 sum_r Vx^-2 H[k,n], den[k] = sum_n sum_r Vx^-1 H[k,n], Wun = W sqrt(num / den), Vx = g Vs + Vb.
+// One WAVE per (bin f, utterance u), four bins per workgroup, 64 frames per step -- as mstep_w_kernel (mcem.hip), with what that kernel
+// lacks at batch scale (116 us for 164 MB, round 4): every load of a step (R sample variances, Vb, X2, g, K rows of H) is requested before
+// the first is used and the NEXT step's loads are in flight under this step's arithmetic (two register sets); buffer addressing with one
+// per-lane offset per matrix shape; the hardware reciprocal (rcp_pos above) instead of ten IEEE divisions per frame.
+template <int RR, int K>
+__global__ __launch_bounds__(256) void mstep_w_reg_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N,
+                                                          const float* __restrict__ W, const float* __restrict__ H, const float* __restrict__ g,
+                                                          const float* __restrict__ Vb, float* __restrict__ Wun,
+                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_count) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x * 4 + wave, u = blockIdx.y;
+    if (f >= XD) return;
+    const int64_t nbeg = seg_start ? seg_start[u] : 0, cnt = seg_count ? seg_count[u] : N, nend = nbeg + cnt;
+    const int64_t FN = (int64_t)XD * N;
+    const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, (int)((int64_t)R * FN * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, (int)(FN * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vb), 0, (int)(FN * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(H), 0, (int)((int64_t)K * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)(N * 4), 0x00020000);
+    const unsigned fnb = (unsigned)(FN * 4), nb = (unsigned)(N * 4);
+    struct Set { float vs[RR], vb, x2, gn, hk[K], m; };
+    auto ldf = [](__amdgpu_buffer_rsrc_t rs, int voff, unsigned soff) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)soff, 0));
+    };
+    auto load = [&](Set& q, int64_t c) __attribute__((always_inline)) {
+        const int64_t nn = nbeg + 64 * c + lane;
+        const bool lv = nn < nend;
+        const int64_t n = lv ? nn : nend - 1;                            // padding lanes read a valid column with weight 0
+        const int vfn = (int)(((int64_t)f * N + n) * 4), vn = (int)(n * 4);
+#pragma unroll
+        for (int r = 0; r < RR; ++r) q.vs[r] = ldf(rs_vs, vfn, (unsigned)(r < R ? r : 0) * fnb);
+        q.vb = ldf(rs_vb, vfn, 0); q.x2 = ldf(rs_x2, vfn, 0); q.gn = ldf(rs_g, vn, 0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) q.hk[k] = ldf(rs_h, vn, (unsigned)k * nb);
+        q.m = lv ? 1.f : 0.f;
+    };
+    float num[K], den[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { num[k] = 0.f; den[k] = 0.f; }
+    auto compute = [&](const Set& q) __attribute__((always_inline)) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            if (r < R) {
+                const float inv = rcp_pos(fmaf(q.gn, q.vs[r], q.vb));
+                a1 += inv; a2 = fmaf(inv, inv, a2);
+            }
+        }
+        const float p2 = q.x2 * a2 * q.m;
+        a1 *= q.m;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { num[k] = fmaf(p2, q.hk[k], num[k]); den[k] = fmaf(a1, q.hk[k], den[k]); }
+    };
+    const int64_t nch = (cnt + 63) / 64;
+    Set A, B;
+    if (nch > 0) load(A, 0);
+    for (int64_t c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) load(B, c + 1);
+        compute(A);
+        if (c + 1 < nch) {
+            if (c + 2 < nch) load(A, c + 2);
+            compute(B);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float a = wave_sum(num[k]), b = wave_sum(den[k]);
+        if (lane == k) {
+            const int64_t o = ((int64_t)u * XD + f) * K + k;
+            Wun[o] = W[o] * sqrtf(a / b);
+        }
+    }
+}
+
+
 namespace mstep {
 int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
@@ -188,6 +264,12 @@ int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K,
     }
     hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10>), dim3(nt16), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
     DVAE_LAUNCH_OK("mstep_frames_reg_kernel");
+    return 0;
+}
+int launch_w_reg(const float* X2, const float* Vs, int R, int64_t N, int U, const float* W, const float* H, const float* g, const float* Vb,
+                 float* Wun, const int* seg_start, const int* seg_count, hipStream_t s) {
+    hipLaunchKernelGGL((mstep_w_reg_kernel<10, 10>), dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, W, H, g, Vb, Wun, seg_start, seg_count);
+    DVAE_LAUNCH_OK("mstep_w_reg_kernel");
     return 0;
 }
 }  // namespace mstep

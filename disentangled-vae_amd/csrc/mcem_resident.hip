@@ -27,10 +27,12 @@
 namespace dvae {
 namespace fused {
 
-struct PolX3C : PolX3 {};
+struct PolX3C : PolX3 {};            // split bf16: two operand planes, three MFMAs per product
+struct PolB1C : PolBF16 {};          // one bf16 per operand (opt-in fast policy)
 constexpr int C8_LDH = HD + 8, C8_LDZ = 32 + 8, C8_LDC = HD + 4;
 constexpr int C8_PLANE = TB * (2 * C8_LDH + C8_LDZ);                      // elements of one operand plane: h1, h2, latents
 template <> struct Pl<PolX3C> { static constexpr int lds = C8_PLANE; };
+template <> struct Pl<PolB1C> { static constexpr int lds = 0; };
 
 constexpr size_t C8_O_X2 = (size_t)C8_PLANE * 2 * sizeof(__bf16);
 constexpr size_t C8_O_VB = C8_O_X2 + (size_t)16 * 16 * 64 * sizeof(float);        // Vb of each wave's output tiles 2 and 3 (tiles 0, 1: registers)
@@ -58,11 +60,11 @@ __device__ __forceinline__ void sfor(F&& f) {
 // likelihood terms of the previous tile, one bin behind each of the first two MFMAs, the next bins' LDS reads behind the third).
 // `acc` comes in holding the bias (read from LDS straight into the accumulator registers): no bias add per bin, no VALU-written SrcC.
 template <typename P, int NSTEPS, int NAG, typename Between>
-__device__ __forceinline__ void gemm_resident_agpr(f32x16& acc, const typename P::Frag (&w)[NSTEPS][2], const typename P::T* brow, Between&& between) {
+__device__ __forceinline__ void gemm_resident_agpr(f32x16& acc, const typename P::Frag (&w)[NSTEPS][P::NP], const typename P::T* brow, Between&& between) {
     typedef typename P::Frag Frag;
     constexpr int STR = 2 * P::E;
     constexpr int BD = NSTEPS < 2 ? NSTEPS : 2;
-    Frag bq[BD][2];
+    Frag bq[BD][P::NP];
 #pragma unroll
     for (int i = 0; i < BD; ++i) bloadp<P>(bq[i], brow + i * STR);
     // one MFMA of the chain; LAST carries the s_nops; AG: the weight fragment lives in an AGPR
@@ -80,21 +82,27 @@ __device__ __forceinline__ void gemm_resident_agpr(f32x16& acc, const typename P
         constexpr int i = decltype(ic)::value;
         typedef std::integral_constant<bool, (i < NAG)> Ag;
         typedef std::integral_constant<bool, false> F;
-        mm(F{}, Ag{}, w[i][1], bq[i % BD][0]);
-        between(ic, std::integral_constant<int, 0>{});
-        mm(F{}, Ag{}, w[i][0], bq[i % BD][1]);
-        between(ic, std::integral_constant<int, 1>{});
-        mm(std::integral_constant<bool, i + 1 == NSTEPS>{}, Ag{}, w[i][0], bq[i % BD][0]);
+        if constexpr (P::NP == 2) {
+            mm(F{}, Ag{}, w[i][1], bq[i % BD][0]);
+            between(ic, std::integral_constant<int, 0>{});
+            mm(F{}, Ag{}, w[i][0], bq[i % BD][1]);
+            between(ic, std::integral_constant<int, 1>{});
+            mm(std::integral_constant<bool, i + 1 == NSTEPS>{}, Ag{}, w[i][0], bq[i % BD][0]);
+        } else {
+            mm(std::integral_constant<bool, i + 1 == NSTEPS>{}, Ag{}, w[i][0], bq[i % BD][0]);
+            between(ic, std::integral_constant<int, 0>{});
+            between(ic, std::integral_constant<int, 1>{});
+        }
         if constexpr (i + BD < NSTEPS) bloadp<P>(bq[i % BD], brow + (i + BD) * STR);
         between(ic, std::integral_constant<int, 2>{});
     });
 }
 
-template <int YP>
+template <typename P, int YP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mcem_resident_kernel(const MhArgs g) {
-    typedef PolX3C P;
     typedef __bf16 T;
-    typedef P::Frag Frag;
+    typedef typename P::Frag Frag;
+    constexpr int NP = P::NP;
     constexpr int LDH = C8_LDH, LDZ = C8_LDZ, LDC = C8_LDC;
     constexpr int OB4 = HD, OB5 = 2 * HD;
     constexpr int NTW = 4;                                                 // output tiles per wave
@@ -121,17 +129,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- resident weight fragments (once per launch); copies: [k-step of 16][32-row tile][lane][8] ----
-    Frag w3zR[1][2], w4R[HD / 16][2], w5R[NTW][HD / 16][2];
+    Frag w3zR[1][NP], w4R[HD / 16][NP], w5R[NTW][HD / 16][NP];
     {
         const unsigned o3 = (unsigned)(g.oW3 * 2) + (unsigned)((wave_u * 64 + lane) * 16);      // k-step 0: the 16 latent columns
         w3zR[0][0] = ld16(o3);
-        w3zR[0][1] = ld16(o3 + g.wpl);
+        if constexpr (NP == 2) w3zR[0][1] = ld16(o3 + g.wpl);
     }
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ++ks) {
         const unsigned o4 = (unsigned)(g.oW4 * 2) + (unsigned)(((ks * 4 + wave_u) * 64 + lane) * 16);
         w4R[ks][0] = ld16(o4);
-        w4R[ks][1] = ld16(o4 + g.wpl);
+        if constexpr (NP == 2) w4R[ks][1] = ld16(o4 + g.wpl);
     }
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int ks = 0; ks < HD / 16; ++ks) {
             const unsigned o5 = (unsigned)(g.oW5 * 2) + (unsigned)(((ks * NT_OUT + NTW * wave_u + tt) * 64 + lane) * 16);
             w5R[tt][ks][0] = ld16(o5);
-            w5R[tt][ks][1] = ld16(o5 + g.wpl);
+            if constexpr (NP == 2) w5R[tt][ks][1] = ld16(o5 + g.wpl);
         }
     }
     for (int i = tid; i < 2 * HD + NO; i += 256) Bias[i] = g.bias[i];
@@ -147,8 +155,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int k = tid;
         const int64_t e = g.oW5 + ((int64_t)((k >> 4) * NT_OUT + 16) * 64 + ((k >> 3) & 1) * 32) * 8 + (k & 7);
         const __bf16* const wc = reinterpret_cast<const __bf16*>(g.wcopy);
-        const __bf16 lo = *reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
-        w512s[k] = (float)wc[e] + (float)lo;
+        float wv = (float)wc[e];
+        if constexpr (NP == 2) wv += (float)*reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
+        w512s[k] = wv;
     }
     __syncthreads();
     const float b512 = Bias[OB5 + 512];
@@ -171,8 +180,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {                             // W3[f][16 + j]: k-step 1, k half j >> 3
                     const int64_t e = g.oW3 + ((int64_t)(1 * 4 + (f >> 5)) * 64 + (j >> 3) * 32 + (f & 31)) * 8 + (j & 7);
-                    const __bf16 lo = *reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
-                    wy[j] = (float)wc[e] + (float)lo;
+                    wy[j] = (float)wc[e];
+                    if constexpr (NP == 2) wy[j] += (float)*reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
                 }
             }
             const float b3 = Bias[f];
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 epi_begin(tc);
                 if constexpr (tt + 1 < NTW) {
                     bias_into(nxt, t + 1);
-                    gemm_resident_agpr<P, HD / 16, (tt + 1 < NTW - 1 ? HD / 16 : 6)>(nxt, w5R[tt + 1], Hbr, [&](auto ic, auto jc) {
+                    gemm_resident_agpr<P, HD / 16, (tt + 1 < NTW - 1 || NP == 1 ? HD / 16 : 6)>(nxt, w5R[tt + 1], Hbr, [&](auto ic, auto jc) {
                         constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
                         if constexpr (j < 2) epi(tc, t, std::integral_constant<int, 2 * i + j>{}, cur[2 * i + j], xq[2 * i + j], vq[2 * i + j]);
                         else if constexpr (i + 1 < HD / 16) {
@@ -415,29 +424,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template <int YP>
+template <typename P, int YP>
 static int launch_resident_t(const MhArgs& a, hipStream_t s) {
     static bool attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)mcem_resident_kernel<YP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C8_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)mcem_resident_kernel<P, YP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C8_LDS);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mcem_resident_kernel, %zu B LDS): %s", C8_LDS, hipGetErrorString(e)); return (int)e; }
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((mcem_resident_kernel<YP>), dim3(a.ntiles), dim3(256), C8_LDS, s, a);
+    hipLaunchKernelGGL((mcem_resident_kernel<P, YP>), dim3(a.ntiles), dim3(256), C8_LDS, s, a);
     DVAE_LAUNCH_OK("mcem_resident_kernel");
     return 0;
 }
 
-bool resident_chain_supported(int precision, int yp) { return precision == DVAE_PREC_BF16X3 && (yp == 0 || yp == 16); }
+bool resident_chain_supported(int precision, int yp) { return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16) && (yp == 0 || yp == 16); }
 
 int launch_resident_chain(int yp, const MhArgs& a, hipStream_t s) {
-    if (a.wpl == 0) { set_error("mcem resident chain: split-bf16 weight copies only"); return DVAE_E_UNSUPPORTED; }
-    if ((int64_t)XD * a.N * 4 >= ((int64_t)1 << 31) || (int64_t)a.nit * ZD * a.N * 4 >= ((int64_t)1 << 31)) { set_error("mcem resident chain: (F, N) matrices of 2 GB and more are not addressed"); return DVAE_E_UNSUPPORTED; }
-    if (yp == 0) return launch_resident_t<0>(a, s);
-    if (yp == 16) return launch_resident_t<16>(a, s);
+    if ((int64_t)XD * a.N * 4 >= ((int64_t)1 << 31) || (int64_t)a.nit * ZD * a.N * 4 >= ((int64_t)1 << 31)) {
+        set_error("mcem resident chain: (F, N) matrices of 2 GB and more are not addressed");
+        return DVAE_E_UNSUPPORTED;
+    }
+    const bool x3 = a.wpl != 0;
+    if (yp == 0) return x3 ? launch_resident_t<PolX3C, 0>(a, s) : launch_resident_t<PolB1C, 0>(a, s);
+    if (yp == 16) return x3 ? launch_resident_t<PolX3C, 16>(a, s) : launch_resident_t<PolB1C, 16>(a, s);
     set_error("mcem resident chain: label rows 0 or 1..16 only");
     return DVAE_E_UNSUPPORTED;
 }
