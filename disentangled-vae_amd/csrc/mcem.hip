@@ -596,12 +596,12 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     a.bias = (const float*)((const char*)wcopy + L.bias_off_bytes);
     const bool bf = plan->precision == DVAE_PREC_BF16;
     a.wpl = plan->precision == DVAE_PREC_BF16X3 ? (unsigned)(L.elems * 2) : 0u;
-    // bf16 policies, label rows 0 / 1..16: the weight-stationary chain (mcem_resident.hip); DVAE_MCEM_CHAIN=stream, the 513-row labels and
+    // label rows 0 / 1..16: the weight-stationary chain (mcem_resident.hip); DVAE_MCEM_CHAIN=stream, the 513-row labels and
     // (F, N) matrices of 2 GB and more: the streaming kernels below
     static const bool stream_only = [] { const char* e = getenv("DVAE_MCEM_CHAIN"); return e && !strcmp(e, "stream"); }();
     if (!stream_only && resident_chain_supported(plan->precision, L.yp) && (int64_t)XD * a.N * 4 < ((int64_t)1 << 31) &&
         (int64_t)a.nit * ZD * a.N * 4 < ((int64_t)1 << 31))
-        return launch_resident_chain(L.yp, a, s);
+        return launch_resident_chain(plan->precision, L.yp, a, s);
     if (plan->precision == DVAE_PREC_BF16X3) {
         if (L.yp == 0) return launch_mh<PolX3M<0>, 0, 0>(a, s);
         if (L.yp == 16) return launch_mh<PolX3M<16>, 16, 0>(a, s);

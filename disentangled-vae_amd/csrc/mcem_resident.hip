@@ -29,10 +29,22 @@ namespace fused {
 
 struct PolX3C : PolX3 {};            // split bf16: two operand planes, three MFMAs per product
 struct PolB1C : PolBF16 {};          // one bf16 per operand (opt-in fast policy)
-constexpr int C8_LDH = HD + 8, C8_LDZ = 32 + 8, C8_LDC = HD + 4;
-constexpr int C8_PLANE = TB * (2 * C8_LDH + C8_LDZ);                      // elements of one operand plane: h1, h2, latents
+struct PolF32C : PolF32 {            // exact fp32 products (v_mfma_f32_32x32x2_f32); epilogue on the hardware exp2 / log2 / rcp units as the
+                                     // streaming fp32 chain (mcem.hip: PolF32Deep)
+    static __device__ __forceinline__ float exp_(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+    static __device__ __forceinline__ float log_(float v) { return __builtin_amdgcn_logf(v) * 0.693147180559945309f; }
+    static __device__ __forceinline__ float tanh_(float v) {
+        const float e = __builtin_amdgcn_exp2f(v * 2.88539008177792681f);
+        return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    }
+    static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+};
+constexpr int C8_LDC = HD + 4;
+constexpr int C8_PLANE = TB * (2 * (HD + 8) + 32 + 8);                    // bf16 elements of one operand plane: h1, h2, latents
 template <> struct Pl<PolX3C> { static constexpr int lds = C8_PLANE; };
 template <> struct Pl<PolB1C> { static constexpr int lds = 0; };
+template <> struct Pl<PolF32C> { static constexpr int lds = 0; };
+static_assert((size_t)TB * (2 * (HD + 4) + 32 + 4) * sizeof(float) <= (size_t)C8_PLANE * 2 * sizeof(__bf16), "the fp32 activation plane fits the two bf16 planes");
 
 constexpr size_t C8_O_X2 = (size_t)C8_PLANE * 2 * sizeof(__bf16);
 constexpr size_t C8_O_VB = C8_O_X2 + (size_t)16 * 16 * 64 * sizeof(float);        // Vb of each wave's output tiles 2 and 3 (tiles 0, 1: registers)
@@ -78,18 +90,37 @@ __device__ __forceinline__ void gemm_resident_agpr(f32x16& acc, const typename P
             else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
         }
     };
+    // fp32: one v_mfma_f32_32x32x2_f32 per fragment element (k = j and 4 + j of the k-step)
+    auto mf = [&](auto last, auto ag, float a, float b) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last)::value, AG = decltype(ag)::value;
+        if constexpr (LAST) {
+            if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+        } else {
+            if constexpr (AG) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        }
+    };
     sfor<0, NSTEPS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         typedef std::integral_constant<bool, (i < NAG)> Ag;
         typedef std::integral_constant<bool, false> F;
-        if constexpr (P::NP == 2) {
+        typedef std::integral_constant<bool, i + 1 == NSTEPS> L;
+        if constexpr (sizeof(typename P::T) == 4) {
+            mf(F{}, Ag{}, w[i][0][0], bq[i % BD][0][0]);
+            mf(F{}, Ag{}, w[i][0][1], bq[i % BD][0][1]);
+            between(ic, std::integral_constant<int, 0>{});
+            mf(F{}, Ag{}, w[i][0][2], bq[i % BD][0][2]);
+            between(ic, std::integral_constant<int, 1>{});
+            mf(L{}, Ag{}, w[i][0][3], bq[i % BD][0][3]);
+        } else if constexpr (P::NP == 2) {
             mm(F{}, Ag{}, w[i][1], bq[i % BD][0]);
             between(ic, std::integral_constant<int, 0>{});
             mm(F{}, Ag{}, w[i][0], bq[i % BD][1]);
             between(ic, std::integral_constant<int, 1>{});
-            mm(std::integral_constant<bool, i + 1 == NSTEPS>{}, Ag{}, w[i][0], bq[i % BD][0]);
+            mm(L{}, Ag{}, w[i][0], bq[i % BD][0]);
         } else {
-            mm(std::integral_constant<bool, i + 1 == NSTEPS>{}, Ag{}, w[i][0], bq[i % BD][0]);
+            mm(L{}, Ag{}, w[i][0], bq[i % BD][0]);
             between(ic, std::integral_constant<int, 0>{});
             between(ic, std::integral_constant<int, 1>{});
         }
@@ -100,10 +131,12 @@ __device__ __forceinline__ void gemm_resident_agpr(f32x16& acc, const typename P
 
 template <typename P, int YP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mcem_resident_kernel(const MhArgs g) {
-    typedef __bf16 T;
+    typedef typename P::T T;
     typedef typename P::Frag Frag;
-    constexpr int NP = P::NP;
-    constexpr int LDH = C8_LDH, LDZ = C8_LDZ, LDC = C8_LDC;
+    constexpr int NP = P::NP, E = P::E, KS = P::KSTEP, NK = HD / KS;     // bf16: 8 k-steps of 16; fp32: 16 k-steps of 8
+    constexpr int BPK = 16 / NK;                                          // bins of the previous tile handled per k-step: 2 / 1
+    constexpr int NAG3 = sizeof(T) == 4 ? 12 : (NP == 2 ? 6 : NK);        // k-steps of tile 3 whose fragments live in AGPRs (<= 240 AGPRs in all)
+    constexpr int LDH = HD + 16 / (int)sizeof(T), LDZ = 32 + 16 / (int)sizeof(T), LDC = C8_LDC;
     constexpr int OB4 = HD, OB5 = 2 * HD;
     constexpr int NTW = 4;                                                 // output tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,41 +162,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- resident weight fragments (once per launch); copies: [k-step of 16][32-row tile][lane][8] ----
-    Frag w3zR[1][NP], w4R[HD / 16][NP], w5R[NTW][HD / 16][NP];
-    {
-        const unsigned o3 = (unsigned)(g.oW3 * 2) + (unsigned)((wave_u * 64 + lane) * 16);      // k-step 0: the 16 latent columns
-        w3zR[0][0] = ld16(o3);
-        if constexpr (NP == 2) w3zR[0][1] = ld16(o3 + g.wpl);
+    Frag w3zR[ZD / KS][NP], w4R[NK][NP], w5R[NTW][NK][NP];
+#pragma unroll
+    for (int ks = 0; ks < ZD / KS; ++ks) {                                 // the 16 latent columns of decoder layer 1
+        const unsigned o3 = (unsigned)(g.oW3 * sizeof(T)) + (unsigned)(((ks * 4 + wave_u) * 64 + lane) * 16);
+        w3zR[ks][0] = ld16(o3);
+        if constexpr (NP == 2) w3zR[ks][1] = ld16(o3 + g.wpl);
     }
 #pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) {
-        const unsigned o4 = (unsigned)(g.oW4 * 2) + (unsigned)(((ks * 4 + wave_u) * 64 + lane) * 16);
+    for (int ks = 0; ks < NK; ++ks) {
+        const unsigned o4 = (unsigned)(g.oW4 * sizeof(T)) + (unsigned)(((ks * 4 + wave_u) * 64 + lane) * 16);
         w4R[ks][0] = ld16(o4);
         if constexpr (NP == 2) w4R[ks][1] = ld16(o4 + g.wpl);
     }
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) {
-            const unsigned o5 = (unsigned)(g.oW5 * 2) + (unsigned)(((ks * NT_OUT + NTW * wave_u + tt) * 64 + lane) * 16);
+        for (int ks = 0; ks < NK; ++ks) {
+            const unsigned o5 = (unsigned)(g.oW5 * sizeof(T)) + (unsigned)(((ks * NT_OUT + NTW * wave_u + tt) * 64 + lane) * 16);
             w5R[tt][ks][0] = ld16(o5);
             if constexpr (NP == 2) w5R[tt][ks][1] = ld16(o5 + g.wpl);
         }
     }
     for (int i = tid; i < 2 * HD + NO; i += 256) Bias[i] = g.bias[i];
-    if (tid < HD) {                                                        // row 512 = tile 16, row 0 of the tile: lane' = (k half) * 32
-        const int k = tid;
-        const int64_t e = g.oW5 + ((int64_t)((k >> 4) * NT_OUT + 16) * 64 + ((k >> 3) & 1) * 32) * 8 + (k & 7);
-        const __bf16* const wc = reinterpret_cast<const __bf16*>(g.wcopy);
-        float wv = (float)wc[e];
-        if constexpr (NP == 2) wv += (float)*reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
-        w512s[k] = wv;
-    }
+    // element (row, column k) of a copy: k-step k / KS, lane' = (k % KS) / E * 32 + row % 32, element k % E
+    const T* const wc = reinterpret_cast<const T*>(g.wcopy);
+    auto welem = [&](int64_t base, int nt, int row, int k) __attribute__((always_inline)) {
+        const int64_t e = base + ((int64_t)((k / KS) * nt + (row >> 5)) * 64 + ((k % KS) / E) * 32 + (row & 31)) * E + (k % E);
+        float v = (float)wc[e];
+        if constexpr (NP == 2) v += (float)*reinterpret_cast<const T*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
+        return v;
+    };
+    if (tid < HD) w512s[tid] = welem(g.oW5, NT_OUT, 512, tid);           // row 512 of the output layer
     __syncthreads();
     const float b512 = Bias[OB5 + 512];
-    const T* const Zbr = Zb + l31 * LDZ + h * 8;
-    const T* const Har = Ha + l31 * LDH + h * 8;
-    const T* const Hbr = Hb + l31 * LDH + h * 8;
+    const T* const Zbr = Zb + l31 * LDZ + h * E;
+    const T* const Har = Ha + l31 * LDH + h * E;
+    const T* const Hbr = Hb + l31 * LDH + h * E;
 
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t n0 = (int64_t)tile * TB;
@@ -176,13 +211,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int f = tid & (HD - 1), fg = tid >> 7;                   // feature, group of 16 frames
             float wy[16];
             if constexpr (YP > 0) {
-                const __bf16* const wc = reinterpret_cast<const __bf16*>(g.wcopy);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {                             // W3[f][16 + j]: k-step 1, k half j >> 3
-                    const int64_t e = g.oW3 + ((int64_t)(1 * 4 + (f >> 5)) * 64 + (j >> 3) * 32 + (f & 31)) * 8 + (j & 7);
-                    wy[j] = (float)wc[e];
-                    if constexpr (NP == 2) wy[j] += (float)*reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
-                }
+                for (int j = 0; j < 16; ++j) wy[j] = welem(g.oW3, 4, f, ZD + j);          // W3[f][16 + j]
             }
             const float b3 = Bias[f];
             for (int fr = 16 * fg; fr < 16 * fg + 16; ++fr) {
@@ -245,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float v[16], bv[16];
             // layer 1: [z | y] -> h1
             zero_acc<P>(acc);
-            gemm_resident_p<P, 1>(acc, w3zR, Zbr);
+            gemm_resident_p<P, ZD / KS>(acc, w3zR, Zbr);
             bias16(c1s + l31 * LDC, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
@@ -253,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __syncthreads();                                               // B1
             // layer 2: h1 -> h2, and this wave's 32 terms of bin 512's pre-activation
             zero_acc<P>(acc);
-            gemm_resident_p<P, HD / 16>(acc, w4R, Har);
+            gemm_resident_p<P, NK>(acc, w4R, Har);
             bias16(Bias + OB4, fb, h, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 16; ++r) dst[r] = bv[r];
             };
             bias_into(acc, NTW * wave_u);
-            gemm_resident_agpr<P, HD / 16, HD / 16>(acc, w5R[0], Hbr, [](auto, auto) {});
+            gemm_resident_agpr<P, NK, NK>(acc, w5R[0], Hbr, [](auto, auto) {});
             sfor<0, NTW>([&](auto tc) {
                 constexpr int tt = decltype(tc)::value;
                 const int t = NTW * wave_u + tt;
@@ -288,21 +318,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     xq[r] = X2s[(t * 16 + r) * 64 + lane];
                     if constexpr (tt < 2) vq[r] = vbR[tt][r]; else vq[r] = Vbs[((wave_u * 2 + tt - 2) * 16 + r) * 64 + lane];
                 };
-                loadxv(std::integral_constant<int, 0>{});
-                loadxv(std::integral_constant<int, 1>{});
+                sfor<0, BPK>([&](auto bc) { loadxv(bc); });
                 epi_begin(tc);
                 if constexpr (tt + 1 < NTW) {
                     bias_into(nxt, t + 1);
-                    gemm_resident_agpr<P, HD / 16, (tt + 1 < NTW - 1 || NP == 1 ? HD / 16 : 6)>(nxt, w5R[tt + 1], Hbr, [&](auto ic, auto jc) {
+                    gemm_resident_agpr<P, NK, (tt + 1 < NTW - 1 ? NK : NAG3)>(nxt, w5R[tt + 1], Hbr, [&](auto ic, auto jc) {
                         constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-                        if constexpr (j < 2) epi(tc, t, std::integral_constant<int, 2 * i + j>{}, cur[2 * i + j], xq[2 * i + j], vq[2 * i + j]);
-                        else if constexpr (i + 1 < HD / 16) {
-                            loadxv(std::integral_constant<int, 2 * i + 2>{});
-                            loadxv(std::integral_constant<int, 2 * i + 3>{});
-                        }
+                        if constexpr (j < BPK) epi(tc, t, std::integral_constant<int, BPK * i + j>{}, cur[BPK * i + j], xq[BPK * i + j], vq[BPK * i + j]);
+                        else if constexpr (j == 2 && i + 1 < NK) sfor<0, BPK>([&](auto bc) { loadxv(std::integral_constant<int, BPK * (i + 1) + decltype(bc)::value>{}); });
                     });
                 } else {
-                    sfor<2, 16>([&](auto rc) { loadxv(rc); });
+                    sfor<BPK, 16>([&](auto rc) { loadxv(rc); });
                     sfor<0, 16>([&](auto rc) { constexpr int r = decltype(rc)::value; epi(tc, t, rc, cur[r], xq[r], vq[r]); });
                 }
                 epi_end(tc);
@@ -440,16 +466,15 @@ static int launch_resident_t(const MhArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool resident_chain_supported(int precision, int yp) { return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16) && (yp == 0 || yp == 16); }
+bool resident_chain_supported(int precision, int yp) { return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_F32) && (yp == 0 || yp == 16); }
 
-int launch_resident_chain(int yp, const MhArgs& a, hipStream_t s) {
+int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s) {
     if ((int64_t)XD * a.N * 4 >= ((int64_t)1 << 31) || (int64_t)a.nit * ZD * a.N * 4 >= ((int64_t)1 << 31)) {
         set_error("mcem resident chain: (F, N) matrices of 2 GB and more are not addressed");
         return DVAE_E_UNSUPPORTED;
     }
-    const bool x3 = a.wpl != 0;
-    if (yp == 0) return x3 ? launch_resident_t<PolX3C, 0>(a, s) : launch_resident_t<PolB1C, 0>(a, s);
-    if (yp == 16) return x3 ? launch_resident_t<PolX3C, 16>(a, s) : launch_resident_t<PolB1C, 16>(a, s);
+    if (yp == 0) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, 0>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, 0>(a, s) : launch_resident_t<PolF32C, 0>(a, s);
+    if (yp == 16) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, 16>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, 16>(a, s) : launch_resident_t<PolF32C, 16>(a, s);
     set_error("mcem resident chain: label rows 0 or 1..16 only");
     return DVAE_E_UNSUPPORTED;
 }

@@ -27,9 +27,9 @@ struct MhArgs {
     const float* bias;         // b3[128] b4[128] b5[544]
 };
 
-// weight-stationary chain (mcem_resident.hip): bf16 policies (split: wpl != 0), label rows 0 / 1..16
+// weight-stationary chain (mcem_resident.hip): every operand policy, label rows 0 / 1..16
 bool resident_chain_supported(int precision, int yp);
-int launch_resident_chain(int yp, const MhArgs& a, hipStream_t s);
+int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s);
 
 }  // namespace fused
 }  // namespace dvae
