@@ -297,6 +297,107 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
     }
 }
 
+// hop = 256 (every caller of the reference), frame-major outputs: the walk of stft1024_kernel<., 1 / 2> with the per-frame VALU work that is
+// not the transform taken out.  Round 3 measured the walk at ~100 % VALU issue (2 waves per SIMD, 520 VALU instructions per frame, 282 of them
+// fp64 transform arithmetic); the rest was (a) 48 v_mov_b64 rotating the six carried sample pairs from one frame's slots into the next, (b) ~80
+// instructions of 64-bit address arithmetic and end-of-signal compares around 10 loads and 9 stores, (c) the denormal-input scaling hipcc wraps
+// around v_sqrt_f32 (5 of 10 instructions per bin).  Here: (a) the pairs live in a ring of 8 registers indexed by frame number mod 4 -- the loop
+// is unrolled by four and nothing moves; (b) loads and stores go through buffer descriptors: one per-lane byte offset, the frame offset in an
+// SGPR, and the zero end-pad is the descriptor's own out-of-range value; (c) the raw v_sqrt_f32 (same instruction, same result for normal
+// inputs; |X|^2 below 1.2e-38 -- where the reference's own result is a denormal or zero -- gives 0).
+template <typename TIN, bool POWER>
+__global__ __launch_bounds__(256) void stft1024_walk_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window, int64_t T, int chunk,
+                                                             void* out) {
+    constexpr int M = 512, F = 513;
+    constexpr int ESZ = POWER ? 4 : 8;
+    __shared__ double lre[4][M + 64], lim[4][M + 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform frame numbers: scalar buffer offsets)
+    double* re = lre[wave];
+    double* im = lim[wave];
+    double wa[8], wb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)]; wb[r] = window[2 * (lane + 64 * r) + 1]; }
+    Fft512 fft;
+    fft.init(lane);
+    double sr[4], si[4];                                                           // split twiddles exp(-2 pi i k / 1024), k = lane + 64 r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sincospi(-2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(x), 0, (int)(n * (int64_t)sizeof(TIN)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(T * F * ESZ), 0x00020000);
+    struct TIN2 { TIN a, b; };
+    const int vx = lane * 2 * (int)sizeof(TIN);
+    // pair slot r of frame t: samples 256 t + 128 r + 2 lane, + 1 (past n: the descriptor returns zeros, which is the reference's end pad)
+    auto ldpair = [&](int64_t t, int r) __attribute__((always_inline)) {
+        const int so = (int)((t * 256 + 128 * r) * (int64_t)sizeof(TIN));
+        if constexpr (sizeof(TIN) == 8) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vx, so, 0);
+            return __builtin_bit_cast(TIN2, v);
+        } else {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vx, so, 0);
+            return __builtin_bit_cast(TIN2, v);
+        }
+    };
+    const int vk = lane * ESZ, vm = (M - 192 - lane) * ESZ;                        // bins lane + 64 r / 512 - lane - 64 r: + 64 r ESZ / + 64 (3 - r) ESZ
+    auto put = [&](int voff, int so, cd X) __attribute__((always_inline)) {
+        const float re32 = (float)X.x, im32 = (float)X.y;
+        if constexpr (POWER) {
+            // np.abs(complex64) ** 2: float32 magnitude (the correctly rounded root of re^2 + im^2 stands in for hypotf: far from overflow), squared
+            const float a = __builtin_amdgcn_sqrtf(fmaf(re32, re32, im32 * im32));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a * a), rs_o, voff, so, 0);
+        } else {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(u2{__builtin_bit_cast(unsigned, re32), __builtin_bit_cast(unsigned, im32)}, rs_o, voff, so, 0);
+        }
+    };
+
+    const int64_t tb = ((int64_t)blockIdx.x * 4 + wave) * chunk;
+    const int64_t te = tb + chunk < T ? tb + chunk : T;
+    TIN2 buf[8];                                                                   // ring: slot r of a frame with t - tb = p (mod 4) is buf[(r + 2 p) & 7]
+    if (tb < te) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[r] = ldpair(tb, r);
+    }
+    auto frame = [&](auto phc, int64_t t) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phc)::value;
+        cd v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const TIN2 q = buf[(r + 2 * PH) & 7]; v[r] = cd{(double)q.a * wa[r], (double)q.b * wb[r]}; }
+        if (t + 1 < te) {                                                          // slots 6, 7 of the next frame take the places of this frame's slots 0, 1
+            buf[(2 * PH) & 7] = ldpair(t + 1, 6);
+            buf[(2 * PH + 1) & 7] = ldpair(t + 1, 7);
+        }
+        fft.run(v, re, im, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); re[i] = v[r].x; im[i] = v[r].y; }
+        __builtin_amdgcn_wave_barrier();
+        const int so = (int)(t * F * ESZ);
+        // real-FFT split: X[k] = E + W^k O, X[M-k] = conj(E - W^k O), partner z[M-k] from LDS
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            const int pi = padidx((M - k) & (M - 1));
+            const cd zk = v[r], zc = cd{re[pi], -im[pi]};
+            const cd e = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y)};
+            const cd d = csub(zk, zc);
+            const cd wo = cmulc(cd{0.5 * d.y, -0.5 * d.x}, sr[r], si[r]);
+            put(vk + 64 * r * ESZ, so, cadd(e, wo));
+            put(vm + 64 * (3 - r) * ESZ, so, cconj(csub(e, wo)));
+        }
+        if (lane == 0) put(256 * ESZ, so, cd{v[4].x, -v[4].y});                    // k = 256 (its own partner): X = E + (-i) O
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int64_t t = tb; t < te; t += 4) {
+        frame(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < te) frame(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < te) frame(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < te) frame(std::integral_constant<int, 3>{}, t + 3);
+    }
+}
+
 // generic O(N^2) DFT for non power-of-two window lengths (e.g. the wrapper's never-used
 // default 50 ms = 800 samples): API completeness only.
 template <typename TIN>
@@ -827,7 +928,18 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
             int chunk = (int)cdiv(T, 2048);
             chunk = chunk < 1 ? 1 : chunk;
             const int wb = (int)cdiv(T, (int64_t)4 * chunk);
-            if (layout == 1) {
+            // hop 256 and everything addressable with 32-bit byte offsets: the walk with buffer addressing and the register ring
+            static const bool oldwalk = getenv("DVAE_STFT_WALK") != nullptr && !strcmp(getenv("DVAE_STFT_WALK"), "r3");
+            const bool ring = hop == 256 && !oldwalk && n * (in_f64 ? 8 : 4) < ((int64_t)1 << 31) && T * 513 * (layout == 1 ? 4 : 8) < ((int64_t)1 << 31);
+            if (ring) {
+                if (layout == 1) {
+                    if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, true>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, T, chunk, out);
+                    else hipLaunchKernelGGL((stft1024_walk_kernel<float, true>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, T, chunk, out);
+                } else {
+                    if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, false>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, T, chunk, out);
+                    else hipLaunchKernelGGL((stft1024_walk_kernel<float, false>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, T, chunk, out);
+                }
+            } else if (layout == 1) {
                 if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, chunk, out);
                 else hipLaunchKernelGGL((stft1024_kernel<float, 1>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, hop, T, chunk, out);
             } else {
