@@ -494,8 +494,9 @@ class BenchImpl:
         traffic, traffic_source = None, None
         try:
             import json, os
-            rel = os.path.join("profiles", "traffic_r03.json")
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), rel)))
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            rel = next(r for r in (os.path.join("profiles", f"traffic_r0{n}.json") for n in (4, 3)) if os.path.exists(os.path.join(root, r)))
+            tj = json.load(open(os.path.join(root, rel)))
             cfg = tj.get("config", {})
             if (cfg.get("model"), cfg.get("y_dim"), cfg.get("batch"), cfg.get("precision")) == (self.model, y, B, self.precision) and knames[dom] in tj["kernels"]:
                 traffic = tj["kernels"][knames[dom]]["hbm_bytes_per_launch"]
