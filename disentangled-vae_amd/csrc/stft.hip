@@ -168,6 +168,39 @@ struct Fft512 {
     }
 };
 
+// The same transform with the pass-1 twiddles read from an LDS table t1l[(lane & 7) * 8 + r] = exp(-2 pi i r (lane & 7) / 64) (they depend on
+// lane & 7 only): 28 registers less per wave (three waves per SIMD: stft1024_walk_kernel, OCC3)
+struct Fft512L {
+    double t2r[8], t2i[8];
+    __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) sincospi(-2.0 * (double)(r * lane) / 512.0, &t2i[r], &t2r[r]);
+    }
+    __device__ __forceinline__ void run(cd (&v)[8], double* re, double* im, int lane, const double2* t1l) const {
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane * 8 + r); re[i] = v[r].x; im[i] = v[r].y; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const double2 t = t1l[(lane & 7) * 8 + r]; v[r] = cmulc(v[r], t.x, t.y); }
+        dft8(v);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int j0 = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = padidx(j0 + 8 * r); re[i] = v[r].x; im[i] = v[r].y; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); v[r] = cd{re[i], im[i]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmulc(v[r], t2r[r], t2i[r]);
+        dft8(v);
+    }
+};
+
 constexpr int STFT_FR = 16;        // frames staged per workgroup pass of the complex layout
 
 template <typename TIN, int LAYOUT>
@@ -305,8 +338,8 @@ __global__ __launch_bounds__(256) void stft1024_kernel(const TIN* __restrict__ x
 // is unrolled by four and nothing moves; (b) loads and stores go through buffer descriptors: one per-lane byte offset, the frame offset in an
 // SGPR, and the zero end-pad is the descriptor's own out-of-range value; (c) the raw v_sqrt_f32 (same instruction, same result for normal
 // inputs; |X|^2 below 1.2e-38 -- where the reference's own result is a denormal or zero -- gives 0).
-template <typename TIN, bool POWER>
-__global__ __launch_bounds__(256) void stft1024_walk_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window, int64_t T, int chunk,
+template <typename TIN, bool POWER, bool OCC3>
+__global__ __launch_bounds__(256, OCC3 ? 3 : 2) void stft1024_walk_kernel(const TIN* __restrict__ x, int64_t n, const double* __restrict__ window, int64_t T, int chunk,
                                                              void* out) {
     constexpr int M = 512, F = 513;
     constexpr int ESZ = POWER ? 4 : 8;
@@ -314,14 +347,23 @@ __global__ __launch_bounds__(256) void stft1024_walk_kernel(const TIN* __restric
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform frame numbers: scalar buffer offsets)
     double* re = lre[wave];
     double* im = lim[wave];
-    double wa[8], wb[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)]; wb[r] = window[2 * (lane + 64 * r) + 1]; }
-    Fft512 fft;
+    // OCC3 (diagnostic build, measured slower -- see the launcher): three waves per SIMD (<= 168 registers): the window (32 registers), the
+    // pass-1 twiddles (28) and the split twiddles (16) are read from LDS tables every frame instead (19 ds_read_b128)
+    __shared__ double2 lwin[OCC3 ? M : 1], lsp[OCC3 ? M / 2 : 1], lt1[OCC3 ? 64 : 1];
+    double wa[OCC3 ? 1 : 8], wb[OCC3 ? 1 : 8], sr[OCC3 ? 1 : 4], si[OCC3 ? 1 : 4];
+    typename std::conditional<OCC3, Fft512L, Fft512>::type fft;
     fft.init(lane);
-    double sr[4], si[4];                                                           // split twiddles exp(-2 pi i k / 1024), k = lane + 64 r
+    if constexpr (OCC3) {
+        for (int k = threadIdx.x; k < M; k += 256) lwin[k] = double2{window[2 * k], window[2 * k + 1]};
+        for (int k = threadIdx.x; k < M / 2; k += 256) { double sn, cs; sincospi(-2.0 * (double)k / 1024.0, &sn, &cs); lsp[k] = double2{cs, sn}; }
+        if (threadIdx.x < 64) { double sn, cs; sincospi(-2.0 * (double)((threadIdx.x & 7) * (threadIdx.x >> 3)) / 64.0, &sn, &cs); lt1[threadIdx.x] = double2{cs, sn}; /* entry (k = tid >> 3, r = tid & 7) */ }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sincospi(-2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);
+        for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)]; wb[r] = window[2 * (lane + 64 * r) + 1]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sincospi(-2.0 * (double)(lane + 64 * r) / 1024.0, &si[r], &sr[r]);   // split twiddles exp(-2 pi i k / 1024), k = lane + 64 r
+    }
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(x), 0, (int)(n * (int64_t)sizeof(TIN)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(T * F * ESZ), 0x00020000);
@@ -364,12 +406,16 @@ __global__ __launch_bounds__(256) void stft1024_walk_kernel(const TIN* __restric
         constexpr int PH = decltype(phc)::value;
         cd v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { const TIN2 q = buf[(r + 2 * PH) & 7]; v[r] = cd{(double)q.a * wa[r], (double)q.b * wb[r]}; }
+        for (int r = 0; r < 8; ++r) {
+            const TIN2 q = buf[(r + 2 * PH) & 7];
+            if constexpr (OCC3) { const double2 w = lwin[lane + 64 * r]; v[r] = cd{(double)q.a * w.x, (double)q.b * w.y}; }
+            else v[r] = cd{(double)q.a * wa[r], (double)q.b * wb[r]};
+        }
         if (t + 1 < te) {                                                          // slots 6, 7 of the next frame take the places of this frame's slots 0, 1
             buf[(2 * PH) & 7] = ldpair(t + 1, 6);
             buf[(2 * PH + 1) & 7] = ldpair(t + 1, 7);
         }
-        fft.run(v, re, im, lane);
+        if constexpr (OCC3) fft.run(v, re, im, lane, lt1); else fft.run(v, re, im, lane);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 8; ++r) { const int i = padidx(lane + 64 * r); re[i] = v[r].x; im[i] = v[r].y; }
@@ -383,7 +429,9 @@ __global__ __launch_bounds__(256) void stft1024_walk_kernel(const TIN* __restric
             const cd zk = v[r], zc = cd{re[pi], -im[pi]};
             const cd e = cd{0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y)};
             const cd d = csub(zk, zc);
-            const cd wo = cmulc(cd{0.5 * d.y, -0.5 * d.x}, sr[r], si[r]);
+            double swr, swi;
+            if constexpr (OCC3) { const double2 w = lsp[k]; swr = w.x; swi = w.y; } else { swr = sr[r]; swi = si[r]; }
+            const cd wo = cmulc(cd{0.5 * d.y, -0.5 * d.x}, swr, swi);
             put(vk + 64 * r * ESZ, so, cadd(e, wo));
             put(vm + 64 * (3 - r) * ESZ, so, cconj(csub(e, wo)));
         }
@@ -932,12 +980,29 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
             static const bool oldwalk = getenv("DVAE_STFT_WALK") != nullptr && !strcmp(getenv("DVAE_STFT_WALK"), "r3");
             const bool ring = hop == 256 && !oldwalk && n * (in_f64 ? 8 : 4) < ((int64_t)1 << 31) && T * 513 * (layout == 1 ? 4 : 8) < ((int64_t)1 << 31);
             if (ring) {
-                if (layout == 1) {
-                    if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, true>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, T, chunk, out);
-                    else hipLaunchKernelGGL((stft1024_walk_kernel<float, true>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, T, chunk, out);
+                // DVAE_STFT_OCC=3 (diagnostic build): three waves per SIMD with the window and two twiddle tables read from LDS every frame
+                // (166 registers, 50 KB of LDS per workgroup) -- measured SLOWER, 63.3 / 64.9 us against 57.8 / 61.4 (complex / power frames,
+                // ten minutes of float64 audio, alternating on one box): the 19 extra ds_read_b128 per frame cost more than the third wave hides
+                static const bool occ3 = kDiagBuild && getenv("DVAE_STFT_OCC") != nullptr && atoi(getenv("DVAE_STFT_OCC")) == 3;
+                if (occ3) {
+                    if constexpr (kDiagBuild) {
+                    int chunk3 = (int)cdiv(T, 3072);                   // one round of 256 CUs x 4 SIMDs x 3 resident waves
+                    chunk3 = chunk3 < 1 ? 1 : chunk3;
+                    const int wb3 = (int)cdiv(T, (int64_t)4 * chunk3);
+                    if (layout == 1) {
+                        if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, true, true>), dim3(wb3), dim3(256), 0, s, (const double*)x, n, window, T, chunk3, out);
+                        else hipLaunchKernelGGL((stft1024_walk_kernel<float, true, true>), dim3(wb3), dim3(256), 0, s, (const float*)x, n, window, T, chunk3, out);
+                    } else {
+                        if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, false, true>), dim3(wb3), dim3(256), 0, s, (const double*)x, n, window, T, chunk3, out);
+                        else hipLaunchKernelGGL((stft1024_walk_kernel<float, false, true>), dim3(wb3), dim3(256), 0, s, (const float*)x, n, window, T, chunk3, out);
+                    }
+                    }
+                } else if (layout == 1) {
+                    if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, true, false>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, T, chunk, out);
+                    else hipLaunchKernelGGL((stft1024_walk_kernel<float, true, false>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, T, chunk, out);
                 } else {
-                    if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, false>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, T, chunk, out);
-                    else hipLaunchKernelGGL((stft1024_walk_kernel<float, false>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, T, chunk, out);
+                    if (in_f64) hipLaunchKernelGGL((stft1024_walk_kernel<double, false, false>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, T, chunk, out);
+                    else hipLaunchKernelGGL((stft1024_walk_kernel<float, false, false>), dim3(wb), dim3(256), 0, s, (const float*)x, n, window, T, chunk, out);
                 }
             } else if (layout == 1) {
                 if (in_f64) hipLaunchKernelGGL((stft1024_kernel<double, 1>), dim3(wb), dim3(256), 0, s, (const double*)x, n, window, hop, T, chunk, out);
