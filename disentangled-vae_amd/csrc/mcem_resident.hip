@@ -44,6 +44,19 @@ constexpr int C8_PLANE = TB * (2 * (HD + 8) + 32 + 8);                    // bf1
 template <> struct Pl<PolX3C> { static constexpr int lds = C8_PLANE; };
 template <> struct Pl<PolB1C> { static constexpr int lds = 0; };
 template <> struct Pl<PolF32C> { static constexpr int lds = 0; };
+// the 513-row label image of a tile ([frame][528 + pad], once per tile, aliased over the X2 / Vb area): same policies, its own plane stride
+struct PolX3Y : PolX3C {};
+struct PolB1Y : PolB1C {};
+struct PolF32Y : PolF32C {};
+constexpr int C8_YP = 528;
+template <> struct Pl<PolX3Y> { static constexpr int lds = TB * (C8_YP + 8); };
+template <> struct Pl<PolB1Y> { static constexpr int lds = 0; };
+template <> struct Pl<PolF32Y> { static constexpr int lds = 0; };
+template <typename P> struct YPol;
+template <> struct YPol<PolX3C> { typedef PolX3Y type; };
+template <> struct YPol<PolB1C> { typedef PolB1Y type; };
+template <> struct YPol<PolF32C> { typedef PolF32Y type; };
+static_assert((size_t)TB * (C8_YP + 8) * 2 * sizeof(__bf16) <= (size_t)(16 + 8) * 16 * 64 * sizeof(float) && (size_t)TB * (C8_YP + 4) * sizeof(float) <= (size_t)(16 + 8) * 16 * 64 * sizeof(float), "the label image fits the X2 / Vb area");
 static_assert((size_t)TB * (2 * (HD + 4) + 32 + 4) * sizeof(float) <= (size_t)C8_PLANE * 2 * sizeof(__bf16), "the fp32 activation plane fits the two bf16 planes");
 
 constexpr size_t C8_O_X2 = (size_t)C8_PLANE * 2 * sizeof(__bf16);
@@ -207,7 +220,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float g_n = g.g ? g.g[nf] : 1.f;
 
         // ---- per tile: label part of decoder layer 1 (fp32, constant along the chain), X2 -> LDS, Vb -> registers ----
-        {
+        if constexpr (YP == C8_YP) {
+            // 513 label rows: one GEMM per tile on the streamed label block of W3 (33 / 66 k-steps: mcem.hip does the same), the tile's labels
+            // as a [frame][528] operand image in the area X2 / Vb take afterwards
+            typedef typename YPol<P>::type PY;
+            constexpr int LDY = C8_YP + 16 / (int)sizeof(T);
+            T* const Yb = reinterpret_cast<T*>(smem + C8_O_X2);
+            for (int idx = tid; idx < TB * C8_YP; idx += 256) {
+                const int f = idx >> 5, fr = idx & 31;              // consecutive threads: consecutive frames of one label row
+                float yv = 0.f;
+                if (f < g.ydim && n0 + fr < g.N) yv = g.y[(int64_t)f * g.N + n0 + fr];
+                const T hi = P::cvt(yv);
+                Yb[fr * LDY + f] = hi;
+                if constexpr (NP == 2) Yb[Pl<PY>::lds + fr * LDY + f] = P::cvt(yv - (float)hi);
+            }
+            __syncthreads();
+            constexpr unsigned FBB = 64 * 16;                       // bytes of one fragment block (64 lanes x 16 B)
+            const WRef w3y{lane * 16, (unsigned)(g.oW3 * sizeof(T)) + (unsigned)((ZD / KS) * 4 + wave_u) * FBB, g.wpl};
+            f32x16 cacc;
+            zero_acc<PY>(cacc);
+            WPre<PY, C8_YP / KS, 2> wp;                             // (a shallow ring: this runs once per tile beside 400 resident registers)
+            wprefetch<PY, C8_YP / KS, 2>(wp, wrs, w3y, 4 * FBB);
+            gemm_block<PY, C8_YP / KS, NoHook, 2, 4>(cacc, wp, wrs, w3y, Yb + l31 * LDY + h * E, 4 * FBB);
+            float b3v[16];
+            bias16(Bias, fb, h, b3v);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<f32x4*>(c1s + l31 * LDC + fb + 8 * gq + 4 * h) =
+                    f32x4{cacc[4 * gq] + b3v[4 * gq], cacc[4 * gq + 1] + b3v[4 * gq + 1], cacc[4 * gq + 2] + b3v[4 * gq + 2], cacc[4 * gq + 3] + b3v[4 * gq + 3]};
+            __syncthreads();                                        // the label image is consumed: its area is X2 / Vb from here on
+        } else {
             const int f = tid & (HD - 1), fg = tid >> 7;                   // feature, group of 16 frames
             float wy[16];
             if constexpr (YP > 0) {
@@ -466,7 +508,7 @@ static int launch_resident_t(const MhArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool resident_chain_supported(int precision, int yp) { return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_F32) && (yp == 0 || yp == 16); }
+bool resident_chain_supported(int precision, int yp) { return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_F32) && (yp == 0 || yp == 16 || yp == C8_YP); }
 
 int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s) {
     if ((int64_t)XD * a.N * 4 >= ((int64_t)1 << 31) || (int64_t)a.nit * ZD * a.N * 4 >= ((int64_t)1 << 31)) {
@@ -475,7 +517,8 @@ int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s)
     }
     if (yp == 0) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, 0>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, 0>(a, s) : launch_resident_t<PolF32C, 0>(a, s);
     if (yp == 16) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, 16>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, 16>(a, s) : launch_resident_t<PolF32C, 16>(a, s);
-    set_error("mcem resident chain: label rows 0 or 1..16 only");
+    if (yp == C8_YP) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, C8_YP>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, C8_YP>(a, s) : launch_resident_t<PolF32C, C8_YP>(a, s);
+    set_error("mcem resident chain: label rows 0, 1..16 or 513 only");
     return DVAE_E_UNSUPPORTED;
 }
 
