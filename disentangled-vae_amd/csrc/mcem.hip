@@ -587,7 +587,10 @@ static int launch_mh(const MhArgs& a, hipStream_t s) {
     return 0;
 }
 
+static unsigned long long* g_mcem_dbg = nullptr;      // set by dvae_mcem_debug_stamps
+
 static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hipStream_t s) {
+    a.dbg = g_mcem_dbg;
     const McemLayout L = mcem_layout(plan->y_dim, plan->precision);
     a.ydim = plan->y_dim;
     a.ntiles = (int)((a.N + TB - 1) / TB);
@@ -622,6 +625,11 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
 
 using namespace dvae;
 using namespace dvae::fused;
+
+extern "C" int dvae_mcem_debug_stamps(void* buf) {
+    g_mcem_dbg = (unsigned long long*)buf;
+    return 0;
+}
 
 extern "C" int dvae_mcem_plan(int y_dim, int precision, dvae_mcem_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr, "mcem_plan: null plan");

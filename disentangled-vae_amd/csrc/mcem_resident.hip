@@ -312,6 +312,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // one decoder pass over the latents in Zb: EPI_BEGIN(tt) / EPI(tt, tile t, r, pre-activation incl. bias) / EPI_END(tt) for this wave's output
         // tiles (tt, r: compile-time constants), EPI512(pre-activation) on wave 3; ends BEHIND the output layer (no trailing barrier)
+        unsigned long long tlast = 0ull, tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto stamp = [&](int k) __attribute__((always_inline)) {
+            if (g.dbg) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tsum[k] += t - tlast; tlast = t; }
+        };
         auto pass = [&](auto&& epi_begin, auto&& epi, auto&& epi_end, auto&& epi512) __attribute__((always_inline)) {
             f32x16 acc;
             float v[16], bv[16];
@@ -322,7 +326,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = P::tanh_(acc[r] + bv[r]);
             put_lds<P>(v, Ha, LDH, fb, l31, h);
+            stamp(2);
             __syncthreads();                                               // B1
+            stamp(3);
             // layer 2: h1 -> h2, and this wave's 32 terms of bin 512's pre-activation
             zero_acc<P>(acc);
             gemm_resident_p<P, NK>(acc, w4R, Har);
@@ -338,7 +344,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 p += __shfl_xor(p, 32, 64);
                 if (h == 0) p512[wave * TB + l31] = p;
             }
+            stamp(4);
             __syncthreads();                                               // B2
+            stamp(5);
             // output layer: four resident 32-row tiles per wave; the epilogue of tile tt (two bins per k-step) runs between the MFMAs of tile tt + 1.
             // 240 of the 256 AGPRs hold fragments (tiles 0-2 whole, 6 of tile 3's 8 k-steps); the rest of tile 3 sits in VGPRs
             f32x16 accn;
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const float a = b512 + ((p512[l31] + p512[TB + l31]) + (p512[2 * TB + l31] + p512[3 * TB + l31]));
                 epi512(a);
             }
+            stamp(6);
         };
 
         const int mstart = g.nit > 0 ? -1 : 0;
@@ -399,6 +408,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         };
         if (wave == 0 && g.nit > 0) load_draws(0);
+        // The kept sample and the trace of step m leave the CU behind step m + 1's proposal: vmcnt retires in issue order, so stores issued
+        // in front of the proposal made the wait for the prefetched draws a wait for the stores' acknowledgement too (the serial section of
+        // wave 0 -- everyone else waits at B0 -- was 2400 of a step's 13 200 clocks, tools/stamp_mcem.py)
+        int pend_m = -1; float pend_prob = 0.f; bool pend_acc = false;
+        auto flush_step = [&]() __attribute__((always_inline)) {
+            if (pend_m >= 0) {
+                if (live && h == 0) {
+                    if (g.accp) g.accp[(int64_t)pend_m * g.N + nf] = pend_prob;
+                    if (g.accd) g.accd[(int64_t)pend_m * g.N + nf] = pend_acc ? 1 : 0;
+                }
+                if (pend_m >= g.burnin && live) {                                                    // mcem.py:271-273
+                    float* dst = g.Zs + ((int64_t)nf * g.R + (pend_m - g.burnin)) * ZD;
+                    *reinterpret_cast<f32x4*>(dst + 4 * h) = f32x4{z[0], z[1], z[2], z[3]};
+                    *reinterpret_cast<f32x4*>(dst + 8 + 4 * h) = f32x4{z[4], z[5], z[6], z[7]};
+                }
+                pend_m = -1;
+            }
+        };
+        if (g.dbg) tlast = __builtin_amdgcn_s_memtime();
         for (int m = mstart; m < mend; ++m) {
             float prior_p = 0.f, lu_cur = 0.f;
             if (wave == 0) {
@@ -406,7 +434,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int r = 0; r < 8; ++r) zp[r] = z[r] + g.sd * nzv[r];                     // mcem.py:244
                     lu_cur = lu;
-                    load_draws(m + 1);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) zp[r] = z[r];
@@ -416,8 +443,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 8; ++r) { zv[r] = zp[r]; zv[r + 8] = 0.f; prior_p += zp[r] * zp[r]; }
                 put_lds<P>(zv, Zb, LDZ, 0, l31, h);
                 prior_p += __shfl_xor(prior_p, 32, 64);
+                __builtin_amdgcn_sched_barrier(0);
+                flush_step();
+                if (m >= 0) load_draws(m + 1);
             }
+            stamp(0);
             __syncthreads();                                               // B0
+            stamp(1);
             double ll = 0.0;
             float slog = 0.f, sdiv = 0.f;                                  // sums of log2(vx) and x2 / vx over one tile
             pass(
@@ -435,7 +467,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 });
             ll += __shfl_xor(ll, 32, 64);
             if (h == 0) red[wave * TB + l31] = ll;
+            stamp(7);
             __syncthreads();                                               // B3
+            stamp(8);
             if (wave == 0) {
                 const double ll_p = red[l31] + red[TB + l31] + red[2 * TB + l31] + red[3 * TB + l31];
                 if (m < 0) {
@@ -448,18 +482,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                         for (int r = 0; r < 8; ++r) z[r] = zp[r];
                     }
-                    if (live && h == 0) {
-                        if (g.accp) g.accp[(int64_t)m * g.N + nf] = acc_prob;
-                        if (g.accd) g.accd[(int64_t)m * g.N + nf] = is_acc ? 1 : 0;
-                    }
-                    if (m >= g.burnin && live) {                                                    // mcem.py:271-273
-                        float* dst = g.Zs + ((int64_t)nf * g.R + (m - g.burnin)) * ZD;
-                        *reinterpret_cast<f32x4*>(dst + 4 * h) = f32x4{z[0], z[1], z[2], z[3]};
-                        *reinterpret_cast<f32x4*>(dst + 8 + 4 * h) = f32x4{z[4], z[5], z[6], z[7]};
-                    }
+                    pend_m = m; pend_prob = acc_prob; pend_acc = is_acc;                             // stored behind the next proposal (flush_step)
                 }
             }
             // red / p512 / Zb are next written behind the barriers of the following pass
+        }
+        if (wave == 0) flush_step();
+        if (g.dbg && lane == 0 && g.nit > 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) g.dbg[((size_t)blockIdx.x * 4 + wave) * 16 + k] = tsum[k];
+            g.dbg[((size_t)blockIdx.x * 4 + wave) * 16 + 9] = (unsigned long long)(mend - mstart);
         }
 
         // ---- speech variances of the kept samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----

@@ -25,6 +25,7 @@ struct MhArgs {
     int64_t oW3, oW4, oW5;     // element offsets of the fragment-major copies
     unsigned wpl;              // bytes between the hi and lo planes of the copies (split-bf16 policy)
     const float* bias;         // b3[128] b4[128] b5[544]
+    unsigned long long* dbg;   // diagnostic: per (workgroup, wave) sums of shader clocks per chain phase (dvae_mcem_debug_stamps), null in production
 };
 
 // weight-stationary chain (mcem_resident.hip): every operand policy, label rows 0 / 1..16

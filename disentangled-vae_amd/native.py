@@ -74,6 +74,7 @@ SIGNATURES = {
     "dvae_module_backward": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_vp]),
     "dvae_train_profile": (c_i, [c_i]),
     "dvae_train_debug_stamps": (c_i, [c_vp]),
+    "dvae_mcem_debug_stamps": (c_i, [c_vp]),
     "dvae_train_profile_read": (c_i, [c_vp, c_vp]),
     "dvae_comm_create": (c_i, [c_i, c_i, c_i64, c_vp, c_vp]),
     "dvae_comm_connect": (c_i, [c_vp, c_vp]),

@@ -32,6 +32,10 @@ typedef struct {
 
 int dvae_mcem_plan(int y_dim, int precision, dvae_mcem_plan_t* plan);
 
+/* Measurement only (no reference counterpart): while buf != NULL the weight-stationary chain kernel adds, per (workgroup, wave), the shader
+ * clocks it spends in each of its 9 chain-step phases into buf[(workgroup * 4 + wave) * 16 + phase] (tools/stamp_mcem.py); NULL switches it off. */
+int dvae_mcem_debug_stamps(void* buf);
+
 /* Kernel-layout copy of the decoder (vae.decoder: hidden.0 [128][16+y_dim], hidden.1 [128][128], reconstruction
  * [513][128], nn.Linear layouts with row strides ld*; packages/models/models.py:108-122).  Call again after the
  * weights change. */
