@@ -47,6 +47,9 @@ struct GemmArgs {
     int accumulate;      // EPI 1
     float* db;           // EPI 2 (may be null)
     int atomic;          // EPI 2: combine grid.z slices with atomics
+    float* part;         // EPI 2, deterministic form: slice z writes its partial tile to part + z * part_stride (same [M][ldo] layout), db partials behind the matrices
+    int64_t part_stride;
+    float* dbpart;       // [slices][M]
 };
 
 constexpr int BM = 64, BN = 64, BK = 32;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < g.M && col < g.N) {
             float v = acc[r];
-            float* dst = g.out + row * g.ldo + col;
+            float* dst = (EPI == 2 && g.part != nullptr ? g.part + (int64_t)blockIdx.z * g.part_stride : g.out) + row * g.ldo + col;
             if (EPI == 0) {
                 if (g.bias) v += g.bias[col];
                 *dst = act_apply(v, g.act);
@@ -145,13 +148,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
                 if (g.accumulate) v += *dst;
                 *dst = v;
             } else {
-                if (g.atomic) atomicAdd(dst, v); else *dst = v;
+                if (g.atomic && g.part == nullptr) atomicAdd(dst, v); else *dst = v;
             }
         }
     }
     if (EPI == 2 && AKM) {
         if (g.db != nullptr && blockIdx.y == 0 && tid < BM && m0 + tid < g.M) {
-            if (g.atomic) atomicAdd(g.db + m0 + tid, dbacc); else g.db[m0 + tid] = dbacc;
+            if (g.part != nullptr) g.dbpart[(int64_t)blockIdx.z * g.M + m0 + tid] = dbacc;
+            else if (g.atomic) atomicAdd(g.db + m0 + tid, dbacc); else g.db[m0 + tid] = dbacc;
         }
     }
 }
@@ -218,6 +222,81 @@ extern "C" int dvae_linear_bwd_data(const float* dpre, int ldp, const float* W, 
     g.out = din; g.ldo = ldi; g.accumulate = accumulate;
     hipLaunchKernelGGL((gemm_f32_kernel<false, true, 1>), gemm_grid(B, K, 1), dim3(256), 0, (hipStream_t)stream, g);
     DVAE_LAUNCH_OK("gemm_f32<bwd_data>");
+    return 0;
+}
+
+// deterministic combination of the slice partials: slices summed in ascending order, one thread per output element
+__global__ __launch_bounds__(256) void slices_sum_kernel(const float* __restrict__ part, int64_t part_stride, int nslices, float* __restrict__ dW, int ldw, int ldp,
+                                                        int N, int Kin, const float* __restrict__ dbpart, float* __restrict__ db) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)N * Kin) {
+        const int64_t r = i / Kin, c = i - r * Kin;
+        float s = 0.f;
+        for (int z = 0; z < nslices; ++z) s += part[(int64_t)z * part_stride + r * ldp + c];
+        dW[r * ldw + c] = s;
+    } else if (db != nullptr && i < (int64_t)N * Kin + N) {
+        const int64_t r = i - (int64_t)N * Kin;
+        float s = 0.f;
+        for (int z = 0; z < nslices; ++z) s += dbpart[(int64_t)z * N + r];
+        db[r] = s;
+    }
+}
+
+static int bwd_weight_slices(int64_t B, int N, int Kin, int ksplit, int64_t* kper_out) {
+    const int64_t tiles = cdiv(N, BM) * cdiv(Kin, BN);
+    if (ksplit <= 0) {
+        int64_t want = cdiv(1024, tiles);
+        int64_t maxs = cdiv(B, 256);
+        ksplit = (int)(want < maxs ? want : maxs);
+        if (ksplit < 1) ksplit = 1;
+    }
+    if (ksplit > 65535) ksplit = 65535;
+    int64_t kper = cdiv(cdiv(B, ksplit), BK) * BK;
+    if (kper < BK) kper = BK;
+    ksplit = (int)cdiv(B, kper);
+    if (ksplit < 1) ksplit = 1;
+    *kper_out = kper;
+    return ksplit;
+}
+
+extern "C" size_t dvae_linear_bwd_weight_workspace_bytes(int64_t B, int N, int Kin, int ksplit) {
+    int64_t kper;
+    const int ns = bwd_weight_slices(B > 0 ? B : 1, N, Kin, ksplit, &kper);
+    return ns > 1 ? (size_t)ns * ((size_t)N * Kin + N) * sizeof(float) : 0;
+}
+
+extern "C" int dvae_linear_bwd_weight_det(const float* dpre, int ldp, const float* x0, int k0, int ld0,
+                                          const float* x1, int k1, int ld1, float* dW, int ldw, float* db,
+                                          int64_t B, int N, int ksplit, void* workspace, void* stream) {
+    DVAE_CHECK_ARG(dpre && x0 && dW && B >= 0 && N > 0 && k0 > 0 && k1 >= 0, "linear_bwd_weight_det: bad pointer or size");
+    DVAE_CHECK_ARG(ldp >= N && ld0 >= k0 && (k1 == 0 || (x1 && ld1 >= k1)) && ldw >= k0 + k1, "linear_bwd_weight_det: bad leading dimension");
+    const int Kin = k0 + k1;
+    DVAE_CHECK_ARG(cdiv(Kin, BN) <= 65535, "linear_bwd_weight_det: fan-in too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        DVAE_HIP(hipMemset2DAsync(dW, (size_t)ldw * sizeof(float), 0, (size_t)Kin * sizeof(float), (size_t)N, s));
+        if (db) DVAE_HIP(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), s));
+        return 0;
+    }
+    int64_t kper;
+    const int ns = bwd_weight_slices(B, N, Kin, ksplit, &kper);
+    DVAE_CHECK_ARG(ns == 1 || workspace != nullptr, "linear_bwd_weight_det: %d slices need the workspace of dvae_linear_bwd_weight_workspace_bytes", ns);
+    GemmArgs g{};
+    g.A = MatCat{dpre, nullptr, N, 0, ldp, 0, B};
+    g.B = MatCat{x0, x1, k0, k1, ld0, ld1, B};
+    g.M = N; g.N = Kin; g.K = B; g.kper = kper;
+    g.out = dW; g.ldo = ldw; g.db = db; g.atomic = 0;
+    if (ns > 1) {
+        g.part = (float*)workspace; g.part_stride = (int64_t)N * Kin; g.ldo = Kin;
+        g.dbpart = (float*)workspace + (int64_t)ns * N * Kin;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, 2>), gemm_grid(N, Kin, ns), dim3(256), 0, s, g);
+    DVAE_LAUNCH_OK("gemm_f32<bwd_weight, slices>");
+    if (ns > 1) {
+        const int64_t total = (int64_t)N * Kin + (db ? N : 0);
+        hipLaunchKernelGGL(slices_sum_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, g.part, g.part_stride, ns, dW, ldw, Kin, N, Kin, g.dbpart, db);
+        DVAE_LAUNCH_OK("slices_sum_kernel");
+    }
     return 0;
 }
 

@@ -31,6 +31,8 @@ SIGNATURES = {
     "dvae_act_bwd": (c_i, [c_vp, c_i, c_vp, c_i, c_vp, c_i, c_i64, c_i, c_i, c_vp]),
     "dvae_linear_bwd_data": (c_i, [c_vp, c_i, c_vp, c_i, c_i, c_vp, c_i, c_i64, c_i, c_i, c_i, c_vp]),
     "dvae_linear_bwd_weight": (c_i, [c_vp, c_i, c_vp, c_i, c_i, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_i64, c_i, c_i, c_vp]),
+    "dvae_linear_bwd_weight_det": (c_i, [c_vp, c_i, c_vp, c_i, c_i, c_vp, c_i, c_i, c_vp, c_i, c_vp, c_i64, c_i, c_i, c_vp, c_vp]),
+    "dvae_linear_bwd_weight_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i, c_i, c_i]),
     "dvae_reparam_fwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dvae_reparam_bwd": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dvae_elbo_workspace_bytes": (c_sz, [c_i64]),

@@ -84,9 +84,12 @@ class LinearAct(torch.autograd.Function):
         if need_w or need_b:
             dW = _new((Nout, k0 + k1), out)
             db = _new((Nout,), out) if ctx.has_bias else None
-            N.check(lib.dvae_linear_bwd_weight(N.ptr(dpre), N.ld(dpre), N.ptr(x0_), k0, N.ld(x0_), N.ptr(x1_), k1,
-                                               0 if x1_ is None else N.ld(x1_), N.ptr(dW), k0 + k1, N.ptr(db), B, Nout, 0, s),
-                    "dvae_linear_bwd_weight")
+            # deterministic slice combination (partials + an ordered sum) -- the reference's GPU GEMMs return the same bits for the same inputs
+            nws = lib.dvae_linear_bwd_weight_workspace_bytes(B, Nout, k0 + k1, 0)
+            ws = torch.empty(nws, dtype=torch.uint8, device=out.device) if nws else None
+            N.check(lib.dvae_linear_bwd_weight_det(N.ptr(dpre), N.ld(dpre), N.ptr(x0_), k0, N.ld(x0_), N.ptr(x1_), k1,
+                                                   0 if x1_ is None else N.ld(x1_), N.ptr(dW), k0 + k1, N.ptr(db), B, Nout, 0, N.ptr(ws), s),
+                    "dvae_linear_bwd_weight_det")
             if not need_w:
                 dW = None
             if not need_b:

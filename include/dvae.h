@@ -69,6 +69,13 @@ int dvae_linear_bwd_data(const float* dpre, int ldp, const float* W, int ldw, in
 int dvae_linear_bwd_weight(const float* dpre, int ldp, const float* x0, int k0, int ld0,
                            const float* x1, int k1, int ld1, float* dW, int ldw, float* db,
                            int64_t B, int N, int ksplit, void* stream);
+/* The same with a DETERMINISTIC combination of the slices (what the drop-in modules call: the reference's own GPU path -- cuBLAS -- returns
+ * the same bits for the same inputs): every slice writes its partial matrix into `workspace` (dvae_linear_bwd_weight_workspace_bytes; may be
+ * NULL when that is 0) and a second launch sums the slices in ascending order. */
+size_t dvae_linear_bwd_weight_workspace_bytes(int64_t B, int N, int Kin, int ksplit);
+int dvae_linear_bwd_weight_det(const float* dpre, int ldp, const float* x0, int k0, int ld0,
+                               const float* x1, int k1, int ld1, float* dW, int ldw, float* db,
+                               int64_t B, int N, int ksplit, void* workspace, void* stream);
 
 /* z = mu + exp(0.5*logvar) * eps     packages/models/models.py:9-22 (Stochastic.reparametrize) */
 int dvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,

@@ -90,6 +90,34 @@ def test_bwd_weight_single_slice_is_deterministic_and_matches_split():
         assert rel_err(db, dpre.double().sum(0).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("B,k0,k1,N", [(8192, 513, 0, 128), (8192, 16, 1, 128), (5000, 128, 0, 1), (300, 513, 513, 128), (64, 128, 0, 128)])
+def test_bwd_weight_of_the_modules_is_deterministic(B, k0, k1, N):
+    """dvae_linear_bwd_weight_det (what the drop-in modules' backward calls): split over frame slices like the atomic form, the slices
+    combined by an ordered sum -- two runs return the same bits (the reference's GPU GEMMs do), padded strides and concatenated inputs
+    included, values against float64."""
+    lib = native.load()
+    rng = np.random.default_rng(B + k0)
+    ldp, ld0, ld1, ldw = N + 3, k0 + 5, k1 + 2, k0 + k1 + 7
+    dpre = dev(rng.standard_normal((B, ldp)).astype(np.float32)); x0 = dev(rng.standard_normal((B, ld0)).astype(np.float32))
+    x1 = dev(rng.standard_normal((B, ld1)).astype(np.float32)) if k1 else None
+    nws = lib.dvae_linear_bwd_weight_workspace_bytes(B, N, k0 + k1, 0)
+    assert nws == 0 if B <= 256 else nws > 0                            # one slice needs no workspace
+    outs = []
+    for _ in range(3):
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device="cuda")
+        dW = torch.full((N, ldw), 7.0, device="cuda"); db = torch.full((N,), 7.0, device="cuda")
+        native.check(lib.dvae_linear_bwd_weight_det(native.ptr(dpre), ldp, native.ptr(x0), k0, ld0, native.ptr(x1), k1, ld1 if k1 else 0,
+                                                    native.ptr(dW), ldw, native.ptr(db), B, N, 0, native.ptr(ws), native.stream()), "bwd_weight_det")
+        outs.append((dW.cpu().numpy(), db.cpu().numpy()))
+    for dW, db in outs[1:]:
+        assert np.array_equal(dW, outs[0][0]) and np.array_equal(db, outs[0][1])
+    xin = x0[:, :k0].double() if not k1 else torch.cat([x0[:, :k0], x1[:, :k1]], dim=1).double()
+    ref = (dpre[:, :N].double().T @ xin).cpu().numpy()
+    assert rel_err(outs[0][0][:, :k0 + k1], ref) < 1e-5
+    assert np.all(outs[0][0][:, k0 + k1:] == 7.0)                     # the padding of dW is not touched
+    assert rel_err(outs[0][1], dpre[:, :N].double().sum(0).cpu().numpy()) < 1e-5
+
+
 def test_bwd_data_accumulate_sums_the_two_heads():
     lib = native.load()
     rng = np.random.default_rng(1)
