@@ -482,6 +482,32 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:
                 out["large_batch"] = {"error": repr(exc)}
+        if world == 1 and extras and impl_name == "fused" and a.precision in ("bf16", "bf16x3"):
+            # north_star: "MFMA utilisation on the encoder GEMM".  The rows kernel stamps its phases with the 100 MHz wall clock
+            # (dvae_train_debug_stamps, tools/stamp_rows.py); phase 1 is the x block of encoder layer 1: [B, 513] x [513, 128] on the chain
+            # waves' MFMAs, the weights streamed from L2.  One stamped step after the timed region (the stamps cost ~0.3 us of the kernel).
+            try:
+                import numpy as np
+                N_ = importlib.import_module("disentangled-vae_amd.native")
+                tr_ = impl.tr
+                if tr_.plan.rows_kernel == 2:
+                    buf = torch.zeros(tr_.plan.rows_grid * 32, dtype=torch.int64, device=device)
+                    bx = batches[0]
+                    for _ in range(3):
+                        impl.step(*bx)
+                    N_.load().dvae_train_debug_stamps(N_.ptr(buf)); impl.step(*bx); impl.finish(); torch.cuda.synchronize(); N_.load().dvae_train_debug_stamps(None)
+                    st = buf.cpu().numpy().reshape(-1, 32)[:, :16].astype(np.float64) * 0.01
+                    us = float(np.median(st[:, 2] - st[:, 1]))
+                    fl = 2.0 * 513 * 128 * B
+                    nm = 3.0 if a.precision == "bf16x3" else 1.0
+                    out["encoder_gemm"] = {"phase_us": us, "algorithmic_TFLOP_per_s": fl / us * 1e-6, "issued_TFLOP_per_s": nm * fl / us * 1e-6,
+                                           "mfma_frac_issued": nm * fl / us * 1e-6 / 2500.0, "mfma_frac_algorithmic": fl / us * 1e-6 / 2500.0,
+                                           "mfmas_per_product": nm,
+                                           "note": "x block of encoder layer 1 (513 -> 128) over the step's frames, median over workgroups of the rows kernel's "
+                                                   "in-kernel phase stamps; issued = MFMA instructions actually executed (split-bf16 operands: hi*hi + lo*hi + hi*lo), "
+                                                   "against the dense bf16 peak of 2500 TFLOP/s at 2.4 GHz (the kernel runs at ~2.1)"}
+            except Exception as exc:
+                out["encoder_gemm"] = {"error": repr(exc)}
         if world == 1 and extras and impl_name == "fused" and a.model == "M2" and B == 8192:
             try:
                 out["side_kernels"] = side_kernels(device)
