@@ -27,6 +27,7 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [8][2K][16], then sums [2K][16]
     float* wpart = lw + (XD * K + 3) / 4 * 4;
     float* sums = wpart + 8 * 2 * K * 16;
+    float* x2s = sums + 2 * K * 16;                                  // [j][thread]: X2 of this thread's 17 bins (read in each of the three passes)
     __shared__ float nrm[KMAX];
     __shared__ double redc[8];
     const int tid = threadIdx.x, fr = tid & 15, grp = tid >> 4, lane = tid & 63, wave = tid >> 6;
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, (int)((int64_t)R * FN * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, (int)(FN * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(Vb, 0, (int)(FN * 4), 0x00020000);
-    auto x2_at = [&](int j) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, (int)(jstep * (unsigned)j), 0)); };
+    // X2 of the thread's bins: requested with the sample variances, parked in LDS (thread-private slots: no barrier), read back in each pass --
+    // as a buffer load inside the passes (one bin at a time, to hold the register count) every bin paid an L2 round trip of its own
+    auto x2_at = [&](int j) __attribute__((always_inline)) { return x2s[j * FT16 + tid]; };
 #pragma unroll
     for (int j = 0; j < FJ16; ++j) {
 #pragma unroll
@@ -58,6 +61,9 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
             vs[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, voff, (int)soff, 0));
         }
     }
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j)
+        x2s[j * FT16 + tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, (int)(jstep * (unsigned)j), 0));
     __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < XD * K; i += FT16) lw[i] = Wun[i];
     __syncthreads();
@@ -254,10 +260,10 @@ namespace mstep {
 int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
     const int nt16 = (int)((N + 15) / 16);
-    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + 8 * 2 * K * 16 + 2 * K * 16) * sizeof(float);
+    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + 8 * 2 * K * 16 + 2 * K * 16 + FJ16 * FT16) * sizeof(float);
     static bool attr_done16 = false;
     if (!attr_done16) {
-        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + 8 * 2 * KMAX * 16 + 2 * KMAX * 16) * sizeof(float);
+        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + 8 * 2 * KMAX * 16 + 2 * KMAX * 16 + FJ16 * FT16) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_reg_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
         attr_done16 = true;
