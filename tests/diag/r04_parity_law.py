@@ -101,7 +101,8 @@ if "b" in which:
     params = gu.make_params("M2", dims, 11)
     res["m2_y513_by_batch"] = {}
     relmax = lambda a, b: float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
-    for B in (1000, 8192, 20000, 65536):
+    # PARITY_LAW_BIG=1: also the bench lines' large batches (the float64 oracle of 2^20 frames takes ~40 s and ~60 GB of host memory)
+    for B in (1000, 8192, 20000, 65536) + ((262144, 1048576) if os.environ.get("PARITY_LAW_BIG") == "1" else ()):
         x, y, e = gu.make_batch(dims, B, 12)
         soft = np.random.default_rng(3).random(y.shape).astype(np.float32)
         for labels, yy in (("binary", y), ("soft", soft)):
