@@ -2,7 +2,9 @@
 // chain over the VAE latents as ONE persistent launch per E-step, the NMF multiplicative updates as
 // two HBM-streaming launches, the Wiener gains as one.  See include/dvae_mcem.h.
 //
-// MH kernel: one 256-thread workgroup owns a tile of 32 frames for the whole chain (frames are
+// MH kernels: since round 4 the chain runs in csrc/mcem_resident.hip (the decoder resident in the CU's registers) for every policy and label
+// variant; the STREAMING kernel below stays for (F, N) matrices of 2 GB and more and as the A/B reference (DVAE_MCEM_CHAIN=stream).
+// Streaming MH kernel: one 256-thread workgroup owns a tile of 32 frames for the whole chain (frames are
 // independent given g and Vb).  The decoder (tanh 128, tanh 128, exp 513) runs on the MFMA tile
 // machinery of the train step (transposed orientation: the lane is the frame), so the
 // log-likelihood terms, the accept test and the masked update never leave registers / LDS:
