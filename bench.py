@@ -5,6 +5,8 @@ Adam; + gradient all-reduce when N > 1) of the M2 VAE, 513 bins, on N MI355X.
     python bench.py --gpus 1 --steps 200 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # no launcher: bench.py starts the N ranks itself (launch_ranks) and relays rank 0's line;
+                                          # fewer than N GPUs under RCCL, or a WORLD_SIZE that is not N, is an error, never a dp1 run
 
 A "step" is one pass of the hot path over one batch of B synthetic frames per GPU
 (weak scaling: B per GPU is fixed).  Inputs are resident in HBM before the timed region
@@ -293,6 +295,8 @@ def direct_trial(a, trainer_mod, dims, B, device, world, dist, batches, impl):
         rec["error"] = "warmup: " + str(e)
     if not agree(ok):
         rec.setdefault("error", "warmup: a step failed or a bounded wait ran out on some rank")
+        del impl2                                        # the trainer holds the exchange: drop it, then unmap the peers' buffers
+        dx.close()
         return rec
     try:
         dt2, _ = timed_steps(impl2, batches, a.warmup, a.steps, dist, device)
@@ -334,28 +338,87 @@ def timed_steps(impl, batches, first, steps, dist, device):
     return dt, last
 
 
+def launch_ranks(a):
+    """`bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this process starts N fresh ranks -- `python -m
+    torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD process -- before it has made a single GPU call
+    (torch.cuda.device_count() does not initialise HIP on this image; nothing else here touches the device, and nothing is ever exec'ed
+    over this process), relays rank 0's one JSON line and exits with the launcher's code.  Fewer than N devices under the RCCL backend is
+    an error, never a silent one-GPU run (the reference is single-device, scripts/training_M2.py:31-33: the N > 1 line is this build's
+    own claim and must be what it says it is)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("DVAE_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} over RCCL needs {a.gpus} visible GPUs, this node shows {ndev}; refusing to measure fewer "
+                         f"(DVAE_DIST_BACKEND=gloo rehearses the flow with the ranks sharing the visible devices)\n")
+        raise SystemExit(2)
+    if ndev < 1:
+        sys.stderr.write("bench.py needs an MI355X (no CPU fallback for the hot path)\n")
+        raise SystemExit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher in the environment, starting the ranks: " + " ".join(cmd) + "\n")
+    sys.stderr.flush()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()                                     # rank 0's line (only rank 0 prints one)
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the launcher exited with code {rc}\n")
+        raise SystemExit(rc if 0 < rc < 256 else 1)
+    if line is None:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        raise SystemExit(1)
+    rec = json.loads(line)
+    if rec.get("n_gpus") != a.gpus or (rec.get("multi_gpu") or {}).get("nranks") != a.gpus:
+        sys.stderr.write(f"bench.py: asked for {a.gpus} ranks, the line says n_gpus {rec.get('n_gpus')}\n")
+        raise SystemExit(1)
+    print(line, flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU (python -m torch.distributed.run --nproc-per-node {a.gpus} "
+                         f"bench.py --gpus {a.gpus} ...), or unset WORLD_SIZE and bench.py starts them itself")
+    backend = os.environ.get("DVAE_DIST_BACKEND", "nccl") if world > 1 else None     # "nccl" is RCCL on ROCm; gloo only for single-GPU rehearsals
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, this node shows {ndev}: refusing to let ranks share a device")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)          # one rank per GPU on the node; wraps only on test rigs with fewer GPUs
+    dev_index = local_rank % max(ndev, 1)          # one rank per GPU on the node; wraps only under the gloo rehearsal backend (checked above)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    dist, backend = None, None
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DVAE_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for single-GPU rehearsals
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"process group of {dist.get_world_size()} ranks, --gpus {a.gpus}")
     synth = importlib.import_module("disentangled-vae_amd.synth")
     y_dim = a.y_dim if a.y_dim is not None else {"M1": 0, "M2": 513, "M2_info": 1}[a.model]
     dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
@@ -434,7 +497,9 @@ def main():
         "spread": spread,
     }
     if world > 1:
-        out["multi_gpu"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "direct": direct_rec,
+        devs = [None] * world
+        dist.all_gather_object(devs, dev_index)
+        out["multi_gpu"] = {"nranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": len(set(devs)), "direct": direct_rec,
                             "exchange": os.environ.get("DVAE_ALLREDUCE", "rccl") + (" (dvae_allreduce_flat: peer pointers, one launch per rank)"
                                                                                     if os.environ.get("DVAE_ALLREDUCE") == "direct" else " (torch.distributed all_reduce)"),
                             "allreduce_us": None if prof is None else prof.get("allreduce_us"),
@@ -513,6 +578,11 @@ def main():
                 out["side_kernels"] = side_kernels(device)
             except Exception as exc:                                                # never lose the headline line to a side measurement
                 out["side_kernels"] = {"error": repr(exc)}
+        if isinstance(out["roofline"], dict):
+            # the driver's record keeps `roofline` whole and drops top-level keys it does not know: the north-star sub-records travel inside it
+            for k in ("spread", "encoder_gemm", "large_batch"):
+                if out.get(k) is not None:
+                    out["roofline"][k] = out[k]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model, dims, B, a.cpu_seconds)
             if "b128" in out:
