@@ -42,10 +42,13 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     // Vs of this thread's (bin, frame) pairs: requested first
     // Buffer accesses throughout: ONE per-lane byte offset (bin grp, frame n) for Vs, X2 and Vb, everything else -- the sample r, the bin
     // step 32 j -- in the scalar offset.  With plain 64-bit addresses hipcc computes the 170 + 17 + 17 of them ahead of the loads, keeps
-    // them live through the three passes and spills 500 registers.  The host takes this kernel only while R F N floats stay below 2 GB;
-    // bins past 512 (j = 16, grp > 0) read inside the buffer or get the buffer's out-of-range zero and are never used.
+    // them live through the three passes and spills 500 registers.  The host takes this kernel only while R F N floats stay below 2 GB.
+    // The scalar offset is NOT part of the descriptor's range check on gfx9 (only the per-lane offset is compared with num_records), so
+    // every access must be in range by construction: the one bin row past 512 that exists only for grp 0 (j = 16) is read by the other
+    // groups at grp 0's own offset (voff16: a valid element whose value they never use).
     float vs[FJ16][RR];
     const int voff = (int)(((int64_t)grp * N + n) * 4);
+    const int voff16 = (int)(n * 4);                               // bin 512 + 0: the only row of j = 16
     const unsigned jstep = (unsigned)(32 * N * 4);
     const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, (int)((int64_t)R * FN * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, (int)(FN * 4), 0x00020000);
@@ -58,12 +61,12 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
             const unsigned soff = jstep * (unsigned)j + (unsigned)((int64_t)(r < R ? r : 0) * FN * 4);
-            vs[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, voff, (int)soff, 0));
+            vs[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, j == FJ16 - 1 ? voff16 : voff, (int)soff, 0));
         }
     }
 #pragma unroll
     for (int j = 0; j < FJ16; ++j)
-        x2s[j * FT16 + tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, (int)(jstep * (unsigned)j), 0));
+        x2s[j * FT16 + tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, j == FJ16 - 1 ? voff16 : voff, (int)(jstep * (unsigned)j), 0));
     __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < XD * K; i += FT16) lw[i] = Wun[i];
     __syncthreads();

@@ -38,5 +38,11 @@ def vae_golden():
 
 
 @pytest.fixture(scope="session")
+def vae_golden_big():
+    """The benchmarked 8192-frame batch captured from the reference (make_golden.py --big)."""
+    return np.load(os.path.join(HERE, "golden", "vae_golden_b8192.npz"))
+
+
+@pytest.fixture(scope="session")
 def stft_golden():
     return np.load(os.path.join(HERE, "golden", "stft_ref_fixture.npz"))

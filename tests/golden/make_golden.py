@@ -1,7 +1,8 @@
 """Capture golden vectors by running the REFERENCE ITSELF (CPU, fp32) on
 deterministic inputs.  Build-container only (imports /root/reference read-only):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py          # -> vae_golden.npz (golden_util.CASES, B <= 32)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py --big    # -> vae_golden_b8192.npz (golden_util.BIG_CASES: the benchmarked 8192-frame batch)
 
 Output: tests/golden/vae_golden.npz -- data only (inputs are regenerated from
 seeds by tests/golden_util.py; a checksum of them is stored).  For each case
@@ -41,9 +42,18 @@ def build(model, dims):
     return DeepGenerativeModel_v5([dims["x_dim"], dims["y_dim"], dims["z_dim"], h])
 
 
-def put(fix, key, arr):
-    for k, v in gu.summarize(arr).items():
+def put(fix, key, arr, stride=gu.SAMPLE_STRIDE):
+    for k, v in gu.summarize(arr, stride).items():
         fix[f"{key}/{k}"] = v
+
+
+def keep(fix, key, arr, big):
+    """Step-1 outputs: whole for the small cases; strided sample + moments at 8192 frames."""
+    arr = arr.detach().numpy()
+    if big:
+        put(fix, key, arr, gu.OUT_STRIDE if arr.size > 2 ** 20 else gu.SAMPLE_STRIDE)
+    else:
+        fix[key] = arr
 
 
 def model_call(m, model, x, y, eps_noise):
@@ -64,7 +74,7 @@ def model_call(m, model, x, y, eps_noise):
     return out
 
 
-def run_case(fix, name, model, dims, B, wscale, seed):
+def run_case(fix, name, model, dims, B, wscale, seed, big=False):
     torch.manual_seed(0)
     m = build(model, dims)
     params = gu.make_params(model, dims, seed, wscale)
@@ -90,11 +100,11 @@ def run_case(fix, name, model, dims, B, wscale, seed):
             loss.backward()
             fix[pre + "/losses"] = np.array([loss.item(), recon.item(), kl.item()], dtype=np.float64)
             if step == 1:
-                fix[pre + "/r"] = r.detach().numpy()
-                fix[pre + "/mu"] = mu.detach().numpy()
-                fix[pre + "/logvar"] = lv.detach().numpy()
+                keep(fix, pre + "/r", r, big)
+                keep(fix, pre + "/mu", mu, big)
+                keep(fix, pre + "/logvar", lv, big)
                 if model == "M1":
-                    fix[pre + "/kl_divergence"] = m.kl_divergence.detach().numpy()
+                    keep(fix, pre + "/kl_divergence", m.kl_divergence, big)
                 for k, p in named.items():
                     put(fix, f"{pre}/grad/{k}", p.grad.numpy())
             opt.step(); opt.zero_grad()
@@ -113,12 +123,12 @@ def run_case(fix, name, model, dims, B, wscale, seed):
                                              classif_loss.item(), aux_loss.item(), aux_enc_loss.item()],
                                             dtype=np.float64)
             if step == 1:
-                fix[pre + "/r"] = r.detach().numpy()
-                fix[pre + "/z"] = z.detach().numpy()
-                fix[pre + "/mu"] = mu.detach().numpy()
-                fix[pre + "/logvar"] = lv.detach().numpy()
-                fix[pre + "/y_hat_class_soft"] = y_hat_class_soft.detach().numpy()
-                fix[pre + "/y_hat_aux_soft"] = y_hat_aux_soft.detach().numpy()
+                keep(fix, pre + "/r", r, big)
+                keep(fix, pre + "/z", z, big)
+                keep(fix, pre + "/mu", mu, big)
+                keep(fix, pre + "/logvar", lv, big)
+                keep(fix, pre + "/y_hat_class_soft", y_hat_class_soft, big)
+                keep(fix, pre + "/y_hat_aux_soft", y_hat_aux_soft, big)
                 for k, p in named.items():      # everything enc_loss.backward() deposited (quirk Q4)
                     put(fix, f"{pre}/grad_enc/{k}", p.grad.numpy())
             opt.step(); opt.zero_grad()
@@ -135,17 +145,26 @@ def run_case(fix, name, model, dims, B, wscale, seed):
 
 
 def main():
+    big = "--big" in sys.argv
     fix = {}
-    for i, (name, model, dims, B, wscale) in enumerate(gu.CASES):
-        run_case(fix, name, model, dims, B, wscale, seed=100 + i)
-        print("captured", name)
-    # known-answer from SURVEY.md 8c (reference seeded init, torch RNG): stored for the record
-    torch.manual_seed(0)
-    m = VariationalAutoencoder([513, 16, [128, 128]])
-    x = torch.rand(32, 513) ** 2
-    r, mu, lv = m(x)
-    fix["kat_m1_seed0_elbo"] = np.array([t.item() for t in elbo(x, r, mu, lv, 1e-8)])
-    out = os.path.join(HERE, "vae_golden.npz")
+    if big:
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+        for name, model, dims, B, wscale in gu.BIG_CASES:
+            run_case(fix, name, model, dims, B, wscale, seed=gu.case_seed(name), big=True)
+            print("captured", name)
+        fix["torch_threads"] = np.int64(torch.get_num_threads())
+        out = os.path.join(HERE, "vae_golden_b8192.npz")
+    else:
+        for i, (name, model, dims, B, wscale) in enumerate(gu.CASES):
+            run_case(fix, name, model, dims, B, wscale, seed=100 + i)
+            print("captured", name)
+        # known-answer from SURVEY.md 8c (reference seeded init, torch RNG): stored for the record
+        torch.manual_seed(0)
+        m = VariationalAutoencoder([513, 16, [128, 128]])
+        x = torch.rand(32, 513) ** 2
+        r, mu, lv = m(x)
+        fix["kat_m1_seed0_elbo"] = np.array([t.item() for t in elbo(x, r, mu, lv, 1e-8)])
+        out = os.path.join(HERE, "vae_golden.npz")
     np.savez_compressed(out, **fix)
     print("wrote", out, os.path.getsize(out), "bytes", len(fix), "arrays")
     print("torch", torch.__version__, "numpy", np.__version__)
