@@ -754,6 +754,31 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     return 0;
 }
 
+// Z (16, N) <- the last kept sample of every frame's chain, Zs (N, R, 16): EM.run's `self.Z = Z_sampled_t[:, -1, :].T` (mcem.py:234, 300)
+__global__ __launch_bounds__(256) void last_sample_kernel(const float* __restrict__ Zs, int R, int64_t N, float* __restrict__ Z) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // i = n * 16 + l: coalesced read of the sample, strided 4-byte writes (64 KB in all)
+    if (i >= N * ZD) return;
+    const int64_t n = i / ZD;
+    const int l = (int)(i - n * ZD);
+    Z[(int64_t)l * N + n] = Zs[(n * R + (R - 1)) * ZD + l];
+}
+
+// One EM iteration = the body of EM.run's loop (mcem.py:156-160: E_step, M_step, cost) as ONE host call: the chain launch (with the decoder
+// variances of its kept samples), Z <- last kept sample, the M-step's launches.  Nothing here synchronises or allocates; between two calls
+// the host only has to point at the next iteration's draws.
+extern "C" int dvae_mcem_em_iteration(const dvae_mcem_plan_t* plan, const void* weights, float* Z, const float* y, float* g, float* Vb,
+                                      const float* X2, const float* noise, const float* logu, int nit, int burnin, float var_rw, int64_t N,
+                                      int K, int U, const int* seg_start, const int* seg_count, const int* tile_seg, float* W, float* H,
+                                      float* Zs, float* Vs, float* cost, void* workspace, void* stream) {
+    DVAE_CHECK_ARG(Z && Zs && Vs, "mcem_em_iteration: Z, Zs and Vs are required");
+    int rc = dvae_mcem_sample(plan, weights, Z, y, g, Vb, X2, noise, logu, nit, burnin, var_rw, N, Zs, Vs, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const int R = nit - burnin;
+    hipLaunchKernelGGL(last_sample_kernel, dim3((unsigned)((N * ZD + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Zs, R, N, Z);
+    DVAE_LAUNCH_OK("last_sample_kernel");
+    return dvae_mcem_m_step_batch(X2, Vs, R, N, K, U, seg_start, seg_count, tile_seg, W, H, g, Vb, cost, workspace, stream);
+}
+
 extern "C" int dvae_mcem_m_step(const float* X2, const float* Vs, int R, int64_t N, int K, float* W, float* H, float* g, float* Vb,
                                 float* cost, void* workspace, void* stream) {
     return dvae_mcem_m_step_batch(X2, Vs, R, N, K, 1, nullptr, nullptr, nullptr, W, H, g, Vb, cost, workspace, stream);

@@ -31,8 +31,17 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     __shared__ float nrm[KMAX];
     __shared__ double redc[8];
     const int tid = threadIdx.x, fr = tid & 15, grp = tid >> 4, lane = tid & 63, wave = tid >> 6;
-    const int u = tile_seg ? tile_seg[blockIdx.x >> 1] : 0;        // the segment table is per 32 frames
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    // A workgroup's 16 frames are HALF of every 128-byte line of the (sample, bin) rows of Vs / X2 / Vb; the other half belongs to the
+    // workgroup of the neighbouring 16 frames.  Workgroup i runs on XCD i % 8 (speed only, never correctness), so consecutive frame
+    // blocks would pull every line into two L2s (twice the HBM traffic of the 164 MB the sample variances of 25 utterances take).
+    // Remap: physical workgroups w and w + 8 of a group of 16 -- same XCD, dispatched together -- take the two halves.
+#ifndef MSTEP_XCD_PAIRS
+#define MSTEP_XCD_PAIRS 1
+#endif
+    int bid = blockIdx.x;
+    if (MSTEP_XCD_PAIRS && bid < ((int)gridDim.x & ~15)) { const int w = bid & 15; bid = (bid & ~15) + ((w & 7) << 1) + (w >> 3); }
+    const int u = tile_seg ? tile_seg[bid >> 1] : 0;               // the segment table is per 32 frames
+    const int64_t n0 = (int64_t)bid * 16;
     const int64_t nend = seg_start ? (int64_t)seg_start[u] + seg_count[u] : N;
     const bool live = n0 + fr < nend;
     const bool any_live = n0 < nend;                               // (the second half of a segment's last 32 frames may be all padding)
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < 8; ++w) t += redc[w];
-        partial[blockIdx.x] = t;
+        partial[bid] = t;
     }
 }
 

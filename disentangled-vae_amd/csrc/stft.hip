@@ -449,6 +449,166 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : 2) void stft1024_walk_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 ARITHMETIC, nfft = 1024 / hop = 256: the transform of stft_pytorch (packages/processing/stft.py:123-152 = torch.stft on an fp32
+// tensor with torch.hann_window(1024): window product, FFT and output all in float32; the caller squares and adds in float32 as well,
+// packages/data_handling.py:136).  The float64 walk above stays the transform of stft() (librosa multiplies by a float64 window, so its
+// FFT runs in double whatever the audio's type) and of every bit-level pin.  Same walk -- one wave per frame, three radix-8 Stockham
+// passes, 8 points per lane, six of the eight sample pairs carried over in a register ring -- with what the narrower type buys: a point
+// is ONE 8-byte LDS slot (re, im) instead of two 8-byte doubles (half the exchange instructions, half the bytes), no fp64 VALU (half
+// rate on gfx950), and under 128 registers, i.e. four waves per SIMD instead of two.
+struct cf { float x, y; };
+__device__ __forceinline__ cf cfadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf cfsub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cfconj(cf a) { return cf{a.x, -a.y}; }
+__device__ __forceinline__ cf cfmulc(cf a, float wr, float wi) { return cf{a.x * wr - a.y * wi, a.x * wi + a.y * wr}; }
+
+__device__ __forceinline__ void dft8f(cf (&a)[8]) {
+    constexpr float H = 0.70710678118654752440f;
+    cf b[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b[i] = cfadd(a[i], a[i + 4]); }
+    { const cf d = cfsub(a[0], a[4]); b[4] = d; }
+    { const cf d = cfsub(a[1], a[5]); b[5] = cf{(d.x + d.y) * H, (d.y - d.x) * H}; }
+    { const cf d = cfsub(a[2], a[6]); b[6] = cf{d.y, -d.x}; }
+    { const cf d = cfsub(a[3], a[7]); b[7] = cf{(d.y - d.x) * H, -(d.x + d.y) * H}; }
+    cf c[8];
+#pragma unroll
+    for (int q = 0; q < 8; q += 4) {
+        c[q] = cfadd(b[q], b[q + 2]); c[q + 1] = cfadd(b[q + 1], b[q + 3]);
+        c[q + 2] = cfsub(b[q], b[q + 2]);
+        const cf d = cfsub(b[q + 1], b[q + 3]); c[q + 3] = cf{d.y, -d.x};
+    }
+    a[0] = cfadd(c[0], c[1]); a[4] = cfsub(c[0], c[1]); a[2] = cfadd(c[2], c[3]); a[6] = cfsub(c[2], c[3]);
+    a[1] = cfadd(c[4], c[5]); a[5] = cfsub(c[4], c[5]); a[3] = cfadd(c[6], c[7]); a[7] = cfsub(c[6], c[7]);
+}
+
+struct Fft512F {
+    float t1r[8], t1i[8], t2r[8], t2i[8];
+    __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+            double sn, cs;
+            sincospi(-2.0 * (double)(r * (lane & 7)) / 64.0, &sn, &cs); t1r[r] = (float)cs; t1i[r] = (float)sn;
+            sincospi(-2.0 * (double)(r * lane) / 512.0, &sn, &cs); t2r[r] = (float)cs; t2i[r] = (float)sn;
+        }
+    }
+    // z: the wave's private exchange buffer, 512 + 64 (re, im) slots, padded like the double buffers (one slot per 8)
+    __device__ __forceinline__ void run(cf (&v)[8], cf* z, int lane) const {
+        dft8f(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[padidx(lane * 8 + r)] = v[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = z[padidx(lane + 64 * r)];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cfmulc(v[r], t1r[r], t1i[r]);
+        dft8f(v);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int j0 = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[padidx(j0 + 8 * r)] = v[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = z[padidx(lane + 64 * r)];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cfmulc(v[r], t2r[r], t2i[r]);
+        dft8f(v);
+    }
+};
+
+// waves per SIMD: 3 (168 registers).  Same box, alternating, ten minutes of float32 audio: complex frames 45.8 / 38.3 / 39.5 us and power
+// frames 39.0 / 37.0 / 39.2 us at 4 / 3 / 2 (at 4 the complex form spills 8 registers)
+#ifndef STFT_F32_OCC
+#define STFT_F32_OCC 3
+#endif
+template <bool POWER>
+__global__ __launch_bounds__(256, STFT_F32_OCC) void stft1024_walk_f32_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ window, int64_t T,
+                                                                              int chunk, void* out) {
+    constexpr int M = 512, F = 513;
+    constexpr int ESZ = POWER ? 4 : 8;
+    __shared__ __attribute__((aligned(8))) cf lz[4][M + 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cf* z = lz[wave];
+    float wa[8], wb[8], sr[4], si[4];
+    Fft512F fft;
+    fft.init(lane);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { wa[r] = window[2 * (lane + 64 * r)]; wb[r] = window[2 * (lane + 64 * r) + 1]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { double sn, cs; sincospi(-2.0 * (double)(lane + 64 * r) / 1024.0, &sn, &cs); sr[r] = (float)cs; si[r] = (float)sn; }
+
+    // every access in range by the host's check that all T frames fit in n samples (the scalar offset is not range-checked)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(n * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(T * F * ESZ), 0x00020000);
+    const int vx = lane * 8;
+    auto ldpair = [&](int64_t t, int r) __attribute__((always_inline)) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vx, (int)((t * 256 + 128 * r) * 4), 0);
+        return __builtin_bit_cast(cf, v);                                          // (samples 2 lane, 2 lane + 1 of the slot)
+    };
+    const int vk = lane * ESZ, vm = (M - 192 - lane) * ESZ;
+    auto put = [&](int voff, int so, cf X) __attribute__((always_inline)) {
+        if constexpr (POWER) {
+            // x_tf[..., 0] ** 2 + x_tf[..., 1] ** 2 (packages/data_handling.py:136): two rounded squares, one rounded sum
+            // (contraction switched off for the expression: __fmul_rn / __fadd_rn are plain operators in HIP's headers and would fuse)
+            float pw;
+            {
+#pragma clang fp contract(off)
+                const float a2 = X.x * X.x, b2 = X.y * X.y;
+                pw = a2 + b2;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pw), rs_o, voff, so, 0);
+        } else {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, X), rs_o, voff, so, 0);
+        }
+    };
+    const int64_t tb = ((int64_t)blockIdx.x * 4 + wave) * chunk;
+    const int64_t te = tb + chunk < T ? tb + chunk : T;
+    cf buf[8];                                                                     // ring: slot r of a frame with t - tb = p (mod 4) is buf[(r + 2 p) & 7]
+    if (tb < te) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[r] = ldpair(tb, r);
+    }
+    auto frame = [&](auto phc, int64_t t) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phc)::value;
+        cf v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const cf q = buf[(r + 2 * PH) & 7]; v[r] = cf{q.x * wa[r], q.y * wb[r]}; }
+        if (t + 1 < te) {
+            buf[(2 * PH) & 7] = ldpair(t + 1, 6);
+            buf[(2 * PH + 1) & 7] = ldpair(t + 1, 7);
+        }
+        fft.run(v, z, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[padidx(lane + 64 * r)] = v[r];
+        __builtin_amdgcn_wave_barrier();
+        const int so = (int)(t * F * ESZ);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            const cf zk = v[r], zc = cfconj(z[padidx((M - k) & (M - 1))]);
+            const cf e = cf{0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y)};
+            const cf d = cfsub(zk, zc);
+            const cf wo = cfmulc(cf{0.5f * d.y, -0.5f * d.x}, sr[r], si[r]);
+            put(vk + 64 * r * ESZ, so, cfadd(e, wo));
+            put(vm + 64 * (3 - r) * ESZ, so, cfconj(cfsub(e, wo)));
+        }
+        if (lane == 0) put(256 * ESZ, so, cf{v[4].x, -v[4].y});
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int64_t t = tb; t < te; t += 4) {
+        frame(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < te) frame(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < te) frame(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < te) frame(std::integral_constant<int, 3>{}, t + 3);
+    }
+}
+
 // generic O(N^2) DFT for non power-of-two window lengths (e.g. the wrapper's never-used
 // default 50 ms = 800 samples): API completeness only.
 template <typename TIN>
@@ -1041,6 +1201,24 @@ extern "C" int dvae_stft(const void* x, int in_f64, int64_t n, const double* win
             hipLaunchKernelGGL((stft_dft_kernel<float>), dim3(blocks), dim3(256), lds, s, (const float*)x, n, window, nfft, hop, T, out, layout);
     }
     DVAE_LAUNCH_OK("stft");
+    return 0;
+}
+
+extern "C" int dvae_stft_f32(const float* x, int64_t n, const float* window, int nfft, int hop, int64_t T, void* out, int layout, void* stream) {
+    DVAE_CHECK_ARG(x && window && out && n > 0 && T >= 0, "stft_f32: bad argument");
+    DVAE_CHECK_ARG(nfft == 1024 && hop == 256, "stft_f32: the float32-arithmetic transform exists for nfft 1024 / hop 256 (got %d / %d): use dvae_stft", nfft, hop);
+    DVAE_CHECK_ARG(layout == 1 || layout == 2, "stft_f32: frame-major layouts only (1 power frames, 2 complex frames), got %d", layout);
+    DVAE_CHECK_ARG(T == 0 || (T - 1) * (int64_t)hop + nfft <= n, "stft_f32: %lld frames do not fit in %lld samples", (long long)T, (long long)n);
+    DVAE_CHECK_ARG(n * 4 < ((int64_t)1 << 31) && T * 513 * (layout == 1 ? 4 : 8) < ((int64_t)1 << 31), "stft_f32: signal or spectrogram beyond 2 GB (32-bit buffer offsets)");
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // one round of waves: 256 CUs x 4 SIMDs x STFT_F32_OCC resident waves
+    int chunk = (int)cdiv(T, (int64_t)1024 * STFT_F32_OCC);
+    chunk = chunk < 1 ? 1 : chunk;
+    const int wb = (int)cdiv(T, (int64_t)4 * chunk);
+    if (layout == 1) hipLaunchKernelGGL((stft1024_walk_f32_kernel<true>), dim3(wb), dim3(256), 0, s, x, n, window, T, chunk, out);
+    else hipLaunchKernelGGL((stft1024_walk_f32_kernel<false>), dim3(wb), dim3(256), 0, s, x, n, window, T, chunk, out);
+    DVAE_LAUNCH_OK("stft1024_walk_f32_kernel");
     return 0;
 }
 

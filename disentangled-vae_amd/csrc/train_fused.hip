@@ -935,7 +935,7 @@ __device__ __forceinline__ void slab_store(float* p, float v) {
 }
 template <typename P> struct Wg4 {
 #ifndef DVAE_W4RING_X3
-#define DVAE_W4RING_X3 3
+#define DVAE_W4RING_X3 2      // round 5, same box, alternating, three rounds: 25.6 us (2) against 27.2 (3) by hipEvent -- 32 instead of 48 KB per wave in flight
 #endif
 #ifndef DVAE_W4RING
 #define DVAE_W4RING 4
@@ -1073,8 +1073,22 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
                 }
         }
     };
+    // timing ablations of the main loop (tools/r05/wgrad_ablate.sh; results are wrong under any of them): W4_NOMFMA = loads + bias sums only,
+    // W4_NOFSUM = no bias sums, W4_NOLOAD = the ring is never refilled (MFMAs on the prologue's fragments), W4_NOEPI = no reduce-scatter / stores
     auto compute = [&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
+#ifdef W4_NOMFMA
+        if constexpr (RAW == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                bs[i] += fsum(a[s][i][0]);
+                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { c[i][j][0] += (float)b[s][j][0][0]; if constexpr (NP == 2 && BLO) c[i][j][1] += (float)b[s][j][1][0]; }
+            }
+            return;
+        }
+#endif
         if constexpr (RAW == 2) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -1105,8 +1119,10 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
             for (int i = 0; i < NA; ++i) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j], BLO);
+#ifndef W4_NOFSUM
                 bs[i] += fsum(a[s][i][0]);                               // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
                 if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+#endif
             }
         }
     };
@@ -1131,7 +1147,11 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
                     // -- its raw values are consumed before this slot's reload below overwrites the ring
                     prepare(std::integral_constant<int, (s + 1) % RD>{});
                 }
+#ifndef W4_NOLOAD
                 load(sc, sn);
+#else
+                (void)sn;
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -1140,6 +1160,19 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
     // ---- the four partial blocks meet in LDS: a reduce-scatter in a fixed order (deterministic).  Wave w ends up with A tile row
     // w of the block (its local row 0) and stores it: a single wave storing 8 tiles with per-element address arithmetic took
     // 17 us (issue-bound), more than the main loop.
+#ifdef W4_NOEPI
+    {
+        float t = bs[0] + bs[1] + bs[2] + bs[3];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += c[i][j][r];
+        if (t == 123.456f) slabs[0] = t;
+        return;
+    }
+#endif
     constexpr int ROWQ = 4 * 4 * 64;                                      // f32x4 quads of one A row (4 tiles x 16 registers x 64 lanes)
     f32x4* const lds = reinterpret_cast<f32x4*>(wsm);
     float* const lbias = reinterpret_cast<float*>(lds + 8 * ROWQ);        // [dest wave][source order][lane]

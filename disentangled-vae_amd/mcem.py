@@ -219,11 +219,28 @@ class McemBatch:
             noise, logu = draws
         return self._pack.sample(self.Z, self.y, self.g, self.Vb, self.X2, noise, logu, burnin, var_rw=float(self.var_RW))
 
-    def _iteration(self, draw):
-        """One EM iteration (mcem.py:156-160): chain, last kept sample -> Z (in place: Z is a static buffer), M-step; cost (U) on device."""
-        Zs, Vs = self._chain(self.n_e, self.b_e, draw)
-        self.Z.copy_(Zs[:, -1, :].t())
-        return m_step_batch_(self.X2, Vs, self.W, self.H, self.g, self.Vb, self.seg_start, self.seg_count, self.tile_seg)
+    def _loop_buffers(self):
+        """Scratch of the EM loop, allocated once per run: the iteration's samples / variances, the M-step workspace."""
+        dev = self.Z.device
+        if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != self.ntot or self._bufs[0].shape[1] != self.n_e:
+            lib = self._pack.lib
+            self._bufs = (torch.empty((self.ntot, self.n_e, Z_DIM), dtype=torch.float32, device=dev),
+                          torch.empty((self.n_e, F_BINS, self.ntot), dtype=torch.float32, device=dev),
+                          torch.empty(lib.dvae_mcem_m_step_workspace_bytes(self.ntot, self.K, len(self.counts)), dtype=torch.uint8, device=dev))
+        return self._bufs
+
+    def _iteration(self, noise_ptr, logu_ptr, cost_ptr):
+        """One EM iteration (mcem.py:156-160) = ONE call into the library (dvae_mcem_em_iteration): chain + decoder variances of the kept
+        samples, last kept sample -> Z in place, the M-step's launches, cost (U) to cost_ptr.  Draws and cost are raw device addresses: the
+        loop does no tensor arithmetic between iterations (it was bound by the interpreter, not by its kernels: ~150 of 590 us per
+        iteration at 25 utterances were gaps between ten launches issued from Python, profiles/r04_mcem_kernel_stats.csv)."""
+        Zs, Vs, ws = self._loop_buffers()
+        pk = self._pack
+        N.check(pk.lib.dvae_mcem_em_iteration(ctypes.byref(pk.plan), N.ptr(pk.weights), N.ptr(self.Z), N.ptr(self.y), N.ptr(self.g), N.ptr(self.Vb),
+                                              N.ptr(self.X2), noise_ptr, logu_ptr, self.n_e + self.b_e, self.b_e, float(self.var_RW), self.ntot,
+                                              self.K, len(self.counts), N.ptr(self.seg_start), N.ptr(self.seg_count), N.ptr(self.tile_seg),
+                                              N.ptr(self.W), N.ptr(self.H), N.ptr(Zs), N.ptr(Vs), cost_ptr, N.ptr(ws), N.stream()),
+                "dvae_mcem_em_iteration")
 
     def run(self, draws=None, graph=None):
         """EM.run (mcem.py:156-179) for all utterances.  draws: optional list of niter + 1 (noise, logu) pairs.
@@ -237,20 +254,46 @@ class McemBatch:
         dev = self.Z.device
         if graph is None:
             graph = os.environ.get("DVAE_MCEM_GRAPH", "0") == "1" and self.niter >= 8
-        cost = torch.empty((self.niter, len(self.counts)), dtype=torch.float32, device=dev)
-        if not graph or self.niter < 2:
+        U = len(self.counts)
+        cost = torch.empty((self.niter, U), dtype=torch.float32, device=dev)
+        nit = self.n_e + self.b_e
+        for a, nm in ((self.Z, "Z"), (self.g, "g"), (self.Vb, "Vb"), (self.X2, "X2"), (self.W, "W"), (self.H, "H")):
+            if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
+                raise RuntimeError(f"McemBatch.run: {nm} must be a contiguous float32 CUDA tensor")
+        cptr = cost.data_ptr()
+        if draws is not None and not graph:
             for it in range(self.niter):
-                cost[it] = self._iteration(None if draws is None else draws[it])
+                noise, logu = (_f32c(a, nm) for a, nm in zip(draws[it], ("noise", "logu")))
+                assert noise.shape == (nit, Z_DIM, self.ntot) and logu.shape == (nit, self.ntot)
+                self._iteration(noise.data_ptr(), logu.data_ptr(), cptr + 4 * U * it)
+        elif not graph or self.niter < 2:
+            # the generator's draws for as many iterations at a time as fit 256 MB (the reference draws inside the loop, mcem.py:244, 257:
+            # the same distributions, fewer launches); the iterations themselves are one library call each
+            per = nit * (Z_DIM + 1) * self.ntot * 4
+            chunk = max(1, min(self.niter, (256 << 20) // per))
+            for it0 in range(0, self.niter, chunk):
+                c = min(chunk, self.niter - it0)
+                noise = torch.randn(c, nit, Z_DIM, self.ntot, device=dev)
+                logu = torch.rand(c, nit, self.ntot, device=dev).log_()
+                nptr, lptr = noise.data_ptr(), logu.data_ptr()
+                for j in range(c):
+                    self._iteration(nptr + 4 * nit * Z_DIM * self.ntot * j, lptr + 4 * nit * self.ntot * j, cptr + 4 * U * (it0 + j))
         else:
-            static = None
+            static = (torch.empty((nit, Z_DIM, self.ntot), dtype=torch.float32, device=dev), torch.empty((nit, self.ntot), dtype=torch.float32, device=dev))
+            c = torch.empty(U, dtype=torch.float32, device=dev)
+
+            def body():
+                if draws is None:
+                    static[0].normal_(); static[1].uniform_().log_()
+                self._iteration(static[0].data_ptr(), static[1].data_ptr(), c.data_ptr())
             if draws is not None:
-                static = (torch.empty_like(draws[0][0]), torch.empty_like(draws[0][1]))
                 static[0].copy_(draws[0][0]); static[1].copy_(draws[0][1])
-            cost[0] = self._iteration(static)                      # eager: first-use set-up (kernel attributes, allocator) happens outside the capture
+            body()                                                 # eager: first-use set-up (kernel attributes, allocator) happens outside the capture
+            cost[0].copy_(c)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                c = self._iteration(static)
+                body()
             for it in range(1, self.niter):
                 if draws is not None:
                     static[0].copy_(draws[it][0]); static[1].copy_(draws[it][1])

@@ -49,6 +49,7 @@ SIGNATURES = {
     "dvae_sqerr_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_vp, c_vp]),
     "dvae_adam_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i64, c_d, c_d, c_d, c_d, c_i, c_d, c_vp]),
     "dvae_stft": (c_i, [c_vp, c_i, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i, c_vp]),
+    "dvae_stft_f32": (c_i, [c_vp, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i, c_vp]),
     "dvae_istft_workspace_bytes": (c_sz, [c_i64, c_i]),
     "dvae_istft_workspace_bytes_hop": (c_sz, [c_i64, c_i, c_i]),
     "dvae_istft": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
@@ -92,6 +93,8 @@ SIGNATURES = {
     "dvae_mcem_m_step_workspace_bytes": (c_sz, [c_i64, c_i, c_i]),
     "dvae_mcem_m_step_batch": (c_i, [c_vp, c_vp, c_i, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_m_step": (c_i, [c_vp, c_vp, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dvae_mcem_em_iteration": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                     c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_wiener": (c_i, [c_vp, c_i, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

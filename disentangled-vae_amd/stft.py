@@ -76,6 +76,36 @@ def stft_device(x_dev, window, nfft, hop, T, layout=0):
     return out
 
 
+def window_f32(nfft, device):
+    """torch.hann_window(nfft) (periodic, float32) on `device`: the window of the reference's stft_pytorch (stft.py:141)."""
+    key = ("hann_f32", int(nfft), str(device))
+    w = _window_cache.get(key)
+    if w is None:
+        w = torch.hann_window(window_length=nfft).to(device)
+        _window_cache[key] = w
+    return w
+
+
+def f32_transform_covers(x_dev, nfft, hop, T):
+    """dvae_stft_f32: nfft 1024 / hop 256, float32 signal, 32-bit byte offsets."""
+    return (nfft == 1024 and hop == 256 and x_dev.dtype == torch.float32 and x_dev.numel() * 4 < 2 ** 31 and T * 513 * 8 < 2 ** 31
+            and os.environ.get("DVAE_STFT_F32", "1") != "0")
+
+
+def stft_device_f32(x_dev, nfft, hop, T, layout=2):
+    """The float32-ARITHMETIC transform (torch.stft's on a float32 tensor: packages/processing/stft.py:123-152): x_dev 1-D float32 CUDA
+    tensor already padded -> layout 2: complex64 [T, F] (frame-major; `.T` is the [F, T] result), layout 1: float32 [T, F] re^2 + im^2."""
+    lib = N.load()
+    if not x_dev.is_cuda or x_dev.dim() != 1 or x_dev.dtype != torch.float32:
+        raise TypeError("stft_device_f32: 1-D float32 CUDA tensor required")
+    x_dev = x_dev.contiguous()
+    F = nfft // 2 + 1
+    out = torch.empty((T, F), dtype=torch.complex64 if layout == 2 else torch.float32, device=x_dev.device)
+    N.check(lib.dvae_stft_f32(N.ptr(x_dev), x_dev.numel(), N.ptr(window_f32(nfft, x_dev.device)), nfft, hop, T, N.ptr(out), layout, N.stream()),
+            "dvae_stft_f32")
+    return out
+
+
 def istft_device(S_dev, window, nfft, hop, n_frames, start, out_len):
     """S_dev: complex64 [F, >= n_frames] CUDA tensor -> float32 [out_len].  A tensor whose memory is frame-major (the `.T` view of
     a contiguous [T, F] tensor, e.g. of stft_device(..., layout=2)) is read in place by the frame-major kernel; anything else is

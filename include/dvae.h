@@ -165,6 +165,14 @@ int dvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doub
 int dvae_stft(const void* x, int in_f64, int64_t n, const double* window, int nfft, int hop,
               int64_t T, void* out, int layout, void* stream);
 
+/* The transform of stft_pytorch (packages/processing/stft.py:123-152: torch.stft of a float32 tensor with torch.hann_window) in ITS
+ * arithmetic: window product, FFT and result in float32 (dvae_stft computes in double whatever the input type -- the arithmetic of
+ * stft(), where librosa multiplies by a float64 window).  nfft 1024 / hop 256 only (every caller); window: nfft floats (device);
+ * layout 2 = [T, 513] interleaved complex64, row = frame -- the memory of the legacy torch.stft result, whose [513, T, 2] real view
+ * is the transpose view of it; layout 1 = [T, 513] float32 re * re + im * im (packages/data_handling.py:136).  Signal and result
+ * below 2 GB each.  Any other size / layout: DVAE_E_ARG (use dvae_stft). */
+int dvae_stft_f32(const float* x, int64_t n, const float* window, int nfft, int hop, int64_t T, void* out, int layout, void* stream);
+
 /* S: complex64 [nfft/2+1, ldT] of which the first T columns (frames) are used;
  * y[out_len] float32 = overlap-add of window * irfft(S[:, t]) (float32 accumulation in frame
  * order, as librosa), divided by the window sum-square where it exceeds FLT_MIN, read from

@@ -74,6 +74,17 @@ int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, int64_t N, i
                            const int* seg_count, const int* tile_seg, float* W, float* H, float* g, float* Vb,
                            float* cost, void* workspace, void* stream);
 
+/* One EM iteration, the body of EM.run's loop (mcem.py:156-160: E_step -- the chain of dvae_mcem_sample with the decoder variances of its
+ * kept samples, mcem.py:207-218 / 372-383 -- then `self.Z = last kept sample`, M_step, cost) as ONE host call, so that the loop is bound by
+ * its kernels and not by the interpreter between them.  Z (16, N) is read as the chain's start and overwritten with the last kept sample;
+ * g, Vb, W, H are updated in place as by dvae_mcem_m_step_batch; Zs (N, nit - burnin, 16) and Vs (nit - burnin, F, N) are caller-owned
+ * scratch that holds the iteration's samples / variances afterwards; cost (U) as dvae_mcem_m_step_batch.  U = 1 with NULL segment tables is
+ * the single-utterance loop of scripts/evaluate_ntcd_M2.py:201-205. */
+int dvae_mcem_em_iteration(const dvae_mcem_plan_t* plan, const void* weights, float* Z, const float* y, float* g, float* Vb,
+                           const float* X2, const float* noise, const float* logu, int nit, int burnin, float var_rw, int64_t N,
+                           int K, int U, const int* seg_start, const int* seg_count, const int* tile_seg, float* W, float* H,
+                           float* Zs, float* Vs, float* cost, void* workspace, void* stream);
+
 /* compute_WF (mcem.py:321-327): WFs = mean_r(g Vs / Vx), WFn = mean_r(Vb / Vx), both (F, N). */
 int dvae_mcem_wiener(const float* Vs, int R, int64_t N, const float* g, const float* Vb, float* WFs, float* WFn, void* stream);
 

@@ -241,6 +241,62 @@ class _MCEM(EM):
         self._cached_vs = None
         return Zs
 
+    # chain lengths (nsamples, burnin) the E-step / the final Wiener chain actually run
+    def _e_counts(self):
+        return self.nsamples_E_step, self.burnin_E_step
+
+    def _wf_counts(self):
+        return self.nsamples_WF, self.burnin_WF
+
+    def run(self):
+        """EM.run (reference mcem.py:156-179).  On the device, with the decoder geometry the kernels cover, the loop body -- E_step, M_step,
+        cost -- is ONE library call per iteration (dvae_mcem_em_iteration) on buffers allocated once, the generator's draws are made for
+        many iterations at a time, and the cost is read back once after the loop: the reference's loop stores `cost[n]` into a numpy array,
+        i.e. it synchronises with the device and crosses the interpreter a dozen times in every iteration (evaluate_ntcd_M2.py:201-205
+        runs one utterance per process, so those gaps are all a process sees of the GPU).  Same kernels, same arithmetic as stepping
+        E_step() / M_step() by hand; DVAE_MCEM_RUN=steps keeps the stepwise loop."""
+        import os
+        dev_mod = _native.mcem_dev() if self._on_device() else None
+        y_dim = self.y.shape[0] if self._label_in_decoder else 0
+        if (dev_mod is None or os.environ.get("DVAE_MCEM_RUN", "fused") == "steps" or self.W.dtype != torch.float32
+                or not dev_mod.decoder_supported(self.vae.decoder, y_dim) or self.W.shape[1] > 16):
+            return EM.run(self)
+        import ctypes
+        Nn = dev_mod.N
+        lib = Nn.load()
+        pk = self._decoder_pack()
+        n_e, b_e = self._e_counts()
+        nit = n_e + b_e
+        F, N = self.X_abs_2_t.shape
+        L = _latent_dim(self.vae)
+        K = self.W.shape[1]
+        dev = self.W.device
+        for nm in ("W", "H", "g", "Vb", "Z", "X_abs_2_t"):
+            setattr(self, nm, getattr(self, nm).detach().to(torch.float32).contiguous())
+        y = self.y.detach().to(torch.float32).contiguous() if self._label_in_decoder else None
+        Zs = torch.empty((N, n_e, L), dtype=torch.float32, device=dev)
+        Vs = torch.empty((n_e, F, N), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.dvae_mcem_m_step_workspace_bytes(N, K, 1), dtype=torch.uint8, device=dev)
+        cost = torch.empty(self.niter, dtype=torch.float32, device=dev)
+        args = (ctypes.byref(pk.plan), Nn.ptr(pk.weights), Nn.ptr(self.Z), Nn.ptr(y), Nn.ptr(self.g), Nn.ptr(self.Vb), Nn.ptr(self.X_abs_2_t))
+        tail = (Nn.ptr(self.W), Nn.ptr(self.H), Nn.ptr(Zs), Nn.ptr(Vs))
+        cptr, wptr, stream = cost.data_ptr(), Nn.ptr(ws), Nn.stream()
+        for it in range(self.niter):
+            # the draws of _chain, in its order (one generator stream for this loop and the stepwise one: equal results on equal seeds)
+            noise = torch.randn(nit, L, N, device=dev)
+            logu = torch.log(torch.rand(nit, N, device=dev))
+            Nn.check(lib.dvae_mcem_em_iteration(*args, Nn.ptr(noise), Nn.ptr(logu), nit, b_e, float(self.var_RW), N, K, 1,
+                                                None, None, None, *tail, cptr + 4 * it, wptr, stream), "dvae_mcem_em_iteration")
+        self.Vs = Vs
+        self._Vs_scaled = None
+        self._Vx = None
+        self._cost = cost[-1]
+        self._cached = None
+        WFs, WFn = self.compute_WF(sample=True)
+        self.S_hat = self.tensor2np(WFs.cpu()) * self.X
+        self.N_hat = self.tensor2np(WFn.cpu()) * self.X
+        return cost.cpu().numpy().astype(np.float64)
+
     def compute_Vs(self, Z):
         """Z: (N, R, L [+ y_dim]) -> self.Vs (R, F, N)."""
         if self._cached is not None and self._cached[0] is Z and self._cached[1] is not None:
@@ -264,6 +320,14 @@ class MCEM_M1(_MCEM):
         Zs = self._chain(Z, None, nsamples, burnin)
         self._cached = (Zs, self._cached_vs)
         return Zs
+
+    # quirk Q12 (reference mcem.py:207, 297-298, 314-315): E_step / compute_WF pass (Z, nsamples, burnin) into (Z, y, nsamples=10, burnin=30),
+    # so the chains keep `burnin` samples after the default burn-in of 30
+    def _e_counts(self):
+        return self.burnin_E_step, 30
+
+    def _wf_counts(self):
+        return self.burnin_WF, 30
 
     def E_step(self):
         Z_t = self.sample_posterior(self.Z, self.nsamples_E_step, self.burnin_E_step)      # sic (Q12)

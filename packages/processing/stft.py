@@ -60,11 +60,16 @@ def stft_pytorch(x,
     dev = x_.device if x_.is_cuda else H._device()
     if win != 'hann':
         raise ValueError("stft_pytorch: only win='hann' is defined (as in the reference)")
-    window = torch.hann_window(window_length=nfft).to(torch.float64).to(dev)
     xin = x_.to(dev)
     if xin.dtype not in (torch.float32, torch.float64):
         xin = xin.to(torch.float32)
-    out = torch.view_as_real(H.stft_device(xin, window, nfft, hop, T, 0))
+    if H.f32_transform_covers(xin, nfft, hop, T):
+        # torch.stft's own arithmetic for a float32 signal (window product, FFT, result: float32), computed frame-major; the [F, T, 2]
+        # result is the transpose view of that memory -- as the legacy torch.stft's was (it transposed its [T, F, 2] transform in place)
+        out = torch.view_as_real(H.stft_device_f32(xin, nfft, hop, T, 2).T)
+    else:
+        window = torch.hann_window(window_length=nfft).to(torch.float64).to(dev)
+        out = torch.view_as_real(H.stft_device(xin, window, nfft, hop, T, 0))
     return out if x.is_cuda else out.cpu()
 
 

@@ -130,3 +130,24 @@ def test_gpu_run_with_device_draws_converges_like_reference(precision):
     assert np.all(np.diff(cost) < 0.02), cost                       # EM: the expected negative log-likelihood goes down
     assert cost[1] < fix["cost"][1] * 1.1 and cost[-1] < fix["cost"][-1]
     assert np.isfinite(em.S_hat).all() and np.abs(em.S_hat + em.N_hat - X).max() < 1e-4 * np.abs(X).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", mc.CASES[:2], ids=[c["name"] for c in mc.CASES[:2]])
+def test_gpu_fused_run_equals_the_stepwise_loop(case, precision, monkeypatch):
+    """_MCEM.run on the device is one library call per EM iteration (dvae_mcem_em_iteration); DVAE_MCEM_RUN=steps keeps the reference's
+    loop structure (E_step / M_step / cost through Python, mcem.py:156-160).  Same generator seed -> the same draws in the same order
+    -> the same kernels on the same operands: costs, factors and estimates are equal bit for bit."""
+    res = {}
+    for mode in ("fused", "steps"):
+        monkeypatch.setenv("DVAE_MCEM_RUN", mode)
+        em, kw, X = make_em(dict(case, niter=5), "cuda")
+        em.precision = precision
+        torch.manual_seed(7)
+        em.init_parameters(**kw)
+        cost = em.run()
+        res[mode] = (np.asarray(cost, np.float64), em.W.cpu().numpy(), em.H.cpu().numpy(), em.g.cpu().numpy(), em.Z.cpu().numpy(), em.S_hat, em.N_hat)
+    for a, b in zip(res["fused"], res["steps"]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert res["fused"][0].shape == (5,) and np.all(np.isfinite(res["fused"][0]))

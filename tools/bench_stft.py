@@ -27,11 +27,19 @@ def main():
         Sr = H.stft_device(x, w, 1024, 256, T, 2).T
         t_i = timeit(lambda: H.istft_device(Sr, w, 1024, 256, T, 0, n))
         t_i0 = timeit(lambda: H.istft_device(S, w, 1024, 256, T, 0, n))
+        extra = {}
+        if dt == torch.float32:
+            # float32 ARITHMETIC (stft_pytorch's transform, dvae_stft_f32): bytes = 256 new fp32 samples in + 513 complex64 (or float32) out
+            t_cf = timeit(lambda: H.stft_device_f32(x, 1024, 256, T, 2))
+            t_pf = timeit(lambda: H.stft_device_f32(x, 1024, 256, T, 1))
+            extra = dict(stft_f32arith_us=t_cf * 1e6, stft_f32arith_power_us=t_pf * 1e6, stft_f32arith_GBs=T * (1024 + 4104) / t_cf / 1e9,
+                         stft_f32arith_power_GBs=T * (1024 + 2052) / t_pf / 1e9, stft_f32arith_hbm_frac=T * (1024 + 4104) / t_cf / 8e12,
+                         stft_f32arith_power_hbm_frac=T * (1024 + 2052) / t_pf / 8e12)
         inb = 256 * x.element_size()
         res[f"{secs}s_{str(dt).split('.')[-1]}"] = dict(frames=T, stft_us=t_c * 1e6, stft_bin_major_us=t_c0 * 1e6, stft_power_us=t_p * 1e6,
             istft_us=t_i * 1e6, istft_bin_major_us=t_i0 * 1e6,
             stft_Mframes_s=T / t_c / 1e6, stft_GBs=T * (inb + 4104) / t_c / 1e9, istft_Mframes_s=T / t_i / 1e6,
-            istft_GBs=T * (4104 + 1024) / t_i / 1e9)
+            istft_GBs=T * (4104 + 1024) / t_i / 1e9, **extra)
     xs = np.random.default_rng(0).standard_normal(16000 * 60)
     from scipy.signal import get_window
     win = get_window("hann", 1024, fftbins=True)
