@@ -3,6 +3,7 @@
 // values of a thread into 64-bit tuples for packed fp32 arithmetic (v_pk_fma_f32), defines the halves of a tuple at different times and
 // spills 300 - 500 registers around the loads; the packed forms are no faster on gfx950 either (MI355X_MICROARCH.md, cycle constants).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "fused_tiles.hpp"
 
@@ -11,25 +12,40 @@ namespace fused {
 
 constexpr int KMAX = 16;
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_j(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_j<I + 1, N>(f); }
+}
+
 // 1 / x for the positive, normal variances of the M-step: the hardware reciprocal (1 ulp).  The IEEE division sequence (v_div_scale x 2,
 // v_rcp, four v_fma, v_div_fmas, v_div_fixup) and even one Newton step on top of v_rcp_f32 tip hipcc's allocation of this kernel from 20
 // to 150 spilled registers (170 of a thread's 256 hold the sample variances); sums of ten such terms per bin are compared with the
 // reference at 1e-5 (tests/test_gpu_mcem.py), three orders above the reciprocal's error.
 __device__ __forceinline__ float rcp_pos(float x) { return __builtin_amdgcn_rcpf(x); }
 
-constexpr int FT16 = 512, FJ16 = 17;
+// Geometry of the frames kernel: FT16 threads = 16 frames x FG bin groups, a thread owns bins grp + FG j (j < FJ16) of one frame.
+// 512 threads / 32 groups / 17 bins (256 registers per thread).  1024 threads / 9 bins (MSTEP_FT=1024, round 5) leaves 128 registers for
+// 90 variances + the H column + 20 accumulators and spills 41 of them: slower.
+#ifndef MSTEP_FT
+#define MSTEP_FT 512
+#endif
+#ifndef MSTEP_FLY
+#define MSTEP_FLY 2      // reciprocals in flight per thread inside a bin (more: more temporaries live, see the remark at the loops)
+#endif
+constexpr int FT16 = MSTEP_FT, FG = FT16 / 16, FW = FT16 / 64, FJ16 = (513 + FG - 1) / FG;
 template <int RR, int K>
 __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int,
                                                                 const float* __restrict__ Wun_all, float* __restrict__ H, float* __restrict__ g,
                                                                 float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial,
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_count,
                                                                 const int* __restrict__ tile_seg) {
-    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [8][2K][16], then sums [2K][16]
+    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [FW][2K][16], then sums [2K][16]
     float* wpart = lw + (XD * K + 3) / 4 * 4;
-    float* sums = wpart + 8 * 2 * K * 16;
+    float* sums = wpart + FW * 2 * K * 16;
     float* x2s = sums + 2 * K * 16;                                  // [j][thread]: X2 of this thread's 17 bins (read in each of the three passes)
+    float* vlast = x2s + FJ16 * FT16;                                // [r][thread]: the sample variances of the LAST bin row (bin 512: one real bin, group 0 only)
     __shared__ float nrm[KMAX];
-    __shared__ double redc[8];
+    __shared__ double redc[FW];
     const int tid = threadIdx.x, fr = tid & 15, grp = tid >> 4, lane = tid & 63, wave = tid >> 6;
     // A workgroup's 16 frames are HALF of every 128-byte line of the (sample, bin) rows of Vs / X2 / Vb; the other half belongs to the
     // workgroup of the neighbouring 16 frames.  Workgroup i runs on XCD i % 8 (speed only, never correctness), so consecutive frame
@@ -55,30 +71,69 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     // The scalar offset is NOT part of the descriptor's range check on gfx9 (only the per-lane offset is compared with num_records), so
     // every access must be in range by construction: the one bin row past 512 that exists only for grp 0 (j = 16) is read by the other
     // groups at grp 0's own offset (voff16: a valid element whose value they never use).
-    float vs[FJ16][RR];
+    // registers: the first FJ16 - 1 bin rows (160 values); the last row -- bin 512, which only group 0 owns -- waits in thread-private LDS
+    // slots like X2: ten registers less at the peak of pass 1, which is what hipcc was short of (it spilled 12 - 13 of the variances)
+    float vs[FJ16 - 1][RR];
+    auto vsv = [&](auto jc, int r) __attribute__((always_inline)) -> float {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j == FJ16 - 1) return vlast[r * FT16 + tid]; else return vs[j][r];
+    };
     const int voff = (int)(((int64_t)grp * N + n) * 4);
     const int voff16 = (int)(n * 4);                               // bin 512 + 0: the only row of j = 16
-    const unsigned jstep = (unsigned)(32 * N * 4);
+    const unsigned jstep = (unsigned)(FG * N * 4);
     const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, (int)((int64_t)R * FN * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, (int)(FN * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(Vb, 0, (int)(FN * 4), 0x00020000);
-    // X2 of the thread's bins: requested with the sample variances, parked in LDS (thread-private slots: no barrier), read back in each pass --
-    // as a buffer load inside the passes (one bin at a time, to hold the register count) every bin paid an L2 round trip of its own
+    // Request order = arrival order (vector-memory results return in issue order): first the small operands every pass needs -- the un-normalised
+    // W for the workgroup's LDS copy, X2 of the thread's bins (parked in thread-private LDS slots, read back in each pass), the frame's H column
+    // and gain -- then the 170 sample variances, bin by bin; the small operands go to LDS once a third of the variances is requested (they have
+    // landed by then, and their registers are free again for the rest of the requests).  The workgroup barrier behind the W copy orders LDS
+    // only (s_waitcnt lgkmcnt): __syncthreads() would drain vmcnt, i.e. every pass would start only after the LAST variance had landed.
+    // Round 5 measured that serialisation (tools/r05/mstep_ablate.sh: loads alone 40 us + passes alone 61 us = the kernel's 95 us at 25
+    // utterances) and, in the ISA, what made it worse: with the variances requested FIRST and W / X2 / H behind them, hipcc ran out of the
+    // 256 registers at the end of the request stream and spilled the last 13 variances one by one as  buffer_load -> s_waitcnt vmcnt(0) ->
+    // scratch_store : thirteen exposed memory round trips per workgroup.
     auto x2_at = [&](int j) __attribute__((always_inline)) { return x2s[j * FT16 + tid]; };
+    constexpr int WCH = (XD * K + FT16 - 1) / FT16;
+    constexpr int JA = (FJ16 + 2) / 3;                              // bins requested ahead of the LDS writes
+    float wtmp[WCH], x2t[FJ16], hk[K], vlt[RR];
 #pragma unroll
-    for (int j = 0; j < FJ16; ++j) {
+    for (int c = 0; c < WCH; ++c) { const int i = tid + c * FT16; wtmp[c] = Wun[i < XD * K ? i : XD * K - 1]; }
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j)
+        x2t[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, j == FJ16 - 1 ? voff16 : voff, (int)(jstep * (unsigned)j), 0));
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+        vlt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, voff16, (int)(jstep * (unsigned)(FJ16 - 1) + (unsigned)((int64_t)(r < R ? r : 0) * FN * 4)), 0));
+#pragma unroll
+    for (int k = 0; k < K; ++k) hk[k] = H[(int64_t)k * N + n];
+    const float gn = g[n];
+    __builtin_amdgcn_sched_barrier(0);
+    auto request = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
             const unsigned soff = jstep * (unsigned)j + (unsigned)((int64_t)(r < R ? r : 0) * FN * 4);
-            vs[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, j == FJ16 - 1 ? voff16 : voff, (int)soff, 0));
+#if defined(MSTEP_ABL) && MSTEP_ABL == 2      // timing ablation: no reads of the sample variances
+            vs[j][r] = 1.0f + 0.001f * (float)(j + r + tid); (void)soff;
+#else
+            vs[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vs, voff, (int)soff, 0));
+#endif
         }
-    }
-#pragma unroll
-    for (int j = 0; j < FJ16; ++j)
-        x2s[j * FT16 + tid] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, j == FJ16 - 1 ? voff16 : voff, (int)(jstep * (unsigned)j), 0));
+    };
+    static_for_j<0, JA>(request);
     __builtin_amdgcn_sched_barrier(0);
-    for (int i = tid; i < XD * K; i += FT16) lw[i] = Wun[i];
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < WCH; ++c) { const int i = tid + c * FT16; if (i < XD * K) lw[i] = wtmp[c]; }
+#pragma unroll
+    for (int j = 0; j < FJ16; ++j) x2s[j * FT16 + tid] = x2t[j];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) vlast[r * FT16 + tid] = vlt[r];
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_j<JA, FJ16 - 1>(request);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (tid < 16 * K) {                                            // column norms of the un-normalised W (mcem.py:130): 16 threads per column
         const int k = tid >> 4, q = tid & 15;
         float s = 0.f;
@@ -86,12 +141,8 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
         s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
         if (q == 0) { nrm[k] = s; if (n0 == (seg_start ? seg_start[u] : 0)) norms_out[u * KMAX + k] = s; }
     }
-    float hk[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) hk[k] = H[(int64_t)k * N + n];
-    const float gn = g[n];
 
-    // sum over the 32 bin groups of `cnt` per-thread values: wave shuffles (4 groups per wave), LDS (8 waves)
+    // sum over the FG bin groups of `cnt` per-thread values: wave shuffles (4 groups per wave), LDS (FW waves)
     auto group_sums = [&](auto& v, int cnt) {
         constexpr int M = (int)(sizeof(v) / sizeof(float));
 #pragma unroll
@@ -107,32 +158,44 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
         if (grp < cnt) {
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) a += wpart[(w * cnt + grp) * 16 + fr];
+            for (int w = 0; w < FW; ++w) a += wpart[(w * cnt + grp) * 16 + fr];
             sums[grp * 16 + fr] = a;
         }
         __syncthreads();
     };
 
+#if defined(MSTEP_ABL) && MSTEP_ABL == 1          // timing ablation: loads only (no passes)
+    {
+        float t = gn;
+        static_for_j<0, FJ16>([&](auto jc) { t += x2_at(decltype(jc)::value);
+#pragma unroll
+            for (int r = 0; r < RR; ++r) t += vsv(jc, r); });
+#pragma unroll
+        for (int k = 0; k < K; ++k) t += hk[k];
+        if (t == 123.456f) g[n] = t;
+        return;
+    }
+#endif
     // ---- H update (mcem.py:118-123) with Vb = Wun H ----
     float acc[2 * K];
 #pragma unroll
     for (int k = 0; k < 2 * K; ++k) acc[k] = 0.f;
-#pragma unroll
-    for (int j = 0; j < FJ16; ++j) {
-        const int f = grp + 32 * j;
+    static_for_j<0, FJ16>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const int f = grp + FG * j;
         if (f < XD) {
             float vb = 0.f;
 #pragma unroll
             for (int k = 0; k < K; ++k) vb = fmaf(lw[f * K + k], hk[k], vb);
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < RR; ++r) { if (r < R) { const float inv = rcp_pos(fmaf(gn, vs[j][r], vb)); a1 += inv; a2 += inv * inv; } if (r & 1) __builtin_amdgcn_sched_barrier(0); }   // (two divisions in flight: ten interleaved IEEE sequences hold 80 temporaries)
+            for (int r = 0; r < RR; ++r) { if (r < R) { const float inv = rcp_pos(fmaf(gn, vsv(jc, r), vb)); a1 += inv; a2 += inv * inv; } if ((r % MSTEP_FLY) == MSTEP_FLY - 1) __builtin_amdgcn_sched_barrier(0); }   // (two divisions in flight: ten interleaved IEEE sequences hold 80 temporaries)
             const float p2 = x2_at(j) * a2;
 #pragma unroll
             for (int k = 0; k < K; ++k) { const float w = lw[f * K + k]; acc[2 * k] = fmaf(w, p2, acc[2 * k]); acc[2 * k + 1] = fmaf(w, a1, acc[2 * k + 1]); }
         }
         __builtin_amdgcn_sched_barrier(0);        // one bin at a time: hoisting every bin's W row above the loop costs 110 more registers
-    }
+    });
     group_sums(acc, 2 * K);
 #pragma unroll
     for (int k = 0; k < K; ++k) hk[k] = hk[k] * sqrtf(sums[(2 * k) * 16 + fr] / sums[(2 * k + 1) * 16 + fr]);
@@ -140,9 +203,9 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
 
     // ---- new Vb = Wun Hnew (mcem.py:126); g update (mcem.py:137-143) ----
     float gv[2] = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < FJ16; ++j) {
-        const int f = grp + 32 * j;
+    static_for_j<0, FJ16>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const int f = grp + FG * j;
         if (f < XD) {
             float vb = 0.f;
 #pragma unroll
@@ -150,19 +213,19 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
             if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vb), rs_vb, voff, (int)(jstep * (unsigned)j), 0);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < RR; ++r) { if (r < R) { const float v = vs[j][r]; const float inv = rcp_pos(fmaf(gn, v, vb)); s1 = fmaf(v, inv, s1); s2 = fmaf(v, inv * inv, s2); } if (r & 1) __builtin_amdgcn_sched_barrier(0); }
+            for (int r = 0; r < RR; ++r) { if (r < R) { const float v = vsv(jc, r); const float inv = rcp_pos(fmaf(gn, v, vb)); s1 = fmaf(v, inv, s1); s2 = fmaf(v, inv * inv, s2); } if ((r % MSTEP_FLY) == MSTEP_FLY - 1) __builtin_amdgcn_sched_barrier(0); }
             gv[0] = fmaf(x2_at(j), s2, gv[0]); gv[1] += s1;
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     group_sums(gv, 2);
     const float gnew = gn * sqrtf(sums[fr] / sums[16 + fr]);
 
     // ---- cost (mcem.py:69-71) with the updated g; H is stored normalised (mcem.py:134).  log through the hardware log2 (~1 ulp of log2) ----
     double c = 0.0;
-#pragma unroll
-    for (int j = 0; j < FJ16; ++j) {
-        const int f = grp + 32 * j;
+    static_for_j<0, FJ16>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const int f = grp + FG * j;
         if (f < XD) {
             float vb = 0.f;
 #pragma unroll
@@ -170,11 +233,11 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
             const float x2 = x2_at(j);
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < RR; ++r) { if (r < R) { const float vx = fmaf(gnew, vs[j][r], vb); s += __builtin_amdgcn_logf(vx) * 0.693147180559945309f + x2 * rcp_pos(vx); } if (r & 1) __builtin_amdgcn_sched_barrier(0); }
+            for (int r = 0; r < RR; ++r) { if (r < R) { const float vx = fmaf(gnew, vsv(jc, r), vb); s += __builtin_amdgcn_logf(vx) * 0.693147180559945309f + x2 * rcp_pos(vx); } if ((r % MSTEP_FLY) == MSTEP_FLY - 1) __builtin_amdgcn_sched_barrier(0); }
             c += (double)s;
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     if (!live) c = 0.0;
     c = wave_sum(c);
     if (lane == 0) redc[wave] = c;
@@ -186,7 +249,7 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
-        for (int w = 0; w < 8; ++w) t += redc[w];
+        for (int w = 0; w < FW; ++w) t += redc[w];
         partial[bid] = t;
     }
 }
@@ -272,10 +335,10 @@ namespace mstep {
 int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
     const int nt16 = (int)((N + 15) / 16);
-    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + 8 * 2 * K * 16 + 2 * K * 16 + FJ16 * FT16) * sizeof(float);
+    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + FW * 2 * K * 16 + 2 * K * 16 + FJ16 * FT16 + 10 * FT16) * sizeof(float);
     static bool attr_done16 = false;
     if (!attr_done16) {
-        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + 8 * 2 * KMAX * 16 + 2 * KMAX * 16 + FJ16 * FT16) * sizeof(float);
+        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + FW * 2 * KMAX * 16 + 2 * KMAX * 16 + FJ16 * FT16 + 10 * FT16) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_reg_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
         attr_done16 = true;

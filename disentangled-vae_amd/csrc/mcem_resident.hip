@@ -75,6 +75,39 @@ static_assert(C8_O_RED % 8 == 0 && C8_LDS <= 160 * 1024, "resident chain: LDS la
 // (the buffer load that defines it writes the AGPR directly).  The compiler does not see into the statement: the chain starts from the
 // inline constant 0 (no VALU-written SrcC), every MFMA accumulates into the one before it (same opcode, back to back), and the s_nops behind
 // the last one cover the longest XDL-write -> VALU-read distance (19 wait states) before anything outside may touch `acc`.
+//
+// Hazard table of the hand-written chain (nothing inside an asm statement is padded by hipcc; outside it adds ONE state after ;;#ASMEND
+// before a VALU that touches the outputs).  Producer -> consumer, the wait states the ISA asks for, and what provides them here:
+//
+//   | producer                                   | consumer                                        | required            | provided by                                   |
+//   |--------------------------------------------|-------------------------------------------------|---------------------|-----------------------------------------------|
+//   | v_mfma D (XDL write of acc)                | the NEXT v_mfma of the chain taking acc whole   | 0 (same opcode,     | back-to-back statements, "+v"(acc): the       |
+//   |                                            | as SrcC (accumulate chain)                      | same size SrcC = D) | hardware interlocks the dependent issue       |
+//   | last v_mfma of a tile: 32x32x16 bf16 /     | any VALU / store / LDS write reading acc, any   | 8-pass: 12 states   | s_nop 7 + s_nop 7 + s_nop 3 = 20 states       |
+//   | f16 (8 passes), 32x32x2 f32 (16 passes)    | non-MFMA writer of acc (compiler code after the | 16-pass: 18 states  | INSIDE the last statement (LAST = true) + the |
+//   |                                            | statement)                                      |                     | compiler's one state after ;;#ASMEND          |
+//   | buffer_load defining an "a" (AGPR) fragment| v_mfma reading it as SrcA                       | s_waitcnt vmcnt     | the loads are compiler-visible builtins: hipcc|
+//   |                                            |                                                 | (compiler-counted)  | waits before the first asm statement reading  |
+//   | VALU / ds_read writing a "v" B operand (bq)| v_mfma reading it as SrcB                       | VALU write: 2 states| bq comes from ds_read (lgkmcnt, compiler-     |
+//   |                                            |                                                 | (Table 38); ds_read:| counted) one k-step ahead; never VALU-written |
+//   |                                            |                                                 | lgkmcnt             | between the read and the MFMA                 |
+//   | v_accvgpr_write (hipcc parks spilled VGPRs | v_mfma reading an AGPR as SrcA                  | 2 states, and never | hipcc pads its OWN v_accvgpr_write -> MFMA    |
+//   | in the 16 AGPRs the fragments leave free:  |                                                 | into a register an  | pairs only for MFMAs it emitted; the asm MFMAs|
+//   | 80 writes / 656 reads over the 9 kernels,  |                                                 | in-flight MFMA reads| name their AGPR through "a": the allocator    |
+//   | ROCm 7.2)                                  |                                                 |                     | keeps spill slots and fragments disjoint as   |
+//   |                                            |                                                 |                     | long as 16 AGPRs stay unassigned (a full file |
+//   |                                            |                                                 |                     | made it rotate fragments through temporaries: |
+//   |                                            |                                                 |                     | the round-4 hazard, see the kernel's header)  |
+//   | VALU write of acc (bias preload)           | first v_mfma reading acc as SrcC                | 2 states            | acc is preloaded by ds_read (no VALU write);  |
+//   |                                            |                                                 |                     | the fp32 form starts from the inline 0        |
+//
+// The figures for rows 2 and 4 are the ISA's (cdna4 ISA, "MFMA dependent instruction" and "VALU write -> MFMA read" tables); 20 states cover
+// both MFMA sizes used, so the bf16 forms carry 8 states of slack.  What a compiler or flag change can break without a build error: (a) the
+// register allocator moving a fragment (a v_accvgpr_write into a register an MFMA of the chain still reads); (b) a VALU instruction that
+// writes acc scheduled between the bias ds_read and the first MFMA.  Neither shows in the build log; both show as launch-to-launch or
+// policy-to-oracle differences: tests/test_gpu_mcem.py::test_chain_launches_are_bit_identical (every policy and label variant, repeated
+// launches bit for bit) and the oracle / reference-golden tests are the guards, and tools/r05/audit_resident.sh prints the per-kernel
+// spill and v_accvgpr counts to compare after a toolchain change (ROCm 7.2: 0 - 22 spilled VGPRs, all parked in the free AGPRs).
 template <int I, int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }

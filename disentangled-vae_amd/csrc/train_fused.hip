@@ -24,6 +24,10 @@
 #include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include <tuple>
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -911,7 +915,14 @@ struct Block4 {
     int32_t raw, rncols;     // rncols: columns of the input matrix (513 / y_dim)
     int32_t rcol[4];         // first column of B tile j in the input matrix
     int32_t wt[4], bt[4], wt_hi, bt_hi;   // tensor numbers of A tile i's weight / bias rows (and of the rows >= 16 of a split tile): fold_tail
+    int32_t layer, pad_;                   // host side (w4_schedule): blocks of one emit() call share their A or their B tiles
 };
+
+// One workgroup of wgrad4_kernel = one item: block `block` over frames [kbeg, kend) into gradient slab `slice`.  The table is built on the
+// host (w4_build_items): which slices a block is cut into, and which XCD a workgroup index lands on, are scheduling decisions the kernel
+// only reads.  block < 0: an empty slot of the grid.
+struct W4Item { int32_t block, slice; int64_t kbeg, kend; };
+constexpr int W4_MAX_ITEMS = 4096;
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for_w(F&& f) {
@@ -950,8 +961,9 @@ template <typename P> struct Wg4 {
 struct RawIn { const float* x; const float* y; int ldx, ldy; int64_t B; };
 
 // BLO = false: the B tiles (labels) have no lo plane in this launch -- it is neither read nor multiplied
-template <typename P, int NA, int NB, int RAW, bool BLO = true>
-__device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __restrict__ bdg, char* wsm, int slice, int64_t Bp, int64_t spl, int64_t kper,
+// BIAS = false: no A tile of the block carries bias rows (only a layer's first B column does): no frame sums of the A fragments
+template <typename P, int NA, int NB, int RAW, bool BLO = true, bool BIAS = true>
+__device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __restrict__ bdg, char* wsm, int slice, int64_t Bp, int64_t spl, int64_t kbeg, int64_t kend_,
                                             float* __restrict__ slabs, int64_t slab_stride, int lane, int wave, const RawIn& ri) {
     typedef typename P::T T;
     typedef typename P::Frag Frag;
@@ -967,8 +979,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
     constexpr int SLD = 128 + 8, SPL = 16 * SLD;                         // staging rows: elements per frame row (odd number of 16-byte slots), per plane
     const int l31 = lane & 31, h = lane >> 5;
     // this wave's quarter of the slice's k-steps
-    const int64_t kbeg = (int64_t)slice * kper;
-    int64_t kend = kbeg + kper;
+    int64_t kend = kend_;
     if (kend > Bp) kend = Bp;
     const int64_t s0 = kbeg / KS, s1 = kend / KS;
     const int64_t nq = (s1 - s0 + 3) / 4;
@@ -1073,7 +1084,7 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
                 }
         }
     };
-    // timing ablations of the main loop (tools/r05/wgrad_ablate.sh; results are wrong under any of them): W4_NOMFMA = loads + bias sums only,
+    // timing ablations of the main loop (tools/r05/ab_libs.sh on variants built by tools/r05/mkvariant.sh; results are wrong under any of them): W4_NOMFMA = loads + bias sums only,
     // W4_NOFSUM = no bias sums, W4_NOLOAD = the ring is never refilled (MFMAs on the prologue's fragments), W4_NOEPI = no reduce-scatter / stores
     auto compute = [&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
@@ -1094,8 +1105,10 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
             for (int i = 0; i < NA; ++i) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[0][j]);
-                bs[i] += fsum(a[s][i][0]);
-                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                if constexpr (BIAS) {
+                    bs[i] += fsum(a[s][i][0]);
+                    if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                }
             }
         } else if constexpr (RAW == 1) {
 #pragma unroll
@@ -1109,10 +1122,12 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 #pragma unroll
                 for (int i = 0; i < NA; ++i) mmap<P>(c[i][j], a[s][i], bj);
             }
+            if constexpr (BIAS) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                bs[i] += fsum(a[s][i][0]);
-                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                for (int i = 0; i < NA; ++i) {
+                    bs[i] += fsum(a[s][i][0]);
+                    if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                }
             }
         } else {
 #pragma unroll
@@ -1120,8 +1135,10 @@ __device__ __forceinline__ void wgrad4_body(const Block4& bd, const Block4* __re
 #pragma unroll
                 for (int j = 0; j < NB; ++j) mmap<P>(c[i][j], a[s][i], b[s][j], BLO);
 #ifndef W4_NOFSUM
-                bs[i] += fsum(a[s][i][0]);                               // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
-                if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                if constexpr (BIAS) {
+                    bs[i] += fsum(a[s][i][0]);                           // bias gradient: frame sum of the A fragment (VALU in the MFMAs' shadow)
+                    if constexpr (NP == 2) bs[i] += fsum(a[s][i][1]);
+                }
 #endif
             }
         }
@@ -1380,8 +1397,8 @@ __device__ __forceinline__ void fold_tail(const ApplyArgs& g, const FoldArgs& fa
 #endif  // DVAE_DIAG
 
 template <typename P>
-__global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, int nblocks, int ksplit, int64_t Bp,
-                                                        int64_t spl, int64_t kper, float* __restrict__ slabs, int64_t slab_stride,
+__global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict__ blocks, const W4Item* __restrict__ items, int ksplit, int64_t Bp,
+                                                        int64_t spl, float* __restrict__ slabs, int64_t slab_stride,
                                                         const RawIn ri, int use_raw, const unsigned* __restrict__ ylo_epoch, unsigned launch_id,
                                                         const ApplyArgs fold_apply, const FoldArgs fold, int fin_block, const unsigned* fin_err) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
@@ -1395,29 +1412,21 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
             fold_apply.losses3[0] = __builtin_nanf("");              // a bounded wait of the rows kernel ran out: the update was not complete
         return;
     }
-    // Workgroup -> (slice, block), XCD-aware (workgroup i runs on XCD i % 8).  The first 8 * (ksplit / 8) slices are "pure": slice s lives
-    // on XCD s % 8 with all of its blocks, so every stash line of it crosses the fabric once.  The ksplit % 8 remaining slices are
-    // dealt out block-wise, `per` consecutive blocks (neighbours share their A tiles) of them per XCD: a few lines are fetched by
-    // more than one XCD, and in exchange the grid covers the CUs (M2 y513: 10 slices x 24 blocks = 240 workgroups, 13 k-steps per
-    // wave instead of 16 at 8 slices).
-    int slice, bi;
-    {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int a8 = ksplit >> 3, r8 = ksplit & 7;
-        const int npure = a8 * nblocks;
-        if (j < npure) { slice = xcd + 8 * (j / nblocks); bi = j % nblocks; }
-        else {
-            const int per = (r8 * nblocks + 7) >> 3;
-            const int e = xcd * per + (j - npure);
-            if (j - npure >= per || e >= r8 * nblocks) return;
-            slice = 8 * a8 + e / nblocks; bi = e % nblocks;
-        }
-    }
+    // Workgroup -> (block, slice, frames): the host's item table (w4_build_items).  Workgroup i runs on XCD i % 8 (speed only): the table
+    // keeps the items that read the same stash lines -- the blocks of a layer over the same frames -- on one XCD, and cuts every block into
+    // as many slices as its cost per k-step asks for, so that all workgroups of the one round finish together.
+    const W4Item it = items[blockIdx.x];
+    if (it.block < 0) return;
+    const int slice = it.slice, bi = it.block;
     const Block4 bd = blocks[bi];                                       // by value: wave-uniform, lives in SGPRs (a reference would be re-read after every slab store)
     int na = 0, nb = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { if (bd.At[k] != nullptr) na = k + 1; if (bd.Bt[k] != nullptr) nb = k + 1; }
-#define W4_GO(NA_, NB_, RAW_) wgrad4_body<P, NA_, NB_, RAW_>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave, ri)
+    // (BIAS = false bodies -- no frame sums of the A fragments in blocks that carry no bias rows -- exist as a template parameter and are NOT
+    // instantiated: built in round 5, the kernel with them took 34.3 us against 25.3 without, same box, alternating (their loops are
+    // tighter, 158 against 394 instructions per two k-steps, but hipcc spills 250 - 650 registers around them; tools/r05/w4_ab2.sh))
+#define W4_GO_(NA_, NB_, RAW_, BLO_) wgrad4_body<P, NA_, NB_, RAW_, BLO_, true>(bd, blocks + bi, wsm, slice, Bp, spl, it.kbeg, it.kend, slabs, slab_stride, lane, wave, ri)
+#define W4_GO(NA_, NB_, RAW_) W4_GO_(NA_, NB_, RAW_, true)
     bool raw = false;
     if constexpr (sizeof(typename P::T) == 2) raw = (use_raw & bd.raw) != 0;      // input-matrix B tiles (16-bit operand policies only); use_raw bit 0: x, bit 1: labels
     if (raw) {
@@ -1429,11 +1438,9 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
         }
     } else if (sizeof(typename P::T) == 2 && P::NP == 2 && bd.raw == 2 && ylo_epoch != nullptr && *ylo_epoch != launch_id) {
         // label-fed blocks of a launch whose label tiles all fit one bf16 plane (binary labels): hi plane only
-#define W4_GO1(NA_, NB_) wgrad4_body<P, NA_, NB_, 0, false>(bd, blocks + bi, wsm, slice, Bp, spl, kper, slabs, slab_stride, lane, wave, ri)
-        if (nb == 1) W4_GO1(4, 1);
-        else if (nb == 2) W4_GO1(4, 2);
-        else W4_GO1(4, 4);
-#undef W4_GO1
+        if (nb == 1) W4_GO_(4, 1, 0, false);
+        else if (nb == 2) W4_GO_(4, 2, 0, false);
+        else W4_GO_(4, 4, 0, false);
     } else if (na == 1) {
         if (nb == 1) W4_GO(1, 1, 0);
         else if (nb == 2) W4_GO(1, 2, 0);
@@ -1444,6 +1451,7 @@ __global__ __launch_bounds__(256, 1) void wgrad4_kernel(const Block4* __restrict
         else W4_GO(4, 4, 0);
     }
 #undef W4_GO
+#undef W4_GO_
 #ifndef W4_FOLD
 #ifdef DVAE_DIAG
 #define W4_FOLD 1      // 0: the folded optimizer tail compiled out (A/B of what its presence costs the main loop)
@@ -1552,7 +1560,7 @@ struct Layout {
     // stash (rows of Bp elements)
     int64_t xT, yT, h1T, h2T, dh1T, dh2T, dmlvT, zT, d1T, d2T, dd1T, dd2T, daT, stash_rows;
     // workspace byte offsets
-    int64_t o_tiles, o_blocks, o_blocks4, o_tensors, o_chunks, o_partials, o_flags, o_defer, o_wcopy, o_stash, o_grads, total;
+    int64_t o_tiles, o_blocks, o_blocks4, o_items4, o_tensors, o_chunks, o_partials, o_flags, o_defer, o_wcopy, o_stash, o_grads, total;
     int ntiles, nblocks, nblocks4;
 };
 // deferred optimizer step (apply_common.hpp): task table, then the arrival counters (DEFER_SHARDS lines of 128 bytes), then one line with
@@ -1617,6 +1625,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_blocks = bytes((int64_t)L.nblocks * sizeof(BlockDesc));
     L.o_blocks4 = bytes((int64_t)L.nblocks4 * sizeof(Block4));
+    L.o_items4 = bytes((int64_t)W4_MAX_ITEMS * sizeof(W4Item));
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
@@ -1671,6 +1680,8 @@ static int wgrad_form(const char* wk) {
     if (wk && strcmp(wk, "lds") == 0) return 1;
     return 4;
 }
+
+static void w4_plan_classes(dvae_train_plan_t* plan);      // (defined behind fill_tables)
 
 extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_hint, dvae_train_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr && B > 0, "train_plan: bad argument");
@@ -1739,6 +1750,19 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     }
     if (ks > 64) ks = 64;
     plan->ksplit = ks;
+    plan->reserved0 = 0;
+    // Class-sliced schedule of the weight-gradient launch (round 5; w4_class_slices): every block is cut into as many frame slices as ITS
+    // cost per k-step asks for, instead of one slice count for all.  Chosen when the library picks the slicing (no hint), for the workgroup
+    // k-split kernel; the diagnostic variants whose protocols count `ksplit` arrivals per block (folded / deferred optimizer step) and
+    // DVAE_W4_UNIFORM=1 keep the uniform table.  plan->reserved0 = workgroups of that launch (0: uniform slices), ksplit = slabs to sum.
+    // Measured (tools/r05/w4_classes_ab.sh, w4_ab2.sh; M2 y 513, 8192 frames, same box, alternating): fp32 operands 60.3 -> 53.2 us (the launch is
+    // bound by its matrix work: the model's quantity); bf16x3 25.3 -> 26.6 us and bf16 18.0 -> 19.8 us -- those launches are bound by the
+    // 85 MB they pull from the stash (4.3 TB/s), not by the heaviest blocks' MFMAs, and more slices only add slab stores.  So: class-sliced
+    // under the fp32 policy, uniform under the bf16 policies (DVAE_W4_CLASSES=1 forces it there, DVAE_W4_UNIFORM=1 switches it off).
+    const bool want_classes = getenv("DVAE_W4_CLASSES") != nullptr ? atoi(getenv("DVAE_W4_CLASSES")) != 0 : !is_bf(precision);
+    if (want_classes && ksplit_hint <= 0 && wgrad_form(getenv("DVAE_WGRAD")) == 4 && plan->Bp > 128 && getenv("DVAE_W4_UNIFORM") == nullptr &&
+        getenv("DVAE_FOLD_APPLY") == nullptr && getenv("DVAE_DEFER_APPLY") == nullptr)
+        w4_plan_classes(plan);
     Layout L;
     make_layout(*plan, L);
     plan->workspace_bytes = L.total;
@@ -1781,7 +1805,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
     auto addB = [&](int64_t row0, int N, int col0, int kind = 0) {
         for (int n0 = 0; n0 < N; n0 += 32) bb[nb++] = BBlock{row0 + n0, N - n0 < 32 ? N - n0 : 32, col0 + n0, kind, n0, N};
     };
-    int nblk = 0, nblk4 = 0;
+    int nblk = 0, nblk4 = 0, layer_id = 0;
     // 2 x 2 group of tiles: A pair starting at block i, B pair starting at block j (all-null when out of range)
     auto make_group = [&](int i, int j) {
         GroupDesc d;
@@ -1836,6 +1860,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
                 for (int j0 = r0; j0 < r1; j0 += 4) {
                     Block4 q;
                     memset(&q, 0, sizeof(q));
+                    q.layer = layer_id;
                     q.raw = bb[r0].kind; q.rncols = bb[r0].sncols;
                     for (int k = 0; k < 4; ++k) {
                         q.bias_off[k] = -1;
@@ -1867,6 +1892,7 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
             r0 = r1;
         }
         na = 0; nb = 0;
+        ++layer_id;
     };
     const int ye = p->model == DVAE_MODEL_M2 ? p->y_dim : 0, yd = p->y_dim;
     addA(L.dh1T, HD, 0, 1); addB(L.xT, XD, 0, 1); if (ye) addB(L.yT, ye, XD, 2); emit();
@@ -1928,6 +1954,10 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
 // workspace and forgets its count
 static std::mutex g_fold_mu;
 static std::unordered_map<const void*, unsigned> g_fold_seq;
+// workgroups of the weight-gradient launch of a workspace (the size of its item table, fixed by dvae_train_init)
+static std::unordered_map<const void*, int> g_w4_grid;
+static void w4_grid_put(const void* ws, int grid) { std::lock_guard<std::mutex> lk(g_fold_mu); g_w4_grid[ws] = grid; }
+static int w4_grid_get(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); auto it = g_w4_grid.find(ws); return it == g_w4_grid.end() ? -1 : it->second; }
 static unsigned fold_seq_next(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); return ++g_fold_seq[ws]; }
 static void fold_seq_reset(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_seq.erase(ws); }
 
@@ -2020,6 +2050,184 @@ static int launch_apply(const dvae_train_plan_t* plan, const Layout& L, float* p
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Host-side schedule of wgrad4_kernel: the item table (one workgroup = one item) the kernel reads.
+//
+// Uniform (plan->reserved0 == 0): `ksplit` equal frame slices for every block, workgroup -> (slice, block) by the XCD-aware index map the
+// kernel had until round 4 (slice s on XCD s % 8 for 8 * (ksplit / 8) "pure" slices, the rest dealt out block-wise).
+//
+// Class-sliced (round 5): the blocks of one launch differ by 4x in work per k-step -- 4 x 4 tiles at three MFMAs per product (48 per wave
+// and k-step), label-fed 4 x 4 blocks at two (binary labels: one operand plane), 4 x 1 / 1 x 4 edge blocks (12, bound by their operand
+// loads) -- and with one slice count for all, the launch lasted as long as its heaviest blocks while a quarter of the CUs had finished
+// (M2 y 513, 8192 frames, 10 slices: 13 k-steps x 1536 clocks on the heavy blocks, 42 % of that on the light ones).  Here every block b gets
+// s_b slices by water-filling on cost_b x k-steps: the block that would finish last is split further until the CUs are used up.  A block
+// writes slabs 0 .. s_b - 1; the slabs it never writes hold the zeros dvae_train_init put there, so the optimizer launch (and the slab
+// reduction of the multi-GPU path) keep summing plan->ksplit = max s_b slabs for every parameter, in slab order: still one deterministic sum.
+struct W4Sched { std::vector<W4Item> items; int grid = 0; };
+
+static void w4_host_blocks(const dvae_train_plan_t& p, const Layout& L, std::vector<Block4>& out) {
+    std::vector<GroupDesc> tiles((size_t)L.ntiles + 8);
+    std::vector<BlockDesc> blocks((size_t)L.nblocks + 8);
+    out.assign((size_t)L.nblocks4 + 8, Block4{});
+    TensorDesc td[DVAE_TRAIN_MAX_TENSORS];
+    memset(td, 0, sizeof(td));
+    char* const base = reinterpret_cast<char*>((uintptr_t)1 << 20);      // never dereferenced: the descriptors' pointers only say "present"
+    if (is_bf(p.precision)) fill_tables<__bf16>(&p, L, base, tiles.data(), blocks.data(), out.data(), td);
+    else fill_tables<float>(&p, L, base, tiles.data(), blocks.data(), out.data(), td);
+    out.resize((size_t)L.nblocks4);
+}
+
+// cost of one 16-frame k-step of block b for one wave, in clocks (a model: matrix-pipe time against operand-fragment pulls at one 1 KB
+// fragment per ~70 clocks and wave; the in-lane bias sums where the block carries bias rows)
+static double w4_block_cost(const dvae_train_plan_t& p, const Block4& b) {
+    int na = 0, nb = 0;
+    bool bias = b.split16 && b.bias_off_hi >= 0;
+    for (int k = 0; k < 4; ++k) { if (b.At[k]) na = k + 1; if (b.Bt[k]) nb = k + 1; bias = bias || b.bias_off[k] >= 0; }
+    const bool x3 = p.precision == DVAE_PREC_BF16X3, bf = is_bf(p.precision);
+    const bool one_plane_b = x3 && b.raw == 2 && p.rows_kernel >= 2;      // label tiles: binary labels need no lo plane (two MFMAs per product)
+    double mfma, load, fsum;
+    if (bf) {
+        mfma = (double)na * nb * (x3 ? (one_plane_b ? 2 : 3) : 1) * 32.0;
+        load = ((double)na * (x3 ? 2 : 1) + (double)nb * (x3 ? (one_plane_b ? 1 : 2) : 1)) * 70.0;
+        fsum = bias ? (double)na * (x3 ? 2 : 1) * 16 * 4 * 0.5 : 0.0;
+    } else {
+        mfma = (double)na * nb * 2 * 4 * 64.0;                            // two 8-frame k-steps of four 32 x 32 x 2 MFMAs per product
+        load = (double)(na + nb) * 2 * 70.0;
+        fsum = bias ? (double)na * 2 * 8 * 4 * 0.5 : 0.0;
+    }
+    if (b.raw != 0 && p.B >= 131072 && bf) load *= 2.0;                   // raw fp32 input tiles (large batches): twice the bytes, converted in the loop
+    return std::max(mfma, load) + 0.3 * std::min(mfma, load) + fsum;
+}
+
+static int64_t w4_kper(const dvae_train_plan_t& p, int slices) {
+    const int64_t unit = 4 * (is_bf(p.precision) ? 16 : 8);
+    return al((p.Bp + slices - 1) / slices, unit);
+}
+
+// s[b] = slices of block b (>= 1), at most `max_items` in all, at most 16 per block (the optimizer launch sums that many slabs), at
+// least 128 frames per slice
+static void w4_class_slices(const dvae_train_plan_t& p, const std::vector<Block4>& blocks, int max_items, std::vector<int>& s) {
+    const int n = (int)blocks.size();
+    s.assign(n, 1);
+    std::vector<double> cost(n);
+    for (int b = 0; b < n; ++b) cost[b] = w4_block_cost(p, blocks[b]);
+    int cap = (int)std::min<int64_t>(16, p.Bp / 128);
+    if (cap < 1) cap = 1;
+    int total = n;
+    for (;;) {
+        int worst = -1;
+        double tw = 0.0;
+        for (int b = 0; b < n; ++b) { const double t = cost[b] * (double)w4_kper(p, s[b]); if (t > tw) { tw = t; worst = b; } }
+        if (worst < 0) break;
+        int s2 = s[worst] + 1;
+        while (s2 <= cap && w4_kper(p, s2) >= w4_kper(p, s[worst])) ++s2;       // the next slice count that shortens the slices
+        if (s2 > cap || total + (s2 - s[worst]) > max_items) break;            // the block that finishes last cannot be split further
+        total += s2 - s[worst];
+        s[worst] = s2;
+    }
+}
+
+static void w4_debug_print(const dvae_train_plan_t& p, const std::vector<Block4>& blocks, const std::vector<int>& s) {
+    if (getenv("DVAE_W4_DEBUG") == nullptr) return;                        // DVAE_W4_DEBUG=1: the schedule, block by block (stderr)
+    {
+        for (int b = 0; b < (int)blocks.size(); ++b) {
+            int na = 0, nb = 0;
+            for (int k = 0; k < 4; ++k) { if (blocks[b].At[k]) na = k + 1; if (blocks[b].Bt[k]) nb = k + 1; }
+            const int64_t kper = w4_kper(p, s[b]);
+            fprintf(stderr, "dvae w4: block %2d layer %d %d x %d kind %d bias %d cost %6.0f slices %2d of %lld frames -> %.0f clocks per wave\n", b, blocks[b].layer, na, nb,
+                    blocks[b].raw, (int)(blocks[b].bias_off[0] >= 0), w4_block_cost(p, blocks[b]), (int)((p.Bp + kper - 1) / kper), (long long)kper,
+                    w4_block_cost(p, blocks[b]) * (double)kper / 64.0);
+        }
+    }
+}
+
+static void w4_plan_classes(dvae_train_plan_t* plan) {
+    dvae_train_plan_t tmp = *plan;
+    tmp.ksplit = 1;
+    Layout L0;
+    make_layout(tmp, L0);
+    std::vector<Block4> blocks;
+    w4_host_blocks(tmp, L0, blocks);
+    std::vector<int> s;
+    w4_class_slices(tmp, blocks, 256, s);
+    w4_debug_print(tmp, blocks, s);
+    int nslabs = 1, items = 0;
+    for (size_t b = 0; b < blocks.size(); ++b) {
+        const int64_t kper = w4_kper(tmp, s[b]);
+        const int eff = (int)((tmp.Bp + kper - 1) / kper);
+        nslabs = std::max(nslabs, eff);
+        items += eff;
+    }
+    plan->ksplit = nslabs;
+    plan->reserved0 = items;
+}
+
+static void w4_build_items(const dvae_train_plan_t& p, const Layout& L, W4Sched& out) {
+    out.items.clear();
+    if (p.reserved0 <= 0) {
+        // uniform slices, the round-2 index map
+        const int64_t kper = w4_kper(p, p.ksplit);
+        const int ks = (int)((p.Bp + kper - 1) / kper), nblocks = L.nblocks4;
+        const int a8 = ks >> 3, r8 = ks & 7, npure = a8 * nblocks, per = (r8 * nblocks + 7) >> 3;
+        out.grid = 8 * (a8 * nblocks + per);
+        for (int w = 0; w < out.grid; ++w) {
+            const int xcd = w & 7, j = w >> 3;
+            W4Item it{-1, 0, 0, 0};
+            if (j < npure) { it.slice = xcd + 8 * (j / nblocks); it.block = j % nblocks; }
+            else {
+                const int e = xcd * per + (j - npure);
+                if (j - npure < per && e < r8 * nblocks) { it.slice = 8 * a8 + e / nblocks; it.block = e % nblocks; }
+            }
+            if (it.block >= 0) { it.kbeg = (int64_t)it.slice * kper; it.kend = std::min<int64_t>(it.kbeg + kper, p.Bp); }
+            out.items.push_back(it);
+        }
+        return;
+    }
+    std::vector<Block4> blocks;
+    w4_host_blocks(p, L, blocks);
+    dvae_train_plan_t tmp = p;
+    std::vector<int> s;
+    w4_class_slices(tmp, blocks, 256, s);
+    struct It { W4Item it; double cost; };
+    // items that read the same stash lines -- the blocks of one layer cut the same way, over the same frames -- form a group: one XCD
+    std::map<std::tuple<int, int64_t, int>, std::vector<It>> groups;
+    for (int b = 0; b < (int)blocks.size(); ++b) {
+        const int64_t kper = w4_kper(p, s[b]);
+        const int eff = (int)((p.Bp + kper - 1) / kper);
+        const double c = w4_block_cost(p, blocks[b]);
+        for (int i = 0; i < eff; ++i) {
+            W4Item it{b, i, (int64_t)i * kper, std::min<int64_t>((int64_t)(i + 1) * kper, p.Bp)};
+            groups[std::make_tuple(blocks[b].layer, kper, i)].push_back(It{it, c * (double)(it.kend - it.kbeg)});
+        }
+    }
+    std::vector<std::vector<It>> gl;
+    for (auto& kv : groups) gl.push_back(kv.second);
+    auto gcost = [](const std::vector<It>& g) { double t = 0; for (const It& i : g) t += i.cost; return t; };
+    std::stable_sort(gl.begin(), gl.end(), [&](const std::vector<It>& a, const std::vector<It>& b) { return gcost(a) > gcost(b); });
+    std::vector<It> lists[8];
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int cap = 32;                                                   // CUs of an XCD: one round of workgroups
+    auto lightest = [&](int need) { int best = -1; for (int x = 0; x < 8; ++x) if ((int)lists[x].size() + need <= cap && (best < 0 || load[x] < load[best])) best = x; return best; };
+    for (auto& g : gl) {
+        int x = lightest((int)g.size());
+        if (x >= 0) { for (const It& i : g) { lists[x].push_back(i); load[x] += i.cost; } continue; }
+        for (const It& i : g) {                                           // no XCD has room for the whole group: item by item
+            x = lightest(1);
+            if (x < 0) { x = 0; for (int q = 1; q < 8; ++q) if (lists[q].size() < lists[x].size()) x = q; }      // (more than 256 items: cannot happen by construction)
+            lists[x].push_back(i); load[x] += i.cost;
+        }
+    }
+    size_t maxlen = 0;
+    for (int x = 0; x < 8; ++x) {
+        std::stable_sort(lists[x].begin(), lists[x].end(), [](const It& a, const It& b) { return a.cost > b.cost; });      // longest first
+        maxlen = std::max(maxlen, lists[x].size());
+    }
+    out.grid = (int)(8 * maxlen);
+    out.items.assign((size_t)out.grid, W4Item{-1, 0, 0, 0});
+    for (int x = 0; x < 8; ++x)
+        for (size_t q = 0; q < lists[x].size(); ++q) out.items[q * 8 + x] = lists[x][q].it;
+}
+
 extern "C" int dvae_train_repack(const dvae_train_plan_t* plan, const float* params, void* ws, void* stream) {
     DVAE_CHECK_ARG(plan && params && ws, "train_repack: bad argument");
     DVAE_CHECK_ARG(!defer_state_get(ws).pending, "train_repack: an optimizer update is pending on this workspace (dvae_train_step_deferred): call dvae_train_flush BEFORE writing parameters");
@@ -2050,6 +2258,10 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
     hipError_t e5 = hipMemcpyAsync(w + L.o_blocks, blocks, (size_t)L.nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, s);
     hipError_t e6 = hipMemcpyAsync(w + L.o_blocks4, blocks4, (size_t)L.nblocks4 * sizeof(Block4), hipMemcpyHostToDevice, s);
+    W4Sched sched;
+    w4_build_items(*plan, L, sched);
+    DVAE_CHECK_ARG(sched.grid <= W4_MAX_ITEMS && (plan->reserved0 <= 0 || sched.grid >= plan->reserved0 / 1), "train_init: weight-gradient schedule of %d workgroups does not fit the item table", sched.grid);
+    hipError_t e8 = hipMemcpyAsync(w + L.o_items4, sched.items.data(), sched.items.size() * sizeof(W4Item), hipMemcpyHostToDevice, s);
     const int64_t nchunks = plan->n_params / 64;
     unsigned char* ct = new unsigned char[nchunks + 64];
     memset(ct, 255, (size_t)nchunks + 64);
@@ -2068,7 +2280,8 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     delete[] blocks;
     delete[] blocks4;
     delete[] ct;
-    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e6); DVAE_HIP(e7); DVAE_HIP(e3);
+    DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e6); DVAE_HIP(e7); DVAE_HIP(e8); DVAE_HIP(e3);
+    w4_grid_put(ws, sched.grid);
     return dvae_train_repack(plan, params, ws, stream);
 }
 
@@ -2280,8 +2493,10 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     if (rc) return rc;
     if (g_eval_only || a.mode == 1) return 0;
     const int64_t kper = kper_of(plan);
-    const int ks = (int)((plan->Bp + kper - 1) / kper);
+    const int ks = plan->reserved0 > 0 ? plan->ksplit : (int)((plan->Bp + kper - 1) / kper);      // slabs the launch fills (class-sliced: the largest slice count)
     DVAE_CHECK_ARG(ks <= plan->ksplit, "train_grads: internal k-split mismatch");
+    DVAE_CHECK_ARG(plan->reserved0 <= 0 || wgrad_form(getenv("DVAE_WGRAD")) == 4,
+                   "train_grads: the plan was made for the workgroup k-split weight-gradient kernel (class-sliced schedule); DVAE_WGRAD changed since");
     float* slabs = (float*)(w + L.o_grads);
     // DVAE_WGRAD=lds selects the workgroup-blocked kernel for the bf16 policies (operands staged once per 4 x 4 block in LDS: half the
     // L2 -> CU operand traffic).  Measured (M2 y513, 8192 frames): 39.3 vs 32.9 us under bf16x3, 25.0 vs 21.4 us under bf16 -- SLOWER than the
@@ -2293,7 +2508,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     for (int rep = 0; rep < wrep; ++rep)
     if (wgrad_form(wk) == 4 && (plan->Bp > 128 || raw_inputs || wk != nullptr)) {      // one 128-frame slice: the 2 x 2 kernel's short epilogue wins (11.2 vs 12.8 us)
         ProfScope ps(s, rep == 0 ? 1 : 2);
-        const dim3 g3((unsigned)(8 * ((ks >> 3) * L.nblocks4 + (((ks & 7) * L.nblocks4 + 7) >> 3))));   // see the index map at the top of wgrad4_kernel
+        const int w4grid = w4_grid_get(w);
+        DVAE_CHECK_ARG(w4grid > 0, "train_grads: workspace was not set up by dvae_train_init");
+        const dim3 g3((unsigned)w4grid);                                  // one workgroup per item of the host's table (w4_build_items)
         RawIn ri;
         ri.x = x; ri.y = y; ri.ldx = ldx; ri.ldy = plan->y_dim ? ldy : 0; ri.B = plan->B;
         const int use_raw = raw_mask;
@@ -2309,12 +2526,13 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             attr_done[dev][pi] = true;
         }
         const Block4* bl = (const Block4*)(w + L.o_blocks4);
+        const W4Item* w4items = (const W4Item*)(w + L.o_items4);
         // the optimizer step in this launch's tail (dvae_train_step asked for it): only when every workgroup of the grid is resident at
         // once -- one per CU, the tail's wait depends on it -- and the block counters fit the flag header
         ApplyArgs fa_apply;
         memset(&fa_apply, 0, sizeof(fa_apply));
         FoldArgs fold{nullptr, 0u, 0u};
-        if (g_fold.want && wrep == 1 && a.mode == 0 && ks > 1 && ks <= 16 && L.nblocks4 <= FOLD_MAXB && (int)g3.x <= device_cu_count(dev)) {
+        if (g_fold.want && plan->reserved0 <= 0 && wrep == 1 && a.mode == 0 && ks > 1 && ks <= 16 && L.nblocks4 <= FOLD_MAXB && (int)g3.x <= device_cu_count(dev)) {
             fa_apply = make_apply_args(plan, L, g_fold.params, g_fold.m, g_fold.v, w, ks, true, g_fold.step, g_fold.lr, g_fold.beta1, g_fold.beta2,
                                        g_fold.adam_eps, 1.0, g_fold.losses3);
             fold.cnt = (unsigned*)(w + L.o_flags);
@@ -2331,9 +2549,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             fin_block = (int)g3.x; fin_err = a.defer.err;
             g3l = dim3(g3.x + 1);
         }
-        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3l, dim3(256), Wg4<PolX3>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id, fa_apply, fold, fin_block, fin_err);
-        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3l, dim3(256), Wg4<PolBF16>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
-        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3l, dim3(256), Wg4<PolF32>::BYTES, s, bl, L.nblocks4, ks, plan->Bp, a.spl, kper, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
+        if (x3) hipLaunchKernelGGL((wgrad4_kernel<PolX3>), g3l, dim3(256), Wg4<PolX3>::BYTES, s, bl, w4items, ks, plan->Bp, a.spl, slabs, plan->n_params, ri, use_raw, a.ylo_skip ? a.ylo_epoch : nullptr, a.launch_id, fa_apply, fold, fin_block, fin_err);
+        else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3l, dim3(256), Wg4<PolBF16>::BYTES, s, bl, w4items, ks, plan->Bp, a.spl, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
+        else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3l, dim3(256), Wg4<PolF32>::BYTES, s, bl, w4items, ks, plan->Bp, a.spl, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
         DVAE_LAUNCH_OK("wgrad4_kernel");
 #ifdef DVAE_DIAG
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
@@ -2377,6 +2595,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
 }
 
 static int used_slabs(const dvae_train_plan_t* plan) {
+    if (plan->reserved0 > 0) return plan->ksplit;                        // class-sliced schedule: the largest slice count of any block
     const int64_t kper = kper_of(plan);
     return (int)((plan->Bp + kper - 1) / kper);
 }

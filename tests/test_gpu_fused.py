@@ -147,6 +147,41 @@ def test_fused_step_vs_oracle(model, y_dim, B, precision):
         assert np.all(np.isfinite(pn[k]))
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("model,y_dim,B", [("M2", 513, 8192), ("M2_info", 1, 2000), ("M1", 0, 300), ("M2", 1, 20000)])
+def test_class_sliced_weight_gradient_schedule_equals_the_uniform_one(model, y_dim, B, precision, monkeypatch):
+    """The weight-gradient launch reads a host-built item table (csrc/train_fused.hip: w4_build_items).  Class-sliced (default under the fp32
+    policy, DVAE_W4_CLASSES=1 elsewhere): every block of 32 x 32 tiles is cut into as many frame slices as its cost per k-step asks for and
+    writes only its own first slabs -- the others keep the zeros of dvae_train_init.  Against the uniform table (DVAE_W4_UNIFORM=1): the same
+    losses bit for bit (the rows kernel is untouched), gradients equal up to the order of the slab sums, over three steps on one workspace
+    (a slab that held anything but zeros would show from the second step on), and the class-sliced run is deterministic."""
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 5)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    batches = [gu.make_batch(dims, B, 60 + i) for i in range(3)]
+    res = {}
+    for mode in ("uniform", "classes", "classes2"):
+        monkeypatch.delenv("DVAE_W4_UNIFORM", raising=False); monkeypatch.delenv("DVAE_W4_CLASSES", raising=False)
+        monkeypatch.setenv("DVAE_W4_UNIFORM" if mode == "uniform" else "DVAE_W4_CLASSES", "1")
+        tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+        assert (tr.plan.reserved0 > 0) == (mode != "uniform")
+        out = []
+        for x, y, e in batches:
+            losses = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+            out.append((losses, tr.grads_numpy()))
+        res[mode] = (out, tr.state_dict_numpy())
+    for i, ((lu, gu_), (lc, gc), (lc2, gc2)) in enumerate(zip(res["uniform"][0], res["classes"][0], res["classes2"][0])):
+        assert np.array_equal(lc, lc2) and all(np.array_equal(gc[k], gc2[k]) for k in gc)
+        if i == 0:
+            assert np.array_equal(lc[:3], lu[:3])
+        np.testing.assert_allclose(lc[:3], lu[:3], rtol=1e-5)      # steps 2, 3 start from parameters that differ where Adam's first steps are sign-like
+        for k in gu_:
+            assert _relmax(gc[k], gu_[k].astype(np.float64)) < (2e-6 if i == 0 else 2e-3), (i, k)
+    for k in res["uniform"][1]:
+        assert np.max(np.abs(res["uniform"][1][k] - res["classes"][1][k])) <= 2.1e-4     # three Adam steps at lr 1e-4, sign-like where |g| ~ eps
+        assert np.array_equal(res["classes"][1][k], res["classes2"][1][k])
+
+
 def test_fused_is_deterministic_and_ksplit_invariant():
     dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
     params = gu.make_params("M2", dims, 3)
