@@ -14,16 +14,19 @@
 // and two flag hops, against RCCL's generic ring / tree for a 1.2 MB message.
 //
 // Waits: phase B waits for `ready` == k * G of EVERY rank (its own included) and phase C for own `done` == k * G * world, so a launch
-// completes only once all G workgroups of every rank have run phase A and phase B -- the 64 workgroups of a rank need not be resident
-// TOGETHER (no workgroup waits for a counter only later workgroups of its own launch could raise before it has added to it itself),
-// but a rank whose launch is starved of CUs for longer than the bound (other streams or processes holding the chip) times out like a
-// missing peer.  Every wait is bounded by WALL TIME (s_memrealtime, 100 MHz; dvae_comm_set_timeout_ms, default 20 s, env
+// completes only once all G workgroups of every rank have run phase A and phase B.  No workgroup waits for a counter before it has added
+// to it itself, so there is no wait cycle inside a launch -- but phase B of every workgroup DOES wait for its own rank's `ready` == k * G,
+// i.e. for all G = 64 workgroups of the launch to have STARTED: they must all become resident within the bound (64 of 256 CUs; a launch
+// that shares the chip with other streams or processes and gets fewer than 64 workgroup slots for longer than the bound spins it out and
+// times out like a missing peer -- status non-zero on every rank, NaN result, sticky for the life of the communicator).  Every wait is bounded by WALL TIME (s_memrealtime, 100 MHz; dvae_comm_set_timeout_ms, default 20 s, env
 // DVAE_COMM_TIMEOUT_MS): when the bound expires the launch stores a non-zero status into the header of EVERY rank, still adds to the
 // `done` counters (nobody waits a second bound for it) and ends; every rank that sees a non-zero status -- its own or a peer's -- fills
 // `out` with NaN, so the failure is in-band (the optimizer step that follows turns the parameters and every later loss into NaN) and
 // dvae_comm_status() reports it -- a missing or late peer is an error, never a hang and never a silently stale gradient.
 // Buffer reuse across calls: a rank leaves phase C only after every peer has finished reading its send[] (their `done` adds come
 // after their phase-B reads), and a peer starts pushing call k + 1 into recv[] only after this rank's phase A of call k + 1.
+#include <stdio.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <unistd.h>
 #include "common.hpp"
@@ -159,7 +162,20 @@ struct HandleBlob {
     long long pid;
     void* local;                  // valid inside process `pid` only
     int pci_domain, pci_bus, pci_device, pad;
+    unsigned long long nonce;     // drawn once per process: two ranks in different PID namespaces (one container per rank) may share a pid
 };
+
+// this process's identity beyond its pid (ranks in separate PID namespaces can both be pid 1): 64 random bits drawn at first use
+static unsigned long long process_nonce() {
+    static unsigned long long v = [] {
+        unsigned long long r = 0;
+        FILE* f = fopen("/dev/urandom", "rb");
+        if (f) { if (fread(&r, sizeof(r), 1, f) != 1) r = 0; fclose(f); }
+        if (r == 0) r = ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)&r ^ 0x9e3779b97f4a7c15ull;
+        return r;
+    }();
+    return v;
+}
 static_assert(sizeof(HandleBlob) <= DVAE_IPC_HANDLE_BYTES, "handle blob size");
 
 static int64_t pad_n(int64_t n, int world, int64_t* shard) {
@@ -201,7 +217,7 @@ extern "C" int dvae_comm_create(int rank, int world, int64_t n_floats, dvae_comm
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
     if (e != hipSuccess) { (void)hipFree(c->local); free(c); set_error("comm_create: %s", hipGetErrorString(e)); return (int)e; }
-    hb.pid = (long long)getpid(); hb.local = c->local;
+    hb.pid = (long long)getpid(); hb.local = c->local; hb.nonce = process_nonce();
     hb.pci_domain = prop.pciDomainID; hb.pci_bus = prop.pciBusID; hb.pci_device = prop.pciDeviceID;
     memset(handle, 0, DVAE_IPC_HANDLE_BYTES);
     memcpy(handle, &hb, sizeof(hb));
@@ -237,7 +253,7 @@ extern "C" int dvae_comm_connect(dvae_comm_t* c, const unsigned char* handles /*
             DVAE_HIP(hipDeviceCanAccessPeer(&can, c->device, pdev));
             DVAE_CHECK_ARG(can != 0, "comm_connect: device %d (rank %d) cannot access device %d (rank %d): no peer path between them", c->device, c->rank, pdev, p);
         }
-        if (hb.pid == (long long)getpid()) {           // a rank hosted by this same process: its pointer is valid here as it is
+        if (hb.pid == (long long)getpid() && hb.nonce == process_nonce()) {      // a rank hosted by this same process (pid AND nonce): its pointer is valid here as it is
             if (pdev >= 0 && pdev != c->device) {
                 hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("comm_connect: hipDeviceEnablePeerAccess(%d): %s", pdev, hipGetErrorString(e)); return (int)e; }

@@ -312,8 +312,34 @@ class Trainer:
             self.bad_rows.zero_()
         return n
 
+    # bf16x3 on the 8-wave rows kernel: the x block of encoder layer 1 (and of the M2_info classifier) multiplies split-FP16 planes with FIXED
+    # scales, x * 2^-3 and W * 2^6 (csrc/fused_tiles.hpp: struct X16): finite for |x| <= 5.2e5 (twice what a peak-normalised 1024-point Hann
+    # frame can hold) and |w| <= 1023.  The reference takes any float32 (e.g. spectra of int16-scaled audio, up to ~1e9): beyond the range the
+    # planes overflow and the losses turn NaN.  So the range is CHECKED -- on the first step of a trainer and on request -- and a violation is
+    # an error that says what to do, not a NaN three steps later.
+    X16_MAX_X, X16_MAX_W = 5.2e5, 1023.0
+
+    def check_operand_range(self, x):
+        """Raises ValueError when x (the batch, or the frame store it is gathered from) or the layer-1 weights leave the range of the
+        split-fp16 planes of the bf16x3 policy.  Synchronises (two reductions and one read-back); step() calls it once, on the first step."""
+        if self.precision != "bf16x3" or self.plan.rows_kernel != 2:
+            return
+        first = [0] + ([14] if self.model == "M2_info" else [])
+        wmax = max(float(self.tensor_view(i)[:, :513].abs().amax().item()) for i in first)
+        xmax = float(x.abs().amax().item())
+        if not (xmax <= self.X16_MAX_X and wmax <= self.X16_MAX_W):          # (NaN fails the comparison too)
+            raise ValueError(f"precision='bf16x3': inputs up to {xmax:.3g} / layer-1 weights up to {wmax:.3g} leave the range of the fixed-scale split-fp16 "
+                             f"planes of the layer-1 x block (|x| <= {self.X16_MAX_X:g}, |w| <= {self.X16_MAX_W:g}): rescale the spectra (the reference's "
+                             "front end peak-normalises the audio, scripts/create_train_set.py:138-140) or use precision='fp32', which takes any float32")
+
+    _range_checked = False
+
     def step(self, x, y=None, eps_noise=None, rows=None):
         self._check_inputs(x, y, rows, eps_noise)
+        if not self._range_checked:
+            self._range_checked = True
+            if os.environ.get("DVAE_RANGE_CHECK", "1") != "0":
+                self.check_operand_range(x)
         x = x if x.stride(1) == 1 else x.contiguous()
         if eps_noise is not None:           # None: the rows kernel draws the noise itself (Philox, see noise())
             eps_noise = eps_noise.contiguous()

@@ -1124,3 +1124,30 @@ def test_folded_optimizer_tail_never_hangs_when_its_wait_runs_out(monkeypatch):
     monkeypatch.delenv("DVAE_FOLD_MAX_POLLS")
     tr2 = trainer.Trainer("M2", dims, params, batch=8192, precision="bf16x3")      # a fresh workspace is unaffected
     assert np.all(np.isfinite(tr2.step(t(x), t(y), t(e)).cpu().numpy()))
+
+
+def test_operand_range_of_the_split_fp16_planes_is_checked(monkeypatch):
+    """bf16x3 multiplies the x block of encoder layer 1 on split-FP16 planes with fixed scales (finite for |x| <= 5.2e5, |w| <= 1023;
+    csrc/fused_tiles.hpp: X16).  The reference (fp32 torch) takes any float32 -- spectra of int16-scaled audio reach 1e9 -- so a batch or a
+    weight beyond the range is an ERROR on the trainer's first step, with the way out in the message; the fp32 policy takes the same batch;
+    with the check switched off (DVAE_RANGE_CHECK=0) the step runs and its losses are not finite (what the check is there to prevent)."""
+    dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params("M2", dims, 3)
+    x, y, e = gu.make_batch(dims, 256, 4)
+    t = lambda a: torch.from_numpy(a).cuda()
+    big = t(x) * 1.0e6
+    tr = trainer.Trainer("M2", dims, params, batch=256, precision="bf16x3")
+    with pytest.raises(ValueError, match="split-fp16"):
+        tr.step(big, t(y), t(e))
+    tr = trainer.Trainer("M2", dims, params, batch=256, precision="bf16x3")
+    assert np.all(np.isfinite(tr.step(t(x), t(y), t(e)).cpu().numpy()[:3]))           # in range: fine, and checked only once
+    wbig = {k: v.copy() for k, v in params.items()}
+    wbig["encoder.hidden.0.weight"][3, 7] = 5000.0
+    tr = trainer.Trainer("M2", dims, wbig, batch=256, precision="bf16x3")
+    with pytest.raises(ValueError, match="layer-1 weights"):
+        tr.step(t(x), t(y), t(e))
+    tr = trainer.Trainer("M2", dims, params, batch=256, precision="fp32")
+    assert np.all(np.isfinite(tr.step(big, t(y), t(e)).cpu().numpy()[:3]))
+    monkeypatch.setenv("DVAE_RANGE_CHECK", "0")
+    tr = trainer.Trainer("M2", dims, params, batch=256, precision="bf16x3")
+    assert not np.all(np.isfinite(tr.step(big, t(y), t(e)).cpu().numpy()[:3]))
