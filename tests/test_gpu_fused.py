@@ -557,12 +557,14 @@ def test_fused_m2info_matches_reference_vectors(vae_golden, name):
     check_case(FusedInfoImpl("fp32"), vae_golden, case)
 
 
+@pytest.mark.parametrize("seed", [31, 77, 123])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
-def test_fused_m2info_vs_oracle_full_batch(precision):
+def test_fused_m2info_vs_oracle_full_batch(precision, seed):
+    """(three parameter / batch draws since round 5: the raw-batch bound no longer rests on one seed)"""
     dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
     B = 8192
-    params = gu.make_params("M2_info", dims, 31)
-    x, y, e = gu.make_batch(dims, B, 32)
+    params = gu.make_params("M2_info", dims, seed)
+    x, y, e = gu.make_batch(dims, B, seed + 1)
     # float32 oracle, like the reference: the classifier sees raw power spectra up to 1e4, its sigmoid saturates to
     # exactly 1.0f and log(1 - p + eps) then depends on the arithmetic width (fp64 would differ by 3e-3 here)
     p32 = {k: v.astype(np.float32) for k, v in params.items()}
@@ -591,7 +593,10 @@ def test_fused_m2info_vs_oracle_full_batch(precision):
         if relu_net and precision != "bf16":
             rows = np.sort(err.reshape(err.shape[0], -1).max(axis=1))[::-1]
             assert rows[0] < 1e-2, (k, rows[:3])
-            assert (rows >= tol).sum() <= 2, (k, rows[:4])
+            # a flip in ONE unit of this layer: at most two rows beyond the bound.  A flip one layer DOWNSTREAM moves every row of this
+            # layer's gradient a little (seed 123 under the exact-fp32 policy: 45 rows of the classifier's first layer between 1e-4 and
+            # 6.6e-4, none above): then every row must stay under 1e-3
+            assert (rows >= tol).sum() <= 2 or rows[0] < 1e-3, (k, rows[:4])
             worst_clean = max(worst_clean, float(rows[rows < tol].max()) if (rows < tol).any() else 0.0)
         else:
             assert err.max() < tol, k
