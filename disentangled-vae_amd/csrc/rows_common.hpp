@@ -223,13 +223,35 @@ __device__ __forceinline__ void load_rows_to_lds(const float* __restrict__ src, 
 // dwordx4 loads at dword alignment.  Column 512 of row (t & 31) rides in slot 16.
 constexpr int NQ513 = 17;
 struct __attribute__((packed, aligned(4))) F4U { f32x4 v; };
+// R2_IN_NT (round 5): 1 = the step's x / label tiles are requested non-temporally (each byte is used once, while the weight copies every CU of
+// the XCD streams should stay in the 4 MB L2 beside them); 2 = the loss epilogue's re-read of x as well.  Measured SLOWER, same box, three rounds
+// (profiles/r05_rows_nontemporal_inputs_ab.txt): rows kernel 43.5 -> 48.7 (1) -> 51.3 us (2) -- the nt loads themselves take longer than the L2
+// lines they spare are worth; the default policy stays
+#ifndef R2_IN_NT
+#define R2_IN_NT 0
+#endif
+typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+__device__ __forceinline__ f32x4 ld_in4(const float* p) {
+#if R2_IN_NT >= 1
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4_a4*>(p));
+#else
+    return reinterpret_cast<const F4U*>(p)->v;
+#endif
+}
+__device__ __forceinline__ f32x4 ld_in4_again(const float* p) {
+#if R2_IN_NT >= 2
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4_a4*>(p));
+#else
+    return reinterpret_cast<const F4U*>(p)->v;
+#endif
+}
 // chunks [I0, I1) of the tile (16 chunks of 4 columns per thread; slot 16 = column 512: tile513_issue_last)
 template <int I0, int I1, typename RowOf>
 __device__ __forceinline__ void tile513_issue_part(const float* __restrict__ base, RowOf rowof, f32x4 (&v)[NQ513], int tid) {
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
         const int c = tid + 256 * i;
-        v[i] = reinterpret_cast<const F4U*>(base + rowof(c >> 7) * XD + 4 * (c & 127))->v;
+        v[i] = ld_in4(base + rowof(c >> 7) * XD + 4 * (c & 127));
     }
 }
 template <typename RowOf>

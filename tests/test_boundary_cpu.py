@@ -174,6 +174,36 @@ def test_train_plan_is_host_only_and_consistent(model, y_dim, precision):
     assert plan.ksplit == 5
 
 
+@pytest.mark.parametrize("model,y_dim", [("M1", 0), ("M2", 1), ("M2", 513), ("M2_info", 1)])
+def test_weight_gradient_schedule_of_the_plan(model, y_dim, monkeypatch):
+    """The weight-gradient launch reads a host-built item table; the plan says which: reserved0 = 0 -> `ksplit` uniform slices;
+    reserved0 > 0 -> class-sliced (every block of tiles cut by its own cost per k-step; reserved0 = workgroups, ksplit = the largest
+    slice count = slabs the optimizer launch sums).  Class-sliced is the default under the exact-fp32 policy only (measured: DESIGN 4a),
+    DVAE_W4_CLASSES / DVAE_W4_UNIFORM override, an explicit slice hint or a batch of one 128-frame slice is always uniform; one round of
+    workgroups (<= 256 items), <= 16 slabs, >= 128 frames per slice."""
+    T = importlib.import_module("disentangled-vae_amd.trainer")
+    lib = native.load()
+    for k in ("DVAE_W4_CLASSES", "DVAE_W4_UNIFORM", "DVAE_WGRAD", "DVAE_FOLD_APPLY", "DVAE_DEFER_APPLY"):
+        monkeypatch.delenv(k, raising=False)
+
+    def plan(prec, B, hint=0):
+        p = T.TrainPlan()
+        native.check(lib.dvae_train_plan(T.MODEL_CODE[model], y_dim, T.PREC_CODE[prec], B, hint, ctypes.byref(p)), "dvae_train_plan")
+        return p
+    for B in (300, 8192, 262144):
+        assert plan("bf16x3", B).reserved0 == 0 and plan("bf16", B).reserved0 == 0
+        p = plan("fp32", B)
+        assert 0 < p.reserved0 <= 256 and 1 <= p.ksplit <= 16 and p.ksplit <= p.Bp // 128
+        assert p.workspace_bytes - p.grad_offset_bytes >= p.ksplit * p.n_params * 4
+        assert plan("fp32", B, hint=6).reserved0 == 0 and plan("fp32", B, hint=6).ksplit == 6
+    assert plan("fp32", 100).reserved0 == 0                      # one 128-frame slice: nothing to schedule
+    monkeypatch.setenv("DVAE_W4_CLASSES", "1")
+    p = plan("bf16x3", 8192)
+    assert 0 < p.reserved0 <= 256 and p.ksplit <= 16
+    monkeypatch.setenv("DVAE_W4_UNIFORM", "1")
+    assert plan("bf16x3", 8192).reserved0 == 0 and plan("fp32", 8192).reserved0 == 0
+
+
 def test_train_plan_m2_dec_exists_for_the_8_wave_kernel_only(monkeypatch):
     """Kernel model M2_DEC (encoder on x alone, decoder on [z | y]: the VAE body of DeepGenerativeModel_v3 / _v5 on the module
     path): same 14 tensors as M2 with a 513-wide first encoder layer; y_dim 1 and the split-bf16 / bf16 policies only -- anything

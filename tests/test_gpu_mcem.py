@@ -189,6 +189,22 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(RuntimeError):
         mcem_dev.m_step_(t(X2), torch.ones((2, 513, 8), device="cuda"), torch.ones((513, 17), device="cuda"),
                          torch.ones((17, 8), device="cuda"), t(g), t((W @ H)))   # K > 16
+    # dvae_mcem_em_iteration (one EM iteration per call): missing scratch / bad chain lengths are codes with a message, never a launch
+    import ctypes
+    N = importlib.import_module("disentangled-vae_amd.native")
+    lib = N.load()
+    Zd, gd, Vb, X2d, yd = t(Z), t(g), t(W @ H).contiguous(), t(X2), t(y)
+    Wd, Hd = t(W).contiguous(), t(H).contiguous()
+    Zs = torch.empty((8, 3, 16), device="cuda"); Vs = torch.empty((3, 513, 8), device="cuda"); cost = torch.empty(1, device="cuda")
+    ws = torch.empty(lib.dvae_mcem_m_step_workspace_bytes(8, W.shape[1], 1), dtype=torch.uint8, device="cuda")
+    call = lambda zs, nit, burnin: lib.dvae_mcem_em_iteration(ctypes.byref(pack.plan), N.ptr(pack.weights), N.ptr(Zd), N.ptr(yd), N.ptr(gd), N.ptr(Vb),
+                                                               N.ptr(X2d), N.ptr(noise), N.ptr(logu), nit, burnin, 0.01, 8, W.shape[1], 1, None, None, None,
+                                                               N.ptr(Wd), N.ptr(Hd), zs, N.ptr(Vs), N.ptr(cost), N.ptr(ws), N.stream())
+    assert call(None, 4, 1) != 0 and "Zs" in lib.dvae_last_error().decode()
+    assert call(N.ptr(Zs), 4, 4) != 0                                          # nothing kept
+    assert call(N.ptr(Zs), 4, 1) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(cost).all() and torch.isfinite(Zd).all()
 
 
 def test_batched_run_equals_per_utterance_runs():
