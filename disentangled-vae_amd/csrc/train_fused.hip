@@ -1625,7 +1625,7 @@ static int make_layout(const dvae_train_plan_t& p, Layout& L) {
     L.o_tiles = bytes((int64_t)L.ntiles * sizeof(GroupDesc));
     L.o_blocks = bytes((int64_t)L.nblocks * sizeof(BlockDesc));
     L.o_blocks4 = bytes((int64_t)L.nblocks4 * sizeof(Block4));
-    L.o_items4 = bytes((int64_t)W4_MAX_ITEMS * sizeof(W4Item));
+    L.o_items4 = bytes((int64_t)3 * W4_MAX_ITEMS * sizeof(W4Item));      // table of the one launch, then the two tables of a grouped plan
     L.o_tensors = bytes(DVAE_TRAIN_MAX_TENSORS * sizeof(TensorDesc));
     L.o_chunks = bytes(p.n_params / 64 + 64);
     L.o_partials = bytes(p.rows_grid * 4 * sizeof(double));
@@ -1681,7 +1681,8 @@ static int wgrad_form(const char* wk) {
     return 4;
 }
 
-static void w4_plan_classes(dvae_train_plan_t* plan);      // (defined behind fill_tables)
+static void w4_plan_classes(dvae_train_plan_t* plan, bool grouped);      // (defined behind fill_tables)
+constexpr int W4_GROUPED = 0x40000000;      // plan->reserved0: two launches (decoder-side blocks, encoder-side blocks), see w4_build_items
 
 extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, int ksplit_hint, dvae_train_plan_t* plan) {
     DVAE_CHECK_ARG(plan != nullptr && B > 0, "train_plan: bad argument");
@@ -1760,9 +1761,13 @@ extern "C" int dvae_train_plan(int model, int y_dim, int precision, int64_t B, i
     // 85 MB they pull from the stash (4.3 TB/s), not by the heaviest blocks' MFMAs, and more slices only add slab stores.  So: class-sliced
     // under the fp32 policy, uniform under the bf16 policies (DVAE_W4_CLASSES=1 forces it there, DVAE_W4_UNIFORM=1 switches it off).
     const bool want_classes = getenv("DVAE_W4_CLASSES") != nullptr ? atoi(getenv("DVAE_W4_CLASSES")) != 0 : !is_bf(precision);
-    if (want_classes && ksplit_hint <= 0 && wgrad_form(getenv("DVAE_WGRAD")) == 4 && plan->Bp > 128 && getenv("DVAE_W4_UNIFORM") == nullptr &&
+    // DVAE_EXCHANGE_GROUPS=2 (opt-in, multi-GPU; read when the plan is made): the weight-gradient pass as TWO launches -- the blocks of the
+    // decoder-side tensors (and M2_info's side nets), then those of the encoder -- each cut to fill the CUs by itself, so that the exchange
+    // of the first group's gradient can run while the second launch computes (dvae_train_grads_group; Trainer, dp.py).  Always class-sliced.
+    const bool want_groups = getenv("DVAE_EXCHANGE_GROUPS") != nullptr && atoi(getenv("DVAE_EXCHANGE_GROUPS")) == 2;
+    if ((want_classes || want_groups) && ksplit_hint <= 0 && wgrad_form(getenv("DVAE_WGRAD")) == 4 && plan->Bp > 128 && getenv("DVAE_W4_UNIFORM") == nullptr &&
         getenv("DVAE_FOLD_APPLY") == nullptr && getenv("DVAE_DEFER_APPLY") == nullptr)
-        w4_plan_classes(plan);
+        w4_plan_classes(plan, want_groups);
     Layout L;
     make_layout(*plan, L);
     plan->workspace_bytes = L.total;
@@ -1955,9 +1960,12 @@ static void fill_tables(const dvae_train_plan_t* p, const Layout& L, char* ws_de
 static std::mutex g_fold_mu;
 static std::unordered_map<const void*, unsigned> g_fold_seq;
 // workgroups of the weight-gradient launch of a workspace (the size of its item table, fixed by dvae_train_init)
-static std::unordered_map<const void*, int> g_w4_grid;
-static void w4_grid_put(const void* ws, int grid) { std::lock_guard<std::mutex> lk(g_fold_mu); g_w4_grid[ws] = grid; }
-static int w4_grid_get(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); auto it = g_w4_grid.find(ws); return it == g_w4_grid.end() ? -1 : it->second; }
+struct W4Grids { int g[3]; };      // table 0 (the one launch of an ungrouped plan), tables 1 / 2 (group 0 / 1 of a grouped plan)
+static std::unordered_map<const void*, W4Grids> g_w4_grid;
+static void w4_grid_put(const void* ws, const W4Grids& grids) { std::lock_guard<std::mutex> lk(g_fold_mu); g_w4_grid[ws] = grids; }
+static int w4_grid_get(const void* ws, int table) { std::lock_guard<std::mutex> lk(g_fold_mu); auto it = g_w4_grid.find(ws); return it == g_w4_grid.end() ? -1 : it->second.g[table]; }
+// dvae_train_grads_group: which part of the step the next dvae_train_grads call runs (-1: all of it)
+static thread_local int g_w4_group = -1;
 static unsigned fold_seq_next(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); return ++g_fold_seq[ws]; }
 static void fold_seq_reset(const void* ws) { std::lock_guard<std::mutex> lk(g_fold_mu); g_fold_seq.erase(ws); }
 
@@ -2086,9 +2094,11 @@ static double w4_block_cost(const dvae_train_plan_t& p, const Block4& b) {
     const bool x3 = p.precision == DVAE_PREC_BF16X3, bf = is_bf(p.precision);
     const bool one_plane_b = x3 && b.raw == 2 && p.rows_kernel >= 2;      // label tiles: binary labels need no lo plane (two MFMAs per product)
     double mfma, load, fsum;
+    // clocks per 1 KB operand fragment and wave: 70 for a lone wave (tools/r03/kstep_bench.hip); W4_KB_CLOCKS overrides (experiments)
+    static const double kb_clocks = getenv("DVAE_W4_KB_CLOCKS") ? atof(getenv("DVAE_W4_KB_CLOCKS")) : 70.0;
     if (bf) {
         mfma = (double)na * nb * (x3 ? (one_plane_b ? 2 : 3) : 1) * 32.0;
-        load = ((double)na * (x3 ? 2 : 1) + (double)nb * (x3 ? (one_plane_b ? 1 : 2) : 1)) * 70.0;
+        load = ((double)na * (x3 ? 2 : 1) + (double)nb * (x3 ? (one_plane_b ? 1 : 2) : 1)) * kb_clocks;
         fsum = bias ? (double)na * (x3 ? 2 : 1) * 16 * 4 * 0.5 : 0.0;
     } else {
         mfma = (double)na * nb * 2 * 4 * 64.0;                            // two 8-frame k-steps of four 32 x 32 x 2 MFMAs per product
@@ -2106,18 +2116,27 @@ static int64_t w4_kper(const dvae_train_plan_t& p, int slices) {
 
 // s[b] = slices of block b (>= 1), at most `max_items` in all, at most 16 per block (the optimizer launch sums that many slabs), at
 // least 128 frames per slice
-static void w4_class_slices(const dvae_train_plan_t& p, const std::vector<Block4>& blocks, int max_items, std::vector<int>& s) {
+static inline bool w4_classed(const dvae_train_plan_t& p) { return (p.reserved0 & ~W4_GROUPED) > 0; }
+static inline bool w4_grouped(const dvae_train_plan_t& p) { return (p.reserved0 & W4_GROUPED) != 0; }
+// group of a block in the two-launch schedule: 0 = launched first (decoder layers 3-5 and, M2_info, the side nets 6-11: tensors 8 and up, the
+// upper part of the flat gradient), 1 = the encoder (layers 0-2: tensors 0-7, the lower part)
+static inline int w4_group_of(const Block4& b) { return b.layer <= 2 ? 1 : 0; }
+
+// group < 0: every block; otherwise only the blocks of that group take part (the others keep s = 0)
+static void w4_class_slices(const dvae_train_plan_t& p, const std::vector<Block4>& blocks, int max_items, std::vector<int>& s, int group = -1) {
     const int n = (int)blocks.size();
     s.assign(n, 1);
     std::vector<double> cost(n);
-    for (int b = 0; b < n; ++b) cost[b] = w4_block_cost(p, blocks[b]);
+    for (int b = 0; b < n; ++b) cost[b] = (group < 0 || w4_group_of(blocks[b]) == group) ? w4_block_cost(p, blocks[b]) : 0.0;
+    for (int b = 0; b < n; ++b) if (cost[b] == 0.0) s[b] = 0;
     int cap = (int)std::min<int64_t>(16, p.Bp / 128);
     if (cap < 1) cap = 1;
-    int total = n;
+    int total = 0;
+    for (int b = 0; b < n; ++b) total += s[b];
     for (;;) {
         int worst = -1;
         double tw = 0.0;
-        for (int b = 0; b < n; ++b) { const double t = cost[b] * (double)w4_kper(p, s[b]); if (t > tw) { tw = t; worst = b; } }
+        for (int b = 0; b < n; ++b) { if (s[b] == 0) continue; const double t = cost[b] * (double)w4_kper(p, s[b]); if (t > tw) { tw = t; worst = b; } }
         if (worst < 0) break;
         int s2 = s[worst] + 1;
         while (s2 <= cap && w4_kper(p, s2) >= w4_kper(p, s[worst])) ++s2;       // the next slice count that shortens the slices
@@ -2131,6 +2150,7 @@ static void w4_debug_print(const dvae_train_plan_t& p, const std::vector<Block4>
     if (getenv("DVAE_W4_DEBUG") == nullptr) return;                        // DVAE_W4_DEBUG=1: the schedule, block by block (stderr)
     {
         for (int b = 0; b < (int)blocks.size(); ++b) {
+            if (s[b] == 0) continue;
             int na = 0, nb = 0;
             for (int k = 0; k < 4; ++k) { if (blocks[b].At[k]) na = k + 1; if (blocks[b].Bt[k]) nb = k + 1; }
             const int64_t kper = w4_kper(p, s[b]);
@@ -2141,30 +2161,37 @@ static void w4_debug_print(const dvae_train_plan_t& p, const std::vector<Block4>
     }
 }
 
-static void w4_plan_classes(dvae_train_plan_t* plan) {
+static void w4_plan_classes(dvae_train_plan_t* plan, bool grouped) {
     dvae_train_plan_t tmp = *plan;
     tmp.ksplit = 1;
     Layout L0;
     make_layout(tmp, L0);
     std::vector<Block4> blocks;
     w4_host_blocks(tmp, L0, blocks);
-    std::vector<int> s;
-    w4_class_slices(tmp, blocks, 256, s);
-    w4_debug_print(tmp, blocks, s);
-    int nslabs = 1, items = 0;
-    for (size_t b = 0; b < blocks.size(); ++b) {
-        const int64_t kper = w4_kper(tmp, s[b]);
-        const int eff = (int)((tmp.Bp + kper - 1) / kper);
-        nslabs = std::max(nslabs, eff);
-        items += eff;
+    int nslabs = 1, items_max = 0;
+    for (int grp = grouped ? 0 : -1; grp <= (grouped ? 1 : -1); ++grp) {
+        std::vector<int> s;
+        w4_class_slices(tmp, blocks, 256, s, grp);
+        w4_debug_print(tmp, blocks, s);
+        int items = 0;
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            if (s[b] == 0) continue;
+            const int64_t kper = w4_kper(tmp, s[b]);
+            const int eff = (int)((tmp.Bp + kper - 1) / kper);
+            nslabs = std::max(nslabs, eff);
+            items += eff;
+        }
+        items_max = std::max(items_max, items);
     }
     plan->ksplit = nslabs;
-    plan->reserved0 = items;
+    plan->reserved0 = items_max | (grouped ? W4_GROUPED : 0);
 }
 
-static void w4_build_items(const dvae_train_plan_t& p, const Layout& L, W4Sched& out) {
+// group: -1 = the one launch of an ungrouped plan; 0 / 1 = the launches of a grouped plan (w4_group_of)
+static void w4_build_items(const dvae_train_plan_t& p, const Layout& L, W4Sched& out, int group = -1) {
     out.items.clear();
-    if (p.reserved0 <= 0) {
+    out.grid = 0;
+    if (!w4_classed(p)) {
         // uniform slices, the round-2 index map
         const int64_t kper = w4_kper(p, p.ksplit);
         const int ks = (int)((p.Bp + kper - 1) / kper), nblocks = L.nblocks4;
@@ -2187,11 +2214,12 @@ static void w4_build_items(const dvae_train_plan_t& p, const Layout& L, W4Sched&
     w4_host_blocks(p, L, blocks);
     dvae_train_plan_t tmp = p;
     std::vector<int> s;
-    w4_class_slices(tmp, blocks, 256, s);
+    w4_class_slices(tmp, blocks, 256, s, group);
     struct It { W4Item it; double cost; };
     // items that read the same stash lines -- the blocks of one layer cut the same way, over the same frames -- form a group: one XCD
     std::map<std::tuple<int, int64_t, int>, std::vector<It>> groups;
     for (int b = 0; b < (int)blocks.size(); ++b) {
+        if (s[b] == 0) continue;                                          // not in this group's launch
         const int64_t kper = w4_kper(p, s[b]);
         const int eff = (int)((p.Bp + kper - 1) / kper);
         const double c = w4_block_cost(p, blocks[b]);
@@ -2258,10 +2286,18 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     hipError_t e2 = hipMemcpyAsync(w + L.o_tensors, td, sizeof(td), hipMemcpyHostToDevice, s);
     hipError_t e5 = hipMemcpyAsync(w + L.o_blocks, blocks, (size_t)L.nblocks * sizeof(BlockDesc), hipMemcpyHostToDevice, s);
     hipError_t e6 = hipMemcpyAsync(w + L.o_blocks4, blocks4, (size_t)L.nblocks4 * sizeof(Block4), hipMemcpyHostToDevice, s);
-    W4Sched sched;
-    w4_build_items(*plan, L, sched);
-    DVAE_CHECK_ARG(sched.grid <= W4_MAX_ITEMS && (plan->reserved0 <= 0 || sched.grid >= plan->reserved0 / 1), "train_init: weight-gradient schedule of %d workgroups does not fit the item table", sched.grid);
-    hipError_t e8 = hipMemcpyAsync(w + L.o_items4, sched.items.data(), sched.items.size() * sizeof(W4Item), hipMemcpyHostToDevice, s);
+    W4Sched sched[3];                                                     // [0]: the one launch; [1], [2]: the two launches of a grouped plan
+    W4Grids grids{{0, 0, 0}};
+    hipError_t e8 = hipSuccess;
+    for (int t = 0; t < 3; ++t) {
+        const bool grouped = w4_grouped(*plan);
+        if ((t == 0) == grouped) continue;                                // a plan uses either table 0 or tables 1 and 2
+        w4_build_items(*plan, L, sched[t], t - 1);
+        DVAE_CHECK_ARG(sched[t].grid > 0 && sched[t].grid <= W4_MAX_ITEMS, "train_init: weight-gradient schedule of %d workgroups does not fit the item table", sched[t].grid);
+        grids.g[t] = sched[t].grid;
+        const hipError_t e = hipMemcpyAsync(w + L.o_items4 + (int64_t)t * W4_MAX_ITEMS * sizeof(W4Item), sched[t].items.data(), sched[t].items.size() * sizeof(W4Item), hipMemcpyHostToDevice, s);
+        if (e8 == hipSuccess) e8 = e;
+    }
     const int64_t nchunks = plan->n_params / 64;
     unsigned char* ct = new unsigned char[nchunks + 64];
     memset(ct, 255, (size_t)nchunks + 64);
@@ -2281,7 +2317,7 @@ extern "C" int dvae_train_init(const dvae_train_plan_t* plan, const float* param
     delete[] blocks4;
     delete[] ct;
     DVAE_HIP(e1); DVAE_HIP(e2); DVAE_HIP(e4); DVAE_HIP(e5); DVAE_HIP(e6); DVAE_HIP(e7); DVAE_HIP(e8); DVAE_HIP(e3);
-    w4_grid_put(ws, sched.grid);
+    w4_grid_put(ws, grids);
     return dvae_train_repack(plan, params, ws, stream);
 }
 
@@ -2442,8 +2478,17 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         const bool wg4 = wgrad_form(wk0) == 4 && (plan->Bp > 128 || raw_inputs || wk0 != nullptr);
         a.ylo_epoch = (unsigned*)(w + L.o_flags);
         a.ylo_dirty = (int*)(w + L.o_flags + 1024);
-        a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);
-        if (a.launch_id == 0) a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of a fresh workspace
+        // (the second launch of a grouped step belongs to the rows kernel of the first call: same id, or its label blocks would misread the epoch word)
+        static thread_local unsigned last_id = 0;
+        static thread_local const void* last_ws = nullptr;
+        if (g_w4_group == 1) {
+            DVAE_CHECK_ARG(last_ws == ws && last_id != 0, "train_grads_group: group 1 must follow a group 0 call on the same workspace");
+            a.launch_id = last_id;
+        } else {
+            a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);
+            if (a.launch_id == 0) a.launch_id = launch_counter.fetch_add(1, std::memory_order_relaxed);      // 0 = the memset value of a fresh workspace
+            last_id = a.launch_id; last_ws = ws;
+        }
         a.ylo_skip = (x3 && plan->y_dim > 0 && plan->rows_kernel >= 2 && rows2_supported(plan->precision, plan->model) && wg4 && !(raw_mask & 2) &&
                       getenv("DVAE_YLO_ALWAYS") == nullptr) ? 1 : 0;
     }
@@ -2460,8 +2505,10 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     }
     const int grid = (int)plan->rows_grid;
     const bool m2 = plan->model == DVAE_MODEL_M2;
-    int rc;
-    {
+    const int gsel = g_w4_group;                                          // dvae_train_grads_group: -1 the whole step, 0 rows + first wgrad launch, 1 second wgrad launch
+    DVAE_CHECK_ARG(gsel < 0 || (w4_grouped(*plan) && g_mode.mode == 0 && !g_eval_only), "train_grads_group: the plan was not made for two weight-gradient launches (DVAE_EXCHANGE_GROUPS=2 when the plan is made)");
+    int rc = 0;
+    if (gsel != 1) {
         ProfScope ps(s, 0);
         if (plan->rows_kernel == 3 && rows3_supported(plan->precision, plan->model)) {
             rc = launch_rows3(plan->model, plan->y_dim, a, grid, s);
@@ -2493,9 +2540,9 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     if (rc) return rc;
     if (g_eval_only || a.mode == 1) return 0;
     const int64_t kper = kper_of(plan);
-    const int ks = plan->reserved0 > 0 ? plan->ksplit : (int)((plan->Bp + kper - 1) / kper);      // slabs the launch fills (class-sliced: the largest slice count)
+    const int ks = w4_classed(*plan) ? plan->ksplit : (int)((plan->Bp + kper - 1) / kper);      // slabs the launch fills (class-sliced: the largest slice count)
     DVAE_CHECK_ARG(ks <= plan->ksplit, "train_grads: internal k-split mismatch");
-    DVAE_CHECK_ARG(plan->reserved0 <= 0 || wgrad_form(getenv("DVAE_WGRAD")) == 4,
+    DVAE_CHECK_ARG(!w4_classed(*plan) || wgrad_form(getenv("DVAE_WGRAD")) == 4,
                    "train_grads: the plan was made for the workgroup k-split weight-gradient kernel (class-sliced schedule); DVAE_WGRAD changed since");
     float* slabs = (float*)(w + L.o_grads);
     // DVAE_WGRAD=lds selects the workgroup-blocked kernel for the bf16 policies (operands staged once per 4 x 4 block in LDS: half the
@@ -2507,8 +2554,11 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     { const char* e = getenv("DVAE_WGRAD_REPEAT"); if (e) { wrep = atoi(e); if (wrep < 1) wrep = 1; } }   // diagnostic: re-run on the warm stash
     for (int rep = 0; rep < wrep; ++rep)
     if (wgrad_form(wk) == 4 && (plan->Bp > 128 || raw_inputs || wk != nullptr)) {      // one 128-frame slice: the 2 x 2 kernel's short epilogue wins (11.2 vs 12.8 us)
+      // one launch (table 0), or the launches of a grouped plan: tables 1 and 2, both (gsel < 0) or the one asked for
+      const int tb0 = !w4_grouped(*plan) ? 0 : (gsel == 1 ? 2 : 1), tb1 = !w4_grouped(*plan) ? 0 : (gsel == 0 ? 1 : 2);
+      for (int tb = tb0; tb <= tb1; ++tb) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
-        const int w4grid = w4_grid_get(w);
+        const int w4grid = w4_grid_get(w, tb);
         DVAE_CHECK_ARG(w4grid > 0, "train_grads: workspace was not set up by dvae_train_init");
         const dim3 g3((unsigned)w4grid);                                  // one workgroup per item of the host's table (w4_build_items)
         RawIn ri;
@@ -2526,13 +2576,13 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
             attr_done[dev][pi] = true;
         }
         const Block4* bl = (const Block4*)(w + L.o_blocks4);
-        const W4Item* w4items = (const W4Item*)(w + L.o_items4);
+        const W4Item* w4items = (const W4Item*)(w + L.o_items4) + (size_t)tb * W4_MAX_ITEMS;
         // the optimizer step in this launch's tail (dvae_train_step asked for it): only when every workgroup of the grid is resident at
         // once -- one per CU, the tail's wait depends on it -- and the block counters fit the flag header
         ApplyArgs fa_apply;
         memset(&fa_apply, 0, sizeof(fa_apply));
         FoldArgs fold{nullptr, 0u, 0u};
-        if (g_fold.want && plan->reserved0 <= 0 && wrep == 1 && a.mode == 0 && ks > 1 && ks <= 16 && L.nblocks4 <= FOLD_MAXB && (int)g3.x <= device_cu_count(dev)) {
+        if (g_fold.want && !w4_classed(*plan) && wrep == 1 && a.mode == 0 && ks > 1 && ks <= 16 && L.nblocks4 <= FOLD_MAXB && (int)g3.x <= device_cu_count(dev)) {
             fa_apply = make_apply_args(plan, L, g_fold.params, g_fold.m, g_fold.v, w, ks, true, g_fold.step, g_fold.lr, g_fold.beta1, g_fold.beta2,
                                        g_fold.adam_eps, 1.0, g_fold.losses3);
             fold.cnt = (unsigned*)(w + L.o_flags);
@@ -2553,6 +2603,7 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
         else if (bf) hipLaunchKernelGGL((wgrad4_kernel<PolBF16>), g3l, dim3(256), Wg4<PolBF16>::BYTES, s, bl, w4items, ks, plan->Bp, a.spl, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
         else hipLaunchKernelGGL((wgrad4_kernel<PolF32>), g3l, dim3(256), Wg4<PolF32>::BYTES, s, bl, w4items, ks, plan->Bp, a.spl, slabs, plan->n_params, ri, use_raw, (const unsigned*)nullptr, 0u, fa_apply, fold, fin_block, fin_err);
         DVAE_LAUNCH_OK("wgrad4_kernel");
+      }
 #ifdef DVAE_DIAG
     } else if ((bf || x3) && wk && strcmp(wk, "lds") == 0) {
         ProfScope ps(s, rep == 0 ? 1 : 2);
@@ -2588,14 +2639,40 @@ extern "C" int dvae_train_grads(const dvae_train_plan_t* plan, const float* para
     }
     if (reduce_slabs && ks > 1) {
         ProfScope ps(s, 2);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(512), dim3(256), 0, s, slabs, plan->n_params, ks, plan->n_params);
+        int64_t lo = 0, hi = plan->n_params;                              // a group's launch reduces its own part of the flat gradient
+        if (gsel == 0) lo = plan->tensor_offset[8];
+        if (gsel == 1) hi = plan->tensor_offset[8];
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(512), dim3(256), 0, s, slabs + lo, hi - lo, ks, plan->n_params);
         DVAE_LAUNCH_OK("slab_reduce_kernel");
     }
     return 0;
 }
 
+// The step's gradient pass in two calls, for a plan made under DVAE_EXCHANGE_GROUPS=2: group 0 = the rows kernel + the weight-gradient launch of
+// the decoder-side tensors (flat gradient [tensor_offset[8], n_params)), group 1 = the launch of the encoder's ([0, tensor_offset[8])); the
+// caller may start the exchange of group 0's part between the two calls.  dvae_train_grads on such a plan runs both.
+extern "C" int dvae_train_grads_group(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx, const float* y, int ldy,
+                                      const float* eps_noise, float elbo_eps, int group, int reduce_slabs, void* stream) {
+    DVAE_CHECK_ARG(plan && (group == 0 || group == 1), "train_grads_group: group must be 0 or 1");
+    DVAE_CHECK_ARG(w4_grouped(*plan), "train_grads_group: the plan was not made for two weight-gradient launches (DVAE_EXCHANGE_GROUPS=2 when the plan is made)");
+    g_w4_group = group;
+    const int rc = dvae_train_grads(plan, params, ws, x, ldx, y, ldy, eps_noise, elbo_eps, reduce_slabs, stream);
+    g_w4_group = -1;
+    return rc;
+}
+
+// float range [lo, hi) of a group's part of the flat gradient (group < 0: everything); *ngroups = 2 for a plan made for two launches, else 1
+extern "C" int dvae_train_group_range(const dvae_train_plan_t* plan, int group, int64_t* lo, int64_t* hi, int* ngroups) {
+    DVAE_CHECK_ARG(plan && lo && hi && group >= -1 && group <= 1, "train_group_range: bad argument");
+    *lo = 0; *hi = plan->n_params;
+    if (group == 0) *lo = plan->tensor_offset[8];
+    if (group == 1) *hi = plan->tensor_offset[8];
+    if (ngroups) *ngroups = w4_grouped(*plan) ? 2 : 1;
+    return 0;
+}
+
 static int used_slabs(const dvae_train_plan_t* plan) {
-    if (plan->reserved0 > 0) return plan->ksplit;                        // class-sliced schedule: the largest slice count of any block
+    if (w4_classed(*plan)) return plan->ksplit;                          // class-sliced schedule: the largest slice count of any block
     const int64_t kper = kper_of(plan);
     return (int)((plan->Bp + kper - 1) / kper);
 }

@@ -33,6 +33,22 @@ def allreduce_flat_(flat, group=None):
     return flat
 
 
+def allreduce_flat_async_(flat, group=None):
+    """SUM all-reduce of a part of the flat gradient that does NOT block the launch stream: returns a handle whose .wait() makes the current
+    stream wait for the result (RCCL: the collective runs on the process group's own stream behind an event of the current one, so kernels
+    launched on the current stream meanwhile overlap with it).  gloo test rigs (ranks sharing one GPU): staged through the host, done at once."""
+    if not flat.is_contiguous():
+        raise ValueError("flat gradient buffer must be contiguous")
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        allreduce_flat_(flat, group)
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def mean_scalars_(t, world, group=None):
     """Average a small tensor of per-rank loss scalars over the ranks (reporting only)."""
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

@@ -65,6 +65,8 @@ SIGNATURES = {
     "dvae_train_init": (c_i, [c_vp, c_vp, c_vp, c_vp]),
     "dvae_train_repack": (c_i, [c_vp, c_vp, c_vp, c_vp]),
     "dvae_train_grads": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_vp]),
+    "dvae_train_grads_group": (c_i, [c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_i, c_vp]),
+    "dvae_train_group_range": (c_i, [c_vp, c_i, c_vp, c_vp, c_vp]),
     "dvae_train_apply": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_d, c_d, c_d, c_d, c_d, c_vp, c_vp]),
     "dvae_train_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_d, c_d, c_d, c_d, c_vp, c_vp]),
     "dvae_train_step_deferred": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_i, c_vp, c_f, c_i, c_d, c_d, c_d, c_d, c_vp, c_vp]),

@@ -106,6 +106,15 @@ class Trainer:
         self.plan.bad_row_counter = self.bad_rows.data_ptr()
         go = self.plan.grad_offset_bytes
         self.flat_grad = self.ws[go:go + 4 * P].view(torch.float32)        # slab 0
+        # two weight-gradient launches per step (plan made under DVAE_EXCHANGE_GROUPS=2): the parts of the flat gradient they fill
+        self._groups, self._group_range = 1, None
+        lo, hi, ng = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        N.check(self.lib.dvae_train_group_range(ctypes.byref(self.plan), -1, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(ng)), "dvae_train_group_range")
+        if ng.value == 2:
+            self._groups, self._group_range = 2, []
+            for grp in (0, 1):
+                N.check(self.lib.dvae_train_group_range(ctypes.byref(self.plan), grp, ctypes.byref(lo), ctypes.byref(hi), None), "dvae_train_group_range")
+                self._group_range.append((int(lo.value), int(hi.value)))
         # gradient exchange of the data-parallel step: the process group's all-reduce (RCCL over xGMI), or the library's own
         # stream-ordered exchange over peer pointers (DVAE_ALLREDUCE=direct; dp.DirectExchange) -- unmeasured on multi-GPU hardware
         self.direct = share.direct if share is not None else direct_exchange      # direct_exchange: a connected dp.DirectExchange of n_params floats
@@ -368,6 +377,31 @@ class Trainer:
             self._reduced = False
         else:
             direct = self.direct
+            if direct is None and self._groups == 2:
+                # DVAE_EXCHANGE_GROUPS=2 (opt-in, process-group exchange): rows + the weight gradients of the decoder-side tensors, their part of
+                # the flat gradient into the exchange -- asynchronously -- then the encoder's weight gradients on the launch stream beside it,
+                # then that part; the optimizer launch waits for both.  UNMEASURED on multi-GPU hardware (exposed-latency model).
+                ev = None
+                if self._ar_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                works = []
+                for grp in (0, 1):
+                    N.check(self.lib.dvae_train_grads_group(plan, N.ptr(self._params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
+                                                            self.elbo_eps, grp, 1, s), "dvae_train_grads_group")
+                    if grp == 0 and ev is not None:
+                        ev[0].record()
+                    lo, hi = self._group_range[grp]
+                    works.append(dp.allreduce_flat_async_(self.flat_grad[lo:hi], self.pg))
+                for w in works:
+                    w.wait()
+                if ev is not None:
+                    ev[1].record()
+                    self._ar_events.append(ev)
+                N.check(self.lib.dvae_train_apply(plan, N.ptr(self._params), N.ptr(self._m), N.ptr(self._v), N.ptr(self.ws), 1, self.step_count,
+                                                  self.lr, self.betas[0], self.betas[1], self.adam_eps, 1.0 / self.world,
+                                                  N.ptr(self.losses), s), "dvae_train_apply")
+                self._reduced = True
+                return self.losses
             N.check(self.lib.dvae_train_grads(plan, N.ptr(self._params), N.ptr(self.ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps_noise),
                                               self.elbo_eps, 0 if direct is not None else 1, s), "dvae_train_grads")
             ev = None

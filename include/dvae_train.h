@@ -104,6 +104,16 @@ int dvae_train_init(const dvae_train_plan_t* plan, const float* params, void* ws
 int dvae_train_grads(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx,
                      const float* y, int ldy, const float* eps_noise, float elbo_eps, int reduce_slabs, void* stream);
 
+/* The gradient pass of a step in TWO calls, so that the exchange of the first part of the flat gradient can run while the second part is
+ * computed (no reference call site: scripts/training_M2.py:31-33 is single-device).  For a plan made while
+ * DVAE_EXCHANGE_GROUPS=2 is set: group 0 = rows kernel + the weight-gradient launch of the decoder-side tensors (and M2_info's side nets) --
+ * floats [tensor_offset[8], n_params) of the flat gradient; group 1 = the launch of the encoder's tensors, floats [0, tensor_offset[8]);
+ * group 1 must follow a group 0 call on the same workspace.  reduce_slabs sums the slabs of the group's range into slab 0.
+ * dvae_train_grads on such a plan runs both launches.  dvae_train_group_range: the range of a group (-1: everything), *ngroups = 2 or 1. */
+int dvae_train_grads_group(const dvae_train_plan_t* plan, const float* params, void* ws, const float* x, int ldx, const float* y, int ldy,
+                           const float* eps_noise, float elbo_eps, int group, int reduce_slabs, void* stream);
+int dvae_train_group_range(const dvae_train_plan_t* plan, int group, int64_t* lo, int64_t* hi, int* ngroups);
+
 /* apply kernel: g = grad_scale * sum of n_slabs slabs; Adam(lr, beta1, beta2, adam_eps) at `step` (1-based) on
  * params/m/v; refresh weight copies; losses3 = {recon + KL, recon, KL} (means over the B local frames);
  * for M2_info the buffer holds 8 floats: {ELBO, recon, KL, enc_loss, classif_loss, aux_loss, aux_enc_loss, 0}. */

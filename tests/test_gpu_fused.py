@@ -182,6 +182,35 @@ def test_class_sliced_weight_gradient_schedule_equals_the_uniform_one(model, y_d
         assert np.array_equal(res["classes"][1][k], res["classes2"][1][k])
 
 
+@pytest.mark.parametrize("model,y_dim,B,precision", [("M2", 513, 8192, "bf16x3"), ("M1", 0, 1000, "bf16x3"), ("M2_info", 1, 3000, "fp32")])
+def test_a_plan_made_for_two_weight_gradient_launches_steps_like_the_one_launch_plan(model, y_dim, B, precision, monkeypatch):
+    """A plan made under DVAE_EXCHANGE_GROUPS=2 holds two item tables (decoder-side blocks, encoder blocks), each cut to fill the CUs by
+    itself; the single-process step on it (dvae_train_step -> both launches, back to back) gives the uniform plan's losses bit for bit and
+    its gradients up to the order of the slab sums, over three steps on one workspace."""
+    dims = dict(x_dim=513, y_dim=y_dim, z_dim=16, h_dim=(128, 128))
+    params = gu.make_params(model, dims, 6)
+    t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    batches = [gu.make_batch(dims, B, 70 + i) for i in range(3)]
+    res = {}
+    for mode in ("uniform", "groups"):
+        for k in ("DVAE_W4_UNIFORM", "DVAE_W4_CLASSES", "DVAE_EXCHANGE_GROUPS"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("DVAE_W4_UNIFORM" if mode == "uniform" else "DVAE_EXCHANGE_GROUPS", "1" if mode == "uniform" else "2")
+        tr = trainer.Trainer(model, dims, params, batch=B, precision=precision)
+        assert tr._groups == (2 if mode == "groups" else 1)
+        out = []
+        for x, y, e in batches:
+            losses = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
+            out.append((losses, tr.grads_numpy()))
+        res[mode] = out
+    for i, ((lu, gu_), (lg, gg)) in enumerate(zip(res["uniform"], res["groups"])):
+        if i == 0:
+            assert np.array_equal(lu[:3], lg[:3])
+        np.testing.assert_allclose(lg[:3], lu[:3], rtol=1e-5)
+        for k in gu_:
+            assert _relmax(gg[k], gu_[k].astype(np.float64)) < (2e-6 if i == 0 else 2e-3), (i, k)
+
+
 def test_fused_is_deterministic_and_ksplit_invariant():
     dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=(128, 128))
     params = gu.make_params("M2", dims, 3)
@@ -264,9 +293,11 @@ def test_state_dict_round_trip_and_repack():
         trainer.Trainer("M2", dict(x_dim=513, y_dim=7, z_dim=16, h_dim=(128, 128)), None, batch=8)
 
 
-def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32", exchange="rccl"):
+def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32", exchange="rccl", groups=1):
     import os, sys
     os.environ["DVAE_ALLREDUCE"] = exchange
+    if groups == 2:
+        os.environ["DVAE_EXCHANGE_GROUPS"] = "2"
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
     import importlib, numpy as np, torch, torch.distributed as dist
@@ -290,6 +321,7 @@ def _dp_worker(rank, world, port, q, model="M2", y_dim=513, precision="fp32", ex
         t = lambda a: torch.from_numpy(a[lo:hi].copy()).cuda()
         losses = tr.step(t(x), t(y), t(e)).cpu().numpy().copy()
     failed = tr.direct.failed() if tr.direct is not None else False
+    assert tr._groups == groups
     q.put((rank, tr.state_dict_numpy(), losses, failed, tr.direct is not None))
     if tr.direct is not None:
         dist.barrier()
@@ -328,6 +360,36 @@ def test_two_rank_data_parallel_equals_single_process(model, y_dim, precision):
         assert d.max() <= (2e-6 if (model, precision) == ("M2", "fp32") else 4.1e-4), (k, d.max())
         assert np.mean(d > 2e-6) < (0.0 if (model, precision) == ("M2", "fp32") else 0.02) + 1e-12, (k, float(np.mean(d > 2e-6)))
     np.testing.assert_allclose(0.5 * (res[0][2] + res[1][2]), losses, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "bf16x3"), ("M2", 513, "fp32"), ("M2_info", 1, "bf16x3")])
+def test_two_launch_weight_gradients_with_the_exchange_between_them(model, y_dim, precision):
+    """DVAE_EXCHANGE_GROUPS=2 (opt-in; csrc/train_fused.hip: dvae_train_grads_group): the gradient pass of a data-parallel step as rows +
+    weight gradients of the decoder-side tensors, their part of the flat gradient handed to the exchange, the encoder's weight gradients,
+    their part, then the optimizer launch.  Two ranks sharing the one GPU (gloo in place of RCCL): replicas identical, and equal to the
+    one-launch / one-exchange step up to the order of the slab sums (the same bounds the two-rank step holds against the one-rank step:
+    Adam's first steps are sign-like where a gradient is rounding noise).  M2_info: the side nets' tensors travel with the decoder's."""
+    import torch.multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    got = {}
+    for groups in (2, 1):
+        q = ctx.Queue()
+        port = 33000 + (os.getpid() + 11 * len(model) + y_dim + 5 * groups + len(precision)) % 2000
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, model, y_dim, precision, "rccl", groups)) for r in range(2)]
+        for pr in procs:
+            pr.start()
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+        got[groups] = res
+    for k in got[1][0][1]:
+        assert np.array_equal(got[2][0][1][k], got[2][1][1][k]), k                # replicas identical
+        d = np.abs(got[2][0][1][k] - got[1][0][1][k])
+        assert d.max() <= 4.1e-4, (k, d.max())
+        assert np.mean(d > 2e-6) < 0.02, (k, float(np.mean(d > 2e-6)))
+    np.testing.assert_allclose(got[2][0][2], got[1][0][2], rtol=1e-5, atol=1e-6)   # the second step's losses (rank 0)
 
 
 @pytest.mark.parametrize("model,y_dim,precision", [("M2", 513, "bf16x3"), ("M2_info", 1, "bf16x3")])
