@@ -48,7 +48,9 @@ typedef struct {
     /* flat fp32 parameter buffer: the reference's state_dict tensors, in state_dict order,
        each contiguous in nn.Linear layout [out, in] at a 256-byte aligned offset */
     int32_t n_tensors;
-    int32_t reserved0;
+    int32_t reserved0;        /* schedule of the weight-gradient launch, set by dvae_train_plan: 0 = ksplit uniform frame slices; low 30 bits > 0 = class-sliced
+                                 (workgroups of the launch; ksplit = the largest slice count of any block = slabs to sum); bit 30 = two launches
+                                 (DVAE_EXCHANGE_GROUPS=2, dvae_train_grads_group).  Callers treat it as opaque. */
     int64_t n_params;                                   /* flat length in floats (with alignment gaps) */
     int64_t tensor_offset[DVAE_TRAIN_MAX_TENSORS];      /* in floats */
     int32_t tensor_rows[DVAE_TRAIN_MAX_TENSORS];
