@@ -65,6 +65,13 @@ class ModuleEngine:
         if sd_names != TENSOR_NAMES:
             raise RuntimeError(f"unexpected parameter set for the fused module path: {sd_names}")
         self.params = [p for _, p in named]
+        # where the module keeps each of them (submodule._parameters[name]): `current()` checks the 14 slots instead of walking
+        # named_parameters() on every forward (35 us of a 400 us step at the scripts' batch size)
+        mods = dict(module.named_modules())
+        self.slots = []
+        for n, _ in named:
+            owner, _, leaf = n.rpartition(".")
+            self.slots.append((mods[owner]._parameters, leaf))
         self.device = self.params[0].device
         self.plans = {}
         p0 = self._plan(128)[0]
@@ -120,6 +127,13 @@ class ModuleEngine:
     def usable(self, x):
         return all(p.is_cuda and p.device == x.device and p.dtype == torch.float32 for p in self.params)
 
+    def current(self):
+        """The module still holds the parameter objects this engine was built on (a replaced nn.Parameter rebuilds the engine)."""
+        for (d, leaf), p in zip(self.slots, self.params):
+            if d.get(leaf) is not p:
+                return False
+        return True
+
     # ---- launches ----
     def forward(self, x, y, eps):
         B = x.shape[0]
@@ -131,9 +145,11 @@ class ModuleEngine:
             r = torch.empty((B, 513), dtype=torch.float32, device=self.device)
             mlz = torch.empty((3, B, 16), dtype=torch.float32, device=self.device)
             yp, ldy = (N.ptr(y), N.ld(y)) if self.y_dim else (None, 0)
+            m0 = mlz.data_ptr()                      # mu | log_var | z, [B, 16] fp32 each
             N.check(self.lib.dvae_module_forward(ctypes.byref(plan), N.ptr(self.flat), N.ptr(ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps),
-                                                 N.ptr(r), 513, N.ptr(mlz[0]), N.ptr(mlz[1]), N.ptr(mlz[2]), 1, N.stream()), "dvae_module_forward")
-        return r, mlz[2], mlz[0], mlz[1]
+                                                 N.ptr(r), 513, m0, m0 + 64 * B, m0 + 128 * B, 1, N.stream()), "dvae_module_forward")
+        mu, lv, z = mlz.unbind(0)
+        return r, z, mu, lv
 
     def backward(self, x, y, eps, gr, gz, gmu, glv, needs):
         """-> list of 14 parameter gradients (None where `needs` is False): views of one flat buffer of this call."""
@@ -150,7 +166,14 @@ class ModuleEngine:
             N.check(self.lib.dvae_module_backward(ctypes.byref(plan), N.ptr(self.flat), N.ptr(ws), N.ptr(x), N.ld(x), yp, ldy, N.ptr(eps),
                                                   N.ptr(gr_), 0 if gr_ is None else N.ld(gr_), N.ptr(gmu), N.ptr(glv), N.ptr(gz),
                                                   N.ptr(dst), 0, N.stream()), "dvae_module_backward")
-        return [dst[o:o + n].view(p.shape) if need else None for p, (o, n), need in zip(self.params, self.spans, needs)]
+        # one view op per gradient (as_strided on the flat buffer: contiguous [out, in] / [out] at the tensor's offset)
+        return [dst.as_strided(shp, std, o) if need else None for (shp, std, o), need in zip(self._grad_views(), needs)]
+
+    def _grad_views(self):
+        gv = self.__dict__.get("_gv")
+        if gv is None:
+            gv = self._gv = [(tuple(p.shape), (p.shape[1], 1) if p.dim() == 2 else (1,), o) for p, (o, n) in zip(self.params, self.spans)]
+        return gv
 
 
 def _rows_ok(t):
@@ -197,9 +220,14 @@ def engine_for(module, model, x, y):
         return None
     if x.requires_grad or (y is not None and y.requires_grad):
         return None                                  # gradients with respect to the data are a layer-path feature
-    if not torch.is_grad_enabled() or not any(p.requires_grad for _, p in vae_parameters(module, model)):
+    if not torch.is_grad_enabled():
         return None                                  # inference: the exact-fp32 per-layer kernels (module docstring)
     eng = module.__dict__.get("_dvae_engine")
+    if eng is not None and not eng.current():
+        eng = None                                   # a parameter object was replaced: a new engine on the new set
+        module.__dict__.pop("_dvae_engine", None)
+    if not any(p.requires_grad for p in (eng.params if eng is not None else [p for _, p in vae_parameters(module, model)])):
+        return None                                  # every parameter frozen: inference as well
     if eng is None:
         if module.__dict__.get("_dvae_engine_off"):
             return None

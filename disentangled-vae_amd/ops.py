@@ -151,7 +151,7 @@ class Elbo(torch.autograd.Function):
         ctx.save_for_backward(x_, r_, mu_, lv_)
         ctx.shapes = (r.shape, mu.shape, logvar.shape)
         ctx.set_materialize_grads(False)
-        return out3[0], out3[1], out3[2]
+        return out3.unbind(0)
 
     @staticmethod
     def backward(ctx, g_loss, g_recon, g_kl):

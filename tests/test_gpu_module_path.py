@@ -72,6 +72,37 @@ def test_training_loop_matches_the_layer_path(model, y_dim, B, monkeypatch):
         assert kl.shape == (B,) and torch.isfinite(kl).all()
 
 
+def test_a_replaced_parameter_object_rebuilds_the_engine(monkeypatch):
+    """`layer.weight = nn.Parameter(...)` after the first fused forward: the next forward runs on the new tensor (a new engine over the
+    14 parameters the module holds now), gradients land on it, and the layer path agrees."""
+    from packages.models import models as M
+    from packages.models.utils import elbo
+    monkeypatch.delenv("DVAE_MODULE_PATH", raising=False)
+    dims, m, ref = _models("M2", 1, 11)
+    x, y, e = (torch.from_numpy(a).cuda() for a in gu.make_batch(dims, 64, 3))
+    M.Stochastic.epsilon_fn = lambda mu: e
+    try:
+        r0 = m(x, y)[0]
+        eng0 = m.__dict__.get("_dvae_engine")
+        assert eng0 is not None
+        w = torch.nn.Parameter(m.decoder.hidden[1].weight.detach().clone() * 0.5)
+        m.decoder.hidden[1].weight = w
+        ref.load_state_dict(m.state_dict())
+        r, mu, lv = m(x, y)
+        eng1 = m.__dict__.get("_dvae_engine")
+        assert eng1 is not None and eng1 is not eng0 and eng1.params[10] is w
+        assert not torch.allclose(r, r0)
+        monkeypatch.setenv("DVAE_MODULE_PATH", "layers")
+        want = ref(x, y)[0]
+        monkeypatch.delenv("DVAE_MODULE_PATH")
+        np.testing.assert_allclose(r.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-4)
+        elbo(x, r, mu, lv, 1e-8)[0].backward()
+        assert w.grad is not None and w.grad.shape == w.shape and torch.isfinite(w.grad).all() and w.grad.abs().max() > 0
+        assert all(p.grad is not None for p in m.parameters() if p.requires_grad)
+    finally:
+        M.Stochastic.epsilon_fn = None
+
+
 def test_parameters_stay_ordinary_parameters(monkeypatch):
     """state_dict / load_state_dict / gradient accumulation / requires_grad=False / no_grad / deepcopy on the fused path."""
     from packages.models import models as M
