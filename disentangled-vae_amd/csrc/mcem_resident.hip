@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float z[8], zp[8];
         float prior_cur = 0.f;
         double ll_cur = 0.0;
-        if (wave == 0 && g.nit > 0) {
+        if (wave_u == 0 && g.nit > 0) {
             const __amdgpu_buffer_rsrc_t rs_z0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Z0), 0, (int)((int64_t)ZD * g.N * 4), 0x00020000);
 #pragma unroll
             for (int r = 0; r < 8; ++r)
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) p = fmaf(v[r], bv[r], p);
                 p += __shfl_xor(p, 32, 64);
-                if (h == 0) p512[wave * TB + l31] = p;
+                if (h == 0) p512[wave_u * TB + l31] = p;
             }
             stamp(4);
             __syncthreads();                                               // B2
@@ -433,14 +433,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const __amdgpu_buffer_rsrc_t rs_lu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.logu), 0, (int)((int64_t)g.nit * g.N * 4), 0x00020000);
         auto load_draws = [&](int m) __attribute__((always_inline)) {
             if (m < g.nit) {
-                const unsigned mb = (unsigned)m * (unsigned)ZD * rowb;
+                // (wave-uniform offsets pinned to scalar registers: hipcc kept m * rowb as a VECTOR induction variable, read it back lane by lane
+                // in a waterfall loop around the logu load, and waited for that load on the spot -- a memory round trip, 1 100 of wave 0's
+                // 1 700 serial clocks per chain step)
+                const unsigned mb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)m * (unsigned)ZD * rowb));
+                const int mlu = __builtin_amdgcn_readfirstlane((int)((unsigned)m * rowb));
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
                     nzv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_nz, voff, (int)(mb + (unsigned)((r & 3) + 8 * (r >> 2)) * rowb), 0));
-                lu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lu, (int)(nf * 4), (int)((unsigned)m * rowb), 0));
+                lu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lu, (int)(nf * 4), mlu, 0));
             }
         };
-        if (wave == 0 && g.nit > 0) load_draws(0);
+        if (wave_u == 0 && g.nit > 0) load_draws(0);
         // The kept sample and the trace of step m leave the CU behind step m + 1's proposal: vmcnt retires in issue order, so stores issued
         // in front of the proposal made the wait for the prefetched draws a wait for the stores' acknowledgement too (the serial section of
         // wave 0 -- everyone else waits at B0 -- was 2400 of a step's 13 200 clocks, tools/stamp_mcem.py)
@@ -462,11 +466,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (g.dbg) tlast = __builtin_amdgcn_s_memtime();
         for (int m = mstart; m < mend; ++m) {
             float prior_p = 0.f, lu_cur = 0.f;
-            if (wave == 0) {
+            if (wave_u == 0) {
                 if (m >= 0) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) zp[r] = z[r] + g.sd * nzv[r];                     // mcem.py:244
-                    lu_cur = lu;
+                    // a copy hipcc cannot sink below the request of the next step's draws: with a plain assignment the old value stayed live
+                    // across that load, the new one landed in a temporary, and the loop-carried copy waited for it on the spot
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(lu_cur) : "v"(lu));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) zp[r] = z[r];
@@ -499,11 +505,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (h == 0) ll += (double)term;
                 });
             ll += __shfl_xor(ll, 32, 64);
-            if (h == 0) red[wave * TB + l31] = ll;
+            if (h == 0) red[wave_u * TB + l31] = ll;
             stamp(7);
             __syncthreads();                                               // B3
             stamp(8);
-            if (wave == 0) {
+            if (wave_u == 0) {
                 const double ll_p = red[l31] + red[TB + l31] + red[2 * TB + l31] + red[3 * TB + l31];
                 if (m < 0) {
                     ll_cur = ll_p; prior_cur = prior_p;
@@ -520,18 +526,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             // red / p512 / Zb are next written behind the barriers of the following pass
         }
-        if (wave == 0) flush_step();
+        if (wave_u == 0) flush_step();
         if (g.dbg && lane == 0 && g.nit > 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) g.dbg[((size_t)blockIdx.x * 4 + wave) * 16 + k] = tsum[k];
-            g.dbg[((size_t)blockIdx.x * 4 + wave) * 16 + 9] = (unsigned long long)(mend - mstart);
+            for (int k = 0; k < 9; ++k) g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + k] = tsum[k];
+            g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 9] = (unsigned long long)(mend - mstart);
         }
 
         // ---- speech variances of the kept samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
         if (g.Vs != nullptr) {
             for (int r_s = 0; r_s < g.R; ++r_s) {
                 __syncthreads();
-                if (wave == 0) {
+                if (wave_u == 0) {
                     const float* src = g.Zs + ((int64_t)nf * g.R + r_s) * ZD;
                     const f32x4 s0 = *reinterpret_cast<const f32x4*>(src + 4 * h);
                     const f32x4 s1 = *reinterpret_cast<const f32x4*>(src + 8 + 4 * h);
@@ -579,6 +585,21 @@ int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s)
     if ((int64_t)XD * a.N * 4 >= ((int64_t)1 << 31) || (int64_t)a.nit * ZD * a.N * 4 >= ((int64_t)1 << 31)) {
         set_error("mcem resident chain: (F, N) matrices of 2 GB and more are not addressed");
         return DVAE_E_UNSUPPORTED;
+    }
+    // chains too short to fill the chip with 32-frame tiles (one utterance of 300 frames: ten tiles) run on 16-frame tiles: a step is bound
+    // by its epilogue, so half the frames per workgroup take about half the time (mcem_resident16.hip)
+    const char* const tile_s = getenv("DVAE_MCEM_TILE");                   // A/B and test switch, read per call
+    const int tile_env = tile_s ? atoi(tile_s) : 0;
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int64_t tiles16 = (a.N + 15) / 16;
+    if (tile_env != 32 && resident16_chain_supported(precision, yp) && (tile_env == 16 || tiles16 <= n_cu)) {
+        MhArgs b = a;
+        b.ntiles = (int)tiles16;
+        return launch_resident16_chain(precision, yp, b, s);
     }
     if (yp == 0) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, 0>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, 0>(a, s) : launch_resident_t<PolF32C, 0>(a, s);
     if (yp == 16) return precision == DVAE_PREC_BF16X3 ? launch_resident_t<PolX3C, 16>(a, s) : precision == DVAE_PREC_BF16 ? launch_resident_t<PolB1C, 16>(a, s) : launch_resident_t<PolF32C, 16>(a, s);

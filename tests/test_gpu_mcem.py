@@ -45,6 +45,14 @@ def setup(model, y_dim, N, seed, wscale=1.0, precision="fp32"):
     return params, prefix, pack, X2, y, Z, g, W, H, rng
 
 
+def pick_tile(monkeypatch, tile, precision):
+    """Frames per workgroup of the weight-stationary chain: 16 (csrc/mcem_resident16.hip, what short chains take by default under the
+    bf16 policies) or 32 (csrc/mcem_resident.hip); exact fp32 has the 32-frame kernel only."""
+    if tile == "16" and precision == "fp32":
+        pytest.skip("the 16-frame chain kernel exists for the bf16 policies")
+    monkeypatch.setenv("DVAE_MCEM_TILE", tile)
+
+
 def chains_agree(accd, trace_a):
     """per frame: index of the first iteration whose accept decision differs (nit if none)."""
     diff = accd != trace_a
@@ -52,10 +60,12 @@ def chains_agree(accd, trace_a):
     return first
 
 
+@pytest.mark.parametrize("tile", ["16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("model,y_dim,N", [("M1", 0, 45), ("M2", 1, 70), ("M2", 513, 33), ("M2_info", 1, 100)])
-def test_sample_posterior_matches_oracle(model, y_dim, N, precision):
+def test_sample_posterior_matches_oracle(model, y_dim, N, precision, tile, monkeypatch):
     """fp32 = exact fp32 products; bf16x3 = split-bf16 operands (16 mantissa bits, three MFMAs per product): the same bounds."""
+    pick_tile(monkeypatch, tile, precision)
     params, prefix, pack, X2, y, Z, g, W, H, rng = setup(model, y_dim, N, 5, precision=precision)
     nit, burnin = 12, 5
     noise = rng.standard_normal((nit, 16, N)).astype(np.float32)
@@ -106,11 +116,13 @@ def test_m_step_and_wiener_match_oracle(N, R, K):
     np.testing.assert_allclose((WFs + WFn).cpu().numpy(), 1.0, rtol=1e-5)        # the two gains partition the mixture
 
 
+@pytest.mark.parametrize("tile", ["16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", mc.CASES, ids=[c["name"] for c in mc.CASES])
-def test_full_run_matches_reference_golden(case, precision):
+def test_full_run_matches_reference_golden(case, precision, tile, monkeypatch):
     """EM.run on the draws recorded from the reference: state after every iteration vs the reference's (exact-fp32 and split-bf16
-    chain policies against the same bounds)."""
+    chain policies, 16- and 32-frame chain kernels, against the same bounds)."""
+    pick_tile(monkeypatch, tile, precision)
     fix = case_fix(case["name"])
     dims = mc.DIMS[case["model"]]
     params, prefix, pack, *_ = setup(case["model"], dims["y_dim"], case["N"], case["seed"], case["wscale"], precision=precision)
@@ -140,13 +152,15 @@ def test_full_run_matches_reference_golden(case, precision):
     assert (np.abs(WFn.cpu().numpy() - fix["WFn"]) > 5e-3).mean() < 0.05
 
 
+@pytest.mark.parametrize("tile", ["16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("model,y_dim,N", [("M2", 1, 300), ("M2", 513, 200), ("M1", 0, 257)])
-def test_chain_launches_are_bit_identical(model, y_dim, N, precision):
+def test_chain_launches_are_bit_identical(model, y_dim, N, precision, tile, monkeypatch):
     """The weight-stationary chain feeds its output-layer MFMAs from AGPR-pinned fragments through inline asm, i.e. outside the compiler's
     hazard bookkeeping (csrc/mcem_resident.hip): a write-after-read slip there shows up as bf16-level differences that change from launch
     to launch (that is how the first version was caught).  Four launches on the same draws return the same bits, every policy and label
-    variant, full-length E-step chain."""
+    variant, both tile sizes, full-length E-step chain."""
+    pick_tile(monkeypatch, tile, precision)
     params, prefix, pack, X2, y, Z, g, W, H, rng = setup(model, y_dim, N, 5, precision=precision)
     nit, burnin = 40, 30
     noise = rng.standard_normal((nit, 16, N)).astype(np.float32)

@@ -1,0 +1,65 @@
+// Round 5: what a dependent chain of v_mfma_f32_16x16x32_bf16 costs, alone and with the MCEM likelihood epilogue's VALU work between the
+// MFMAs (csrc/mcem_resident16.hip: 12 dependent MFMAs per output tile, three transcendentals + four plain VALU per bin).  One wave per SIMD,
+// one workgroup, s_memtime ticks (= shader clocks here) per MFMA slot, measured around 96 x REP of them.  Variants:
+//   0 dependent chain   1 two independent chains, alternating   2 dependent chain, one v_exp_f32 behind every MFMA
+//   3 dependent chain, v_exp_f32 + two v_fma_f32 behind every MFMA   4 two chains alternating, v_exp_f32 + two v_fma_f32 behind every MFMA
+//   5 no MFMA, the VALU work of 3 alone   6 dependent chain, two v_fma_f32 behind every MFMA
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/r05/mfma16_chain_bench.hip -o tools/r05/bin/mfma16_chain_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int V>
+__global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink, int rep) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    float e = 0.5f + lane * 1e-3f, f = 1.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rep; ++r) {
+#pragma unroll
+        for (int i = 0; i < 96; ++i) {
+            if constexpr (V != 5) {
+                if constexpr (V == 1 || V == 4) {
+                    if (i & 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a), "v"(b));
+                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b));
+                } else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b));
+            }
+            if constexpr (V == 2 || V == 3 || V == 4 || V == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(e));
+            if constexpr (V == 3 || V == 4 || V == 5 || V == 6) asm volatile("v_fma_f32 %0, %0, %1, %1\n\tv_fma_f32 %0, %0, %1, %1" : "+v"(f) : "v"(e));
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[threadIdx.x >> 6] = t1 - t0;
+    sink[threadIdx.x] = c0[0] + c1[1] + e + f;
+}
+
+template <int V> void run(const char* what) {
+    unsigned long long* out; float* sink;
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&sink, 4096));
+    const int rep = 200;
+    hipLaunchKernelGGL(k<V>, dim3(1), dim3(256), 0, 0, out, sink, rep);
+    hipLaunchKernelGGL(k<V>, dim3(1), dim3(256), 0, 0, out, sink, rep);
+    CK(hipDeviceSynchronize());
+    unsigned long long h[4];
+    CK(hipMemcpy(h, out, 32, hipMemcpyDeviceToHost));
+    // (s_memtime ticks at the shader clock here: a back-to-back chain of these 4-pass MFMAs reads 16.15 per MFMA)
+    printf("%d %-70s %.1f s_memtime ticks per 96 slots = %.2f per slot\n", V, what, (double)h[0] / rep, (double)h[0] / rep / 96.0);
+    CK(hipFree(out)); CK(hipFree(sink));
+}
+
+int main() {
+    run<0>("dependent chain");
+    run<1>("two independent chains, alternating");
+    run<2>("dependent chain + v_exp_f32");
+    run<3>("dependent chain + v_exp_f32 + 2 v_fma_f32");
+    run<4>("two chains alternating + v_exp_f32 + 2 v_fma_f32");
+    run<5>("v_exp_f32 + 2 v_fma_f32, no MFMA");
+    run<6>("dependent chain + 2 v_fma_f32");
+    return 0;
+}

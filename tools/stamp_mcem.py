@@ -14,12 +14,13 @@ mc.DIMS["bench"] = dims
 X, S, y = mc.make_utterance(dict(seed=5, N=300, model="bench"))
 mb = M.McemBatch(m, niter=3, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, precision=prec)
 mb.init_parameters([X] * U, [torch.from_numpy(y).cuda()] * U); mb.run()
-ntiles = mb.ntot // 32
+ntiles = mb.ntot // 16                                   # room for 16-frame tiles (csrc/mcem_resident16.hip); 32-frame launches fill the first half
 buf = torch.zeros(ntiles * 4 * 16, dtype=torch.int64, device="cuda")
 N.load().dvae_mcem_debug_stamps(N.ptr(buf))
 Zs, Vs = mb._chain(10, 30)
 torch.cuda.synchronize(); N.load().dvae_mcem_debug_stamps(None)
 r = buf.cpu().numpy().reshape(ntiles, 4, 16).astype(np.float64)
+r = r[r[:, 0, 9] > 0]; ntiles = len(r)
 steps = r[:, :, 9:10]
 per = r[:, :, :9] / np.maximum(steps, 1)
 names = ["P4+P0 (accept, next proposal)", "wait B0", "L1 + tanh + put", "wait B1", "L2 + tanh + put + bin-512 terms", "wait B2", "output layer + likelihood", "reduce + red write", "wait B3"]
