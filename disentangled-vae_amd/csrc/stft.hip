@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // per-bin constants of the whole workgroup in LDS (two waves per SIMD need the kernel under 256 registers):
     // tw[k] = exp(+2 pi i k / 1024); wn[k] = (window[2 k], -window[2 k + 1]) / M  (conj and 1/M folded into the window)
     __shared__ double2 tw[M], wn[M];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform chunk and frame numbers: scalar loop control and addresses
     double* re = lre[wave];
     double* im = lim[wave];
     for (int k = threadIdx.x; k < M; k += 256) {
