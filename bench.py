@@ -242,6 +242,17 @@ def side_kernels(device):
                                         "utterances_per_s": U / dt, "decoder_TFLOP_per_s": flops / dt * 1e-12, "mfma_frac": flops / dt * 1e-12 / peak,
                                         "mfma_peak_TFLOP_per_s": peak,
                                         "note": "whole run incl. M-steps and the Wiener chain; flops = decoder MACs x 2 of the chain / decode passes the kernels execute"}
+    # ONE utterance -- what scripts/evaluate_ntcd_M2.py runs per process: the chain on 16-frame tiles (csrc/mcem_resident16.hip), 20 of 256 CUs busy
+    mb = M.McemBatch(vae, niter=2, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, label_in_encoder=True,
+                     label_in_decoder=True, precision="bf16x3")
+    mb.init_parameters([X], [y]); mb.run()
+    mb.niter = 100
+    mb.init_parameters([X], [y])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mb.run()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out["mcem_single_bf16x3"] = {"utterances": 1, "frames_each": N, "em_iterations": 100, "ms_per_utterance": 1e3 * dt, "ms_per_em_iteration": 10.0 * dt,
+                                 "note": "the reference's settings (100 EM iterations, 10 + 30 chain steps each, final Wiener chain 25 + 75)"}
     return out
 
 
@@ -589,6 +600,11 @@ def main():
             for k in ("spread", "encoder_gemm", "large_batch"):
                 if out.get(k) is not None:
                     out["roofline"][k] = out[k]
+            sk = out.get("side_kernels")
+            if isinstance(sk, dict) and "error" not in sk:
+                # one figure per side kernel: microseconds per launch (STFT / ISTFT of ten minutes of audio), utterances per second / milliseconds per utterance (MCEM)
+                out["roofline"]["side_kernels"] = {k: (round(v["us"], 1) if "us" in v else round(v.get("utterances_per_s", v.get("ms_per_utterance", 0.0)), 1))
+                                                   for k, v in sk.items() if isinstance(v, dict)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model, dims, B, a.cpu_seconds)
             if "b128" in out:

@@ -6,9 +6,11 @@
 //
 // Same decomposition as the 32-frame kernel -- one 256-thread workgroup per tile, one wave per SIMD, the whole decoder in the lane's 512
 // registers for the launch, the tile's X2 / Vb on chip for the chain, four workgroup barriers per step -- on v_mfma_f32_16x16x32_bf16
-// (bf16 policies only: split bf16 = three MFMAs per product, and plain bf16):
+// (split bf16 = three MFMAs per product, and plain bf16) or v_mfma_f32_16x16x4_f32 (exact fp32 products: MFMA-bound, half the frames = half
+// the matrix work per workgroup):
 //   * the lane is (frame f = lane & 15, quarter q = lane >> 4): a 16 x 16 C tile holds rows 4 q .. 4 q + 3 of frame f in the lane's four
-//     accumulator registers; an operand fragment is the 16-byte chunk (row or frame = lane & 15, k octet q) of a 32-deep k-step;
+//     accumulator registers; an operand fragment is the 16-byte chunk (row or frame = lane & 15, chunk q) of a k-step of four chunks (32
+//     deep in bf16; 16 deep in fp32, where MFMA j of the k-step takes element j of the chunk: lane quarter q supplies k = 4 q + j);
 //   * the weight copies are the 32-row fragment-major ones of the 32-frame kernel ([k-step of 16][32-row tile][lane][8]): both shapes are made
 //     of the same 16-byte chunks (row, k octet), so a lane gathers its chunk of a (16-row tile, k-step of 32) fragment by its own offset
 //     -- once per launch;
@@ -31,20 +33,40 @@ namespace fused {
 
 struct PolX3S : PolX3 {};
 struct PolB1S : PolBF16 {};
+struct PolF32S : PolF32 {            // exact fp32 products (v_mfma_f32_16x16x4_f32, four per 16-deep k-step); epilogue on the hardware exp2 / log2 / rcp
+                                     // units, as the 32-frame fp32 chain (mcem_resident.hip: PolF32C)
+    static __device__ __forceinline__ float exp_(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896341f); }
+    static __device__ __forceinline__ float log_(float v) { return __builtin_amdgcn_logf(v) * 0.693147180559945309f; }
+    static __device__ __forceinline__ float tanh_(float v) {
+        const float e = __builtin_amdgcn_exp2f(v * 2.88539008177792681f);
+        return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    }
+    static __device__ __forceinline__ float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+};
 struct PolX3SY : PolX3S {};          // the label image of a tile (513 label rows), its own plane stride
 struct PolB1SY : PolB1S {};
+struct PolF32SY : PolF32S {};
 constexpr int T16 = 16;                                                  // frames per tile
-constexpr int S_LDH = HD + 8, S_LDZ = 32 + 8, S_LDC = HD + 4, S_LDY = NO + 8;
-constexpr int S_PLANE = T16 * (2 * S_LDH + S_LDZ);                       // bf16 elements of one operand plane: h1, h2, latents
-template <> struct Pl<PolX3S> { static constexpr int lds = S_PLANE; };
+// LDS rows ([frame][feature]): one 16-byte chunk of padding; a k-step is four chunks (32 deep in bf16, 16 deep in fp32)
+template <typename T> struct SL {
+    static constexpr int E = 16 / (int)sizeof(T), KW = 4 * E;
+    static constexpr int ldh = HD + E, ldz = (ZD > KW ? ZD : KW) + E, ldy = NO + E;
+    static constexpr int plane = T16 * (2 * ldh + ldz);                  // elements of one operand plane: h1, h2, latents
+};
+constexpr int S_LDC = HD + 4;
+template <> struct Pl<PolX3S> { static constexpr int lds = SL<__bf16>::plane; };
 template <> struct Pl<PolB1S> { static constexpr int lds = 0; };
-template <> struct Pl<PolX3SY> { static constexpr int lds = T16 * S_LDY; };
+template <> struct Pl<PolF32S> { static constexpr int lds = 0; };
+template <> struct Pl<PolX3SY> { static constexpr int lds = T16 * SL<__bf16>::ldy; };
 template <> struct Pl<PolB1SY> { static constexpr int lds = 0; };
+template <> struct Pl<PolF32SY> { static constexpr int lds = 0; };
 template <typename P> struct YPolS;
 template <> struct YPolS<PolX3S> { typedef PolX3SY type; };
 template <> struct YPolS<PolB1S> { typedef PolB1SY type; };
+template <> struct YPolS<PolF32S> { typedef PolF32SY type; };
 
-constexpr size_t S_O_X2 = (size_t)S_PLANE * 2 * sizeof(__bf16);
+constexpr size_t S_O_X2 = (size_t)SL<__bf16>::plane * 2 * sizeof(__bf16);      // (one fp32 plane is exactly as large: 16 x (2 x 132 + 20) x 4 bytes)
+static_assert((size_t)SL<float>::plane * sizeof(float) <= S_O_X2, "the fp32 activation plane fits the two bf16 planes");
 constexpr size_t S_O_VB = S_O_X2 + (size_t)32 * 64 * 4 * sizeof(float);             // X2: [row tile 0..31][lane][4]
 constexpr size_t S_O_C1 = S_O_VB + (size_t)32 * 64 * 4 * sizeof(float);             // Vb likewise
 constexpr size_t S_O_BIAS = S_O_C1 + (size_t)T16 * S_LDC * sizeof(float);
@@ -53,7 +75,8 @@ constexpr size_t S_O_P512 = S_O_W512 + (size_t)HD * sizeof(float);
 constexpr size_t S_O_RED = S_O_P512 + (size_t)4 * T16 * sizeof(float);
 constexpr size_t S_LDS = S_O_RED + (size_t)4 * T16 * sizeof(double);
 static_assert(S_O_X2 % 16 == 0 && S_O_C1 % 16 == 0 && S_O_BIAS % 16 == 0 && S_O_RED % 8 == 0 && S_LDS <= 160 * 1024, "resident chain (16 frames): LDS layout");
-static_assert((size_t)T16 * S_LDY * 2 * sizeof(__bf16) <= S_O_C1 - S_O_X2, "the label image fits the X2 / Vb area");
+static_assert((size_t)T16 * SL<__bf16>::ldy * 2 * sizeof(__bf16) <= S_O_C1 - S_O_X2 && (size_t)T16 * SL<float>::ldy * sizeof(float) <= S_O_C1 - S_O_X2,
+              "the label image fits the X2 / Vb area");
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -65,6 +88,11 @@ __device__ __forceinline__ void sfor16(F&& f) {
 // acc += a * b over the plane pairs that matter (hi*hi, lo*hi, hi*lo), compiler-scheduled (layers 1 and 2, the label GEMM)
 template <typename P>
 __device__ __forceinline__ void mm16(f32x4_t& acc, const typename P::Frag (&a)[P::NP], const typename P::Frag (&b)[P::NP]) {
+    if constexpr (sizeof(typename P::T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][j], b[0][j], acc, 0, 0, 0);
+        return;
+    } else
     if constexpr (P::NP == 2) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
@@ -77,11 +105,13 @@ __device__ __forceinline__ void mm16(f32x4_t& acc, const typename P::Frag (&a)[P
 // behind the last MFMA, 12, are the 8-pass requirement; a leading s_nop 1 covers a VALU-written SrcC should hipcc ever move the bias through
 // a VALU copy; dependent MFMAs accumulate back to back).  between(k-step i, slot j): work placed behind the j-th MFMA of k-step i.
 template <typename P, int NAG, typename Between>
-__device__ __forceinline__ void gemm16_agpr(f32x4_t& acc, const typename P::Frag (&w)[4][P::NP], const typename P::T* brow, Between&& between) {
+__device__ __forceinline__ void gemm16_agpr(f32x4_t& acc, const typename P::Frag (&w)[HD / (4 * P::E)][P::NP], const typename P::T* brow, Between&& between) {
     typedef typename P::Frag Frag;
+    constexpr int KW = 4 * P::E, NKS = HD / KW;                            // bf16: 4 k-steps of 32; fp32: 8 k-steps of 16
+    constexpr bool F32 = sizeof(typename P::T) == 4;
     Frag bq[2][P::NP];
     bloadp<P>(bq[0], brow);
-    bloadp<P>(bq[1], brow + 32);
+    bloadp<P>(bq[1], brow + KW);
     auto mm = [&](auto first, auto last, auto ag, const Frag& a, const Frag& b) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value, LAST = decltype(last)::value, AG = decltype(ag)::value;
         if constexpr (FIRST) {
@@ -95,14 +125,35 @@ __device__ __forceinline__ void gemm16_agpr(f32x4_t& acc, const typename P::Frag
             else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
         }
     };
+    // fp32: one v_mfma_f32_16x16x4_f32 (8 passes) per fragment element: lane quarter q supplies k = 4 q + j of the k-step to MFMA j
+    auto mf = [&](auto first, auto last, auto ag, float a, float b) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value, LAST = decltype(last)::value, AG = decltype(ag)::value;
+        if constexpr (FIRST) {
+            if constexpr (AG) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        } else if constexpr (LAST) {
+            if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 3" : "+v"(acc) : "v"(a), "v"(b));
+        } else {
+            if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        }
+    };
     typedef std::integral_constant<bool, false> F;
     typedef std::integral_constant<bool, true> Tr;
-    sfor16<0, 4>([&](auto ic) {
+    sfor16<0, NKS>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         typedef std::integral_constant<bool, (i < NAG)> Ag;
         typedef std::integral_constant<bool, i == 0> Fi;
-        typedef std::integral_constant<bool, i == 3> L;
-        if constexpr (P::NP == 2) {
+        typedef std::integral_constant<bool, i == NKS - 1> L;
+        if constexpr (F32) {
+            mf(Fi{}, F{}, Ag{}, w[i][0][0], bq[i & 1][0][0]);
+            mf(F{}, F{}, Ag{}, w[i][0][1], bq[i & 1][0][1]);
+            between(ic, std::integral_constant<int, 0>{});
+            mf(F{}, F{}, Ag{}, w[i][0][2], bq[i & 1][0][2]);
+            between(ic, std::integral_constant<int, 1>{});
+            mf(F{}, L{}, Ag{}, w[i][0][3], bq[i & 1][0][3]);
+        } else if constexpr (P::NP == 2) {
             // (hipcc moves the VALU work freely across the statements; pinning one part of a bin between two MFMAs with scheduling fences
             // measured slower, 4000 against 3600 clocks per step: tools/r05/mfma16_chain_bench.hip -- a dependent chain of these MFMAs issues
             // back to back at 16 clocks each, and any VALU work between two of them costs its own time plus 8 clocks, chained or not)
@@ -120,7 +171,7 @@ __device__ __forceinline__ void gemm16_agpr(f32x4_t& acc, const typename P::Frag
             between(ic, std::integral_constant<int, 0>{});
             between(ic, std::integral_constant<int, 1>{});
         }
-        if constexpr (i + 2 < 4) bloadp<P>(bq[i & 1], brow + (i + 2) * 32);
+        if constexpr (i + 2 < NKS) bloadp<P>(bq[i & 1], brow + (i + 2) * KW);
         between(ic, std::integral_constant<int, 2>{});
     });
 }
@@ -130,10 +181,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef typename P::T T;
     typedef typename P::Frag Frag;
     typedef typename P::Pack4 Pack4;
-    constexpr int NP = P::NP;
-    constexpr int NK = HD / 32;                                           // k-steps of 32 of the 128-deep layers
+    constexpr int NP = P::NP, E = P::E;
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int KW = 4 * E;                                             // depth of a k-step: four 16-byte chunks (bf16: 32, fp32: 16)
+    constexpr int NK = HD / KW;                                           // k-steps of the 128-deep layers (4 / 8)
     constexpr int NTW = 8;                                                // output tiles (16 bins) per wave
-    constexpr int NAGL = NP == 2 ? 2 : NK;                                // k-steps of the last tile whose fragments live in AGPRs (<= 240 in all)
+    constexpr int NAGL = F32 ? 4 : (NP == 2 ? 2 : NK);                    // k-steps of the last tile whose fragments live in AGPRs (<= 240 in all)
+    constexpr int S_LDH = SL<T>::ldh, S_LDZ = SL<T>::ldz, S_LDY = SL<T>::ldy;
     constexpr int OB4 = HD, OB5 = 2 * HD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* const Ha = reinterpret_cast<T*>(smem);
@@ -159,18 +213,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the lane's chunk of fragment (16-row tile rt16, k octet o) of a copy with nt 32-row tiles per k-step of 16
     auto chunk_off = [&](int64_t base_elems, int nt, int rt16, int o) __attribute__((always_inline)) {
         const int row = 16 * rt16 + f16;
-        return (unsigned)(base_elems * (int64_t)sizeof(T)) + (unsigned)((((o >> 1) * nt + (row >> 5)) * 64 + (o & 1) * 32 + (row & 31)) * 16);
+        return (unsigned)(base_elems * (int64_t)sizeof(T)) + (unsigned)((((o >> 1) * nt + (row >> 5)) * 64 + (o & 1) * 32 + (row & 31)) * 16);   // chunk o: E elements
     };
     const Frag zfrag = __builtin_bit_cast(Frag, u32x4{0u, 0u, 0u, 0u});
 
     // ---- resident weight fragments (once per launch) ----
     Frag w3zR[2][NP], w4R[2][NK][NP], w5R[NTW][NK][NP];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {                                       // the 16 latent columns of decoder layer 1: k octets 0, 1; octets 2, 3 are zero
-        const unsigned o3 = chunk_off(g.oW3, 4, 2 * wave_u + rt, q & 1);
+    for (int rt = 0; rt < 2; ++rt) {                                       // the 16 latent columns of decoder layer 1: bf16: k octets 0, 1 (octets 2, 3 zero); fp32: quads 0 .. 3
+        const unsigned o3 = chunk_off(g.oW3, 4, 2 * wave_u + rt, F32 ? q : (q & 1));
         w3zR[rt][0] = ld16(o3);
         if constexpr (NP == 2) w3zR[rt][1] = ld16(o3 + g.wpl);
-        if (q >= 2) { w3zR[rt][0] = zfrag; if constexpr (NP == 2) w3zR[rt][1] = zfrag; }
+        if constexpr (!F32) { if (q >= 2) { w3zR[rt][0] = zfrag; if constexpr (NP == 2) w3zR[rt][1] = zfrag; } }
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -191,10 +245,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     for (int i = tid; i < 2 * HD + NO; i += 256) Bias[i] = g.bias[i];
-    // element (row, column k) of a copy: k-step k / 16, lane' = (k % 16) / 8 * 32 + row % 32, element k % 8
+    // element (row, column k) of a copy: k-step k / (2 E), lane' = (k % (2 E)) / E * 32 + row % 32, element k % E
     const T* const wc = reinterpret_cast<const T*>(g.wcopy);
     auto welem = [&](int64_t base, int nt, int row, int k) __attribute__((always_inline)) {
-        const int64_t e = base + ((int64_t)((k / 16) * nt + (row >> 5)) * 64 + ((k % 16) / 8) * 32 + (row & 31)) * 8 + (k % 8);
+        const int64_t e = base + ((int64_t)((k / (2 * E)) * nt + (row >> 5)) * 64 + ((k % (2 * E)) / E) * 32 + (row & 31)) * E + (k % E);
         float v = (float)wc[e];
         if constexpr (NP == 2) v += (float)*reinterpret_cast<const T*>(reinterpret_cast<const char*>(wc + e) + g.wpl);
         return v;
@@ -202,9 +256,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (tid < HD) w512s[tid] = welem(g.oW5, NT_OUT, 512, tid);            // row 512 of the output layer
     __syncthreads();
     const float b512 = Bias[OB5 + 512];
-    const T* const Zbr = Zb + f16 * S_LDZ + q * 8;
-    const T* const Har = Ha + f16 * S_LDH + q * 8;
-    const T* const Hbr = Hb + f16 * S_LDH + q * 8;
+    const T* const Zbr = Zb + f16 * S_LDZ + q * E;
+    const T* const Har = Ha + f16 * S_LDH + q * E;
+    const T* const Hbr = Hb + f16 * S_LDH + q * E;
 
     for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
         const int64_t n0 = (int64_t)tile * T16;
@@ -214,8 +268,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
         // ---- per tile: label part of decoder layer 1 (fp32, constant along the chain), X2 / Vb -> LDS ----
         if constexpr (YP == NO) {
-            // 513 label rows: one GEMM per tile on the label block of W3 (17 k-steps of 32, gathered from the copy), the tile's labels as a
-            // [frame][544] operand image in the area X2 / Vb take afterwards
+            // 513 label rows: one GEMM per tile on the label block of W3 (17 k-steps of 32 / 34 of 16, gathered from the copy), the tile's labels
+            // as a [frame][544] operand image in the area X2 / Vb take afterwards
             typedef typename YPolS<P>::type PY;
             T* const Yb = reinterpret_cast<T*>(smem + S_O_X2);
             for (int idx = tid; idx < T16 * NO; idx += 256) {
@@ -228,20 +282,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             __syncthreads();
             f32x4_t cacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-            const T* const Ybr = Yb + f16 * S_LDY + q * 8;
+            const T* const Ybr = Yb + f16 * S_LDY + q * E;
 #pragma unroll 1
-            for (int ks = 0; ks < NO / 32; ++ks) {
-                const int o = 4 * ks + q;                                  // k octet within the label block; the block starts at k-step 1 of the copy
-                const bool in = o < XP / 8;                                // the copy holds 33 label k-steps of 16 (528 columns)
+            for (int ks = 0; ks < NO / KW; ++ks) {
+                const int o = 4 * ks + q;                                  // 16-byte chunk within the label block; the block starts behind the 16 latent columns
+                const bool in = o < XP / E;                                // the copy holds 528 label columns
                 Frag a[2][NP], b[NP];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const unsigned oy = chunk_off(g.oW3, 4, 2 * wave_u + rt, in ? 2 + o : 0);
+                    const unsigned oy = chunk_off(g.oW3, 4, 2 * wave_u + rt, in ? ZD / E + o : 0);
                     a[rt][0] = ld16(oy);
                     if constexpr (NP == 2) a[rt][1] = ld16(oy + g.wpl);
                     if (!in) { a[rt][0] = zfrag; if constexpr (NP == 2) a[rt][1] = zfrag; }
                 }
-                bloadp<PY>(b, Ybr + ks * 32);
+                bloadp<PY>(b, Ybr + ks * KW);
                 mm16<P>(cacc[0], a[0], b);
                 mm16<P>(cacc[1], a[1], b);
             }
@@ -305,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int j = 0; j < 4; ++j) z[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z0, zoff, (int)((unsigned)j * rowb), 0));
         }
-        if (wave_u == 0) {                                                   // the zero half of the latent operand rows (k 16 .. 31), once per tile
+        if (!F32 && wave_u == 0) {                                           // bf16: the zero half of the latent operand rows (k 16 .. 31), once per tile
             Pack4 zz;
             zz[0] = P::cvt(0.f); zz[1] = zz[0]; zz[2] = zz[0]; zz[3] = zz[0];
             *reinterpret_cast<Pack4*>(Zb + f16 * S_LDZ + 16 + 4 * q) = zz;
@@ -356,14 +410,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             {
                 Frag b[2][NP];
                 bloadp<P>(b[0], Har);
-                bloadp<P>(b[1], Har + 32);
+                bloadp<P>(b[1], Har + KW);
                 a2[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 a2[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NK; ++ks) {
                     mm16<P>(a2[0], w4R[0][ks], b[ks & 1]);
                     mm16<P>(a2[1], w4R[1][ks], b[ks & 1]);
-                    if (ks + 2 < NK) bloadp<P>(b[ks & 1], Har + (ks + 2) * 32);
+                    if (ks + 2 < NK) bloadp<P>(b[ks & 1], Har + (ks + 2) * KW);
                 }
             }
             {
@@ -403,7 +457,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     bias_into(nxt, t + 1);
                     gemm16_agpr<P, (tt + 1 < NTW - 1 ? NK : NAGL)>(nxt, w5R[tt + 1], Hbr, [&](auto ic, auto jc) {
                         constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-                        epi(tc, t, ic, jc, cur[i], xq[tt & 1][i], vq[tt & 1][i]);
+                        // bf16: bin i of the tile behind k-step i, its three parts in the three slots; fp32 (eight k-steps): bin i / 2, parts
+                        // 0 and 1 behind the even k-step, part 2 behind the odd one
+                        if constexpr (!F32) epi(tc, t, ic, jc, cur[i], xq[tt & 1][i], vq[tt & 1][i]);
+                        else if constexpr ((i & 1) == 0 && j < 2) epi(tc, t, std::integral_constant<int, i / 2>{}, jc, cur[i / 2], xq[tt & 1][i / 2], vq[tt & 1][i / 2]);
+                        else if constexpr ((i & 1) == 1 && j == 0) epi(tc, t, std::integral_constant<int, i / 2>{}, std::integral_constant<int, 2>{}, cur[i / 2], xq[tt & 1][i / 2], vq[tt & 1][i / 2]);
                         if constexpr (j == 2 && i == 0) {
                             xq[(tt + 1) & 1] = X2s[(t + 1) * 64 + lane];
                             vq[(tt + 1) & 1] = Vbs[(t + 1) * 64 + lane];
@@ -574,14 +632,16 @@ static int launch_resident16_t(const MhArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool resident16_chain_supported(int precision, int yp) { return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16) && (yp == 0 || yp == 16 || yp == XP); }
+bool resident16_chain_supported(int precision, int yp) {
+    return (precision == DVAE_PREC_BF16X3 || precision == DVAE_PREC_BF16 || precision == DVAE_PREC_F32) && (yp == 0 || yp == 16 || yp == XP);
+}
 
 // a.ntiles: 16-frame tiles
 int launch_resident16_chain(int precision, int yp, const MhArgs& a, hipStream_t s) {
-    const bool x3 = precision == DVAE_PREC_BF16X3;
-    if (yp == 0) return x3 ? launch_resident16_t<PolX3S, 0>(a, s) : launch_resident16_t<PolB1S, 0>(a, s);
-    if (yp == 16) return x3 ? launch_resident16_t<PolX3S, 16>(a, s) : launch_resident16_t<PolB1S, 16>(a, s);
-    if (yp == XP) return x3 ? launch_resident16_t<PolX3S, NO>(a, s) : launch_resident16_t<PolB1S, NO>(a, s);
+    const bool x3 = precision == DVAE_PREC_BF16X3, f32 = precision == DVAE_PREC_F32;
+    if (yp == 0) return x3 ? launch_resident16_t<PolX3S, 0>(a, s) : f32 ? launch_resident16_t<PolF32S, 0>(a, s) : launch_resident16_t<PolB1S, 0>(a, s);
+    if (yp == 16) return x3 ? launch_resident16_t<PolX3S, 16>(a, s) : f32 ? launch_resident16_t<PolF32S, 16>(a, s) : launch_resident16_t<PolB1S, 16>(a, s);
+    if (yp == XP) return x3 ? launch_resident16_t<PolX3S, NO>(a, s) : f32 ? launch_resident16_t<PolF32S, NO>(a, s) : launch_resident16_t<PolB1S, NO>(a, s);
     set_error("mcem resident chain (16 frames): label rows 0, 1..16 or 513 only");
     return DVAE_E_UNSUPPORTED;
 }

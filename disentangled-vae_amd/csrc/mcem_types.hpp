@@ -31,7 +31,7 @@ struct MhArgs {
 // weight-stationary chain (mcem_resident.hip): every operand policy, label rows 0 / 1..16
 bool resident_chain_supported(int precision, int yp);
 int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s);
-// the same chain on 16-frame tiles (mcem_resident16.hip: bf16 policies; a.ntiles counts 16-frame tiles): launch_resident_chain takes it when
+// the same chain on 16-frame tiles (mcem_resident16.hip; a.ntiles counts 16-frame tiles): launch_resident_chain takes it when
 // the 16-frame tiles of the call fit the chip in one round (DVAE_MCEM_TILE=16 / 32 forces either)
 bool resident16_chain_supported(int precision, int yp);
 int launch_resident16_chain(int precision, int yp, const MhArgs& a, hipStream_t s);

@@ -46,10 +46,8 @@ def setup(model, y_dim, N, seed, wscale=1.0, precision="fp32"):
 
 
 def pick_tile(monkeypatch, tile, precision):
-    """Frames per workgroup of the weight-stationary chain: 16 (csrc/mcem_resident16.hip, what short chains take by default under the
-    bf16 policies) or 32 (csrc/mcem_resident.hip); exact fp32 has the 32-frame kernel only."""
-    if tile == "16" and precision == "fp32":
-        pytest.skip("the 16-frame chain kernel exists for the bf16 policies")
+    """Frames per workgroup of the weight-stationary chain: 16 (csrc/mcem_resident16.hip, what chains take by default while their 16-frame
+    tiles fit the chip in one round) or 32 (csrc/mcem_resident.hip)."""
     monkeypatch.setenv("DVAE_MCEM_TILE", tile)
 
 
