@@ -39,6 +39,85 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, float* sink
     sink[threadIdx.x] = c0[0] + c1[1] + e + f;
 }
 
+// fp32 MFMAs (the exact-fp32 MCEM chains): W = 0: v_mfma_f32_16x16x4_f32 (8 passes), W = 1: v_mfma_f32_32x32x2_f32 (16 passes); NCH chains alternating
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int W, int NCH>
+__global__ __launch_bounds__(256, 1) void kf(unsigned long long* out, float* sink, int rep) {
+    const int lane = threadIdx.x & 63;
+    float a = 0.001f * lane, b = 0.002f * lane;
+    f32x4 c4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x16 c16[2];
+    for (int i = 0; i < 16; ++i) { c16[0][i] = 0.f; c16[1][i] = 0.f; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rep; ++r) {
+#pragma unroll
+        for (int i = 0; i < 96; ++i) {
+            if constexpr (W == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c4[i % NCH]) : "v"(a), "v"(b));
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c16[i % NCH]) : "v"(a), "v"(b));
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[threadIdx.x >> 6] = t1 - t0;
+    sink[threadIdx.x] = c4[0][0] + c4[1][1] + c4[2][2] + c4[3][3] + c16[0][0] + c16[1][1];
+}
+
+template <int W, int NCH> void runf(const char* what) {
+    unsigned long long* out; float* sink;
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&sink, 4096));
+    const int rep = 200;
+    hipLaunchKernelGGL((kf<W, NCH>), dim3(1), dim3(256), 0, 0, out, sink, rep);
+    hipLaunchKernelGGL((kf<W, NCH>), dim3(1), dim3(256), 0, 0, out, sink, rep);
+    CK(hipDeviceSynchronize());
+    unsigned long long h[4];
+    CK(hipMemcpy(h, out, 32, hipMemcpyDeviceToHost));
+    printf("f %-70s %.1f s_memtime ticks per 96 slots = %.2f per slot\n", what, (double)h[0] / rep, (double)h[0] / rep / 96.0);
+    CK(hipFree(out)); CK(hipFree(sink));
+}
+
+// the epilogue's instruction mix with no dependences between consecutive instructions: per slot NT transcendentals (v_exp_f32 on eight rotating
+// registers) and NF v_fma_f32 (eight rotating registers), with MF = 0 no MFMA, 1 a dependent v_mfma_f32_16x16x32_bf16, 2 a dependent v_mfma_f32_16x16x4_f32
+template <int MF, int NT, int NF>
+__global__ __launch_bounds__(256, 1) void km(unsigned long long* out, float* sink, int rep) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
+    float af = 0.001f * lane, bf = 0.002f * lane;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+    float e[8], f[8];
+    for (int i = 0; i < 8; ++i) { e[i] = 0.1f * i + lane * 1e-3f; f[i] = 1.f + i; }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rep; ++r) {
+#pragma unroll
+        for (int i = 0; i < 96; ++i) {
+            if constexpr (MF == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b));
+            if constexpr (MF == 2) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c0) : "v"(af), "v"(bf));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) asm volatile("v_exp_f32 %0, %0" : "+v"(e[(i * NT + t) & 7]));
+#pragma unroll
+            for (int t = 0; t < NF; ++t) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(i * NF + t) & 7]) : "v"(af));
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[threadIdx.x >> 6] = t1 - t0;
+    float sm = c0[0];
+    for (int i = 0; i < 8; ++i) sm += e[i] + f[i];
+    sink[threadIdx.x] = sm;
+}
+template <int MF, int NT, int NF> void runm(const char* what) {
+    unsigned long long* out; float* sink;
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&sink, 4096));
+    const int rep = 200;
+    hipLaunchKernelGGL((km<MF, NT, NF>), dim3(1), dim3(256), 0, 0, out, sink, rep);
+    hipLaunchKernelGGL((km<MF, NT, NF>), dim3(1), dim3(256), 0, 0, out, sink, rep);
+    CK(hipDeviceSynchronize());
+    unsigned long long h[4];
+    CK(hipMemcpy(h, out, 32, hipMemcpyDeviceToHost));
+    printf("m %-70s %.1f s_memtime ticks per 96 slots = %.2f per slot\n", what, (double)h[0] / rep, (double)h[0] / rep / 96.0);
+    CK(hipFree(out)); CK(hipFree(sink));
+}
+
 template <int V> void run(const char* what) {
     unsigned long long* out; float* sink;
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&sink, 4096));
@@ -61,5 +140,19 @@ int main() {
     run<4>("two chains alternating + v_exp_f32 + 2 v_fma_f32");
     run<5>("v_exp_f32 + 2 v_fma_f32, no MFMA");
     run<6>("dependent chain + 2 v_fma_f32");
+    runm<0, 1, 0>("independent VALU: 1 v_exp_f32 per slot, no MFMA");
+    runm<0, 0, 4>("independent VALU: 4 v_fma_f32 per slot, no MFMA");
+    runm<0, 1, 2>("independent VALU: 1 v_exp_f32 + 2 v_fma_f32 per slot, no MFMA");
+    runm<1, 1, 2>("bf16 16x16x32 chain + 1 v_exp_f32 + 2 v_fma_f32 (independent) per slot");
+    runm<1, 0, 4>("bf16 16x16x32 chain + 4 v_fma_f32 (independent) per slot");
+    runm<1, 1, 0>("bf16 16x16x32 chain + 1 v_exp_f32 per slot");
+    runm<2, 1, 2>("fp32 16x16x4 chain + 1 v_exp_f32 + 2 v_fma_f32 (independent) per slot");
+    runm<2, 2, 4>("fp32 16x16x4 chain + 2 v_exp_f32 + 4 v_fma_f32 (independent) per slot");
+    runm<2, 0, 6>("fp32 16x16x4 chain + 6 v_fma_f32 (independent) per slot");
+    runf<0, 1>("v_mfma_f32_16x16x4_f32 (8 passes): dependent chain");
+    runf<0, 2>("v_mfma_f32_16x16x4_f32: two chains alternating");
+    runf<0, 4>("v_mfma_f32_16x16x4_f32: four chains alternating");
+    runf<1, 1>("v_mfma_f32_32x32x2_f32 (16 passes): dependent chain");
+    runf<1, 2>("v_mfma_f32_32x32x2_f32: two chains alternating");
     return 0;
 }
