@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float p = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) p = fmaf(v[r], bv[r], p);
-                p += __shfl_xor(p, 32, 64);
+                p = xsum32(p);
                 if (h == 0) p512[wave_u * TB + l31] = p;
             }
             stamp(4);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int r = 0; r < 8; ++r) { zv[r] = zp[r]; zv[r + 8] = 0.f; prior_p += zp[r] * zp[r]; }
                 put_lds<P>(zv, Zb, LDZ, 0, l31, h);
-                prior_p += __shfl_xor(prior_p, 32, 64);
+                prior_p = xsum32(prior_p);
                 __builtin_amdgcn_sched_barrier(0);
                 flush_step();
                 if (m >= 0) load_draws(m + 1);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const float term = P::log_(vx) + P::div_(x2_512, vx);
                     if (h == 0) ll += (double)term;
                 });
-            ll += __shfl_xor(ll, 32, 64);
+            ll = xsum32(ll);
             if (h == 0) red[wave_u * TB + l31] = ll;
             stamp(7);
             __syncthreads();                                               // B3

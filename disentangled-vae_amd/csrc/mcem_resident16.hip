@@ -430,8 +430,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int j = 0; j < 4; ++j) { v2[rt][j] = P::tanh_(a2[rt][j] + c[j]); p = fmaf(v2[rt][j], w[j], p); }
                     put4(v2[rt], Hb + f16 * S_LDH + fb + 16 * rt + 4 * q);
                 }
-                p += __shfl_xor(p, 16, 64);
-                p += __shfl_xor(p, 32, 64);
+                p = xsum16(p);
+                p = xsum32(p);
                 if (q == 0) p512[wave_u * T16 + f16] = p;
             }
             stamp(4);
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) prior_p += zp[j] * zp[j];
                 put4(f32x4_t{zp[0], zp[1], zp[2], zp[3]}, Zb + f16 * S_LDZ + 4 * q);
-                prior_p += __shfl_xor(prior_p, 16, 64);
-                prior_p += __shfl_xor(prior_p, 32, 64);
+                prior_p = xsum16(prior_p);
+                prior_p = xsum32(prior_p);
                 __builtin_amdgcn_sched_barrier(0);
                 flush_step();
                 if (m >= 0) load_draws(m + 1);
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const float term = P::log_(vx) + P::div_(x2_512, vx);
                     if (q == 0) ll += (double)term;
                 });
-            ll += __shfl_xor(ll, 16, 64);
-            ll += __shfl_xor(ll, 32, 64);
+            ll = xsum16(ll);
+            ll = xsum32(ll);
             if (q == 0) red[wave_u * T16 + f16] = ll;
             stamp(7);
             __syncthreads();                                               // B3

@@ -28,6 +28,43 @@ struct MhArgs {
     unsigned long long* dbg;   // diagnostic: per (workgroup, wave) sums of shader clocks per chain phase (dvae_mcem_debug_stamps), null in production
 };
 
+// Sums across the lane groups of a wave on gfx950's VALU half / quarter exchanges instead of ds_bpermute_b32 (an LDS round trip each, and the
+// second waits for the first: two of them were 250 of wave 0's 1 240 serial clocks per chain step).  v_permlane32_swap vdst, src: lanes 32-63
+// of vdst <-> lanes 0-31 of src; v_permlane16_swap: the odd rows of 16 of vdst <-> the even rows of src.  With both operands = x the two
+// results are (lower | lower) and (upper | upper): their sum is x[lane] + x[lane ^ 32] (^ 16) in every lane -- the operands of each addition
+// are those of `x += __shfl_xor(x, 32)`, so the results are bit-identical to the shuffle form.
+// (Written out: with the builtins hipcc / ROCm 7.2 emitted `v_add_f32 v, v, v` behind a float swap -- it added the first result to itself, also
+// with the second operand made a value of its own -- while the double form came out right.  The s_nop covers the two wait states a VALU write
+// of an operand needs before a permlane swap reads it.)
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float xsum32(float x) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    swap32(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xsum16(float x) {
+    unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    swap16(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ double xsum32(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    unsigned alo = (unsigned)u, ahi = (unsigned)(u >> 32), blo = alo, bhi = ahi;
+    swap32(alo, blo);
+    swap32(ahi, bhi);
+    return __builtin_bit_cast(double, (unsigned long long)alo | ((unsigned long long)ahi << 32)) +
+           __builtin_bit_cast(double, (unsigned long long)blo | ((unsigned long long)bhi << 32));
+}
+__device__ __forceinline__ double xsum16(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    unsigned alo = (unsigned)u, ahi = (unsigned)(u >> 32), blo = alo, bhi = ahi;
+    swap16(alo, blo);
+    swap16(ahi, bhi);
+    return __builtin_bit_cast(double, (unsigned long long)alo | ((unsigned long long)ahi << 32)) +
+           __builtin_bit_cast(double, (unsigned long long)blo | ((unsigned long long)bhi << 32));
+}
+
 // weight-stationary chain (mcem_resident.hip): every operand policy, label rows 0 / 1..16
 bool resident_chain_supported(int precision, int yp);
 int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s);
