@@ -15,7 +15,7 @@ python bench.py --impl modules --steps 1000 --warmup 200 --no-extras --no-cpu-ba
 python bench.py --impl modules --batch 128 --steps 1000 --warmup 200 --no-extras --no-cpu-baseline > $O/bench_modules_B128.json 2>/dev/null
 python bench.py --impl modules --model M2_info --steps 300 --warmup 50 --no-extras --no-cpu-baseline > $O/bench_modules_M2_info.json 2>/dev/null
 python tools/bench_stft.py > $O/bench_stft.json 2>/dev/null
-python tools/bench_mcem.py --batch 25 > $O/bench_mcem.json 2>/dev/null
+python tools/bench_mcem.py --batch 8 25 > $O/bench_mcem.json 2>/dev/null
 # the N > 1 line as the driver would ask for it (no launcher in the environment): bench.py starts the ranks itself; gloo lets the two ranks share the one GPU
 DVAE_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 5 --batch 4096 --no-extras --no-cpu-baseline > $O/bench_2rank_selflaunch_gloo_rehearsal.json 2> $O/bench_2rank_selflaunch.err
 timeout -k 10 120 python bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_2rank_rccl_on_one_gpu.out 2> $O/bench_2rank_rccl_on_one_gpu.err; echo "exit code $?" >> $O/bench_2rank_rccl_on_one_gpu.err
