@@ -116,6 +116,28 @@ def test_m_step_and_wiener_match_oracle(N, R, K):
 
 @pytest.mark.parametrize("tile", ["16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 31, 33])
+def test_chain_on_tiny_and_ragged_frame_counts(N, precision, tile, monkeypatch):
+    """One frame, one short of a tile, exactly a tile, one more (both tile sizes): log acceptance ratios of the first chain step (every chain
+    still in its initial state) against the oracle, kept samples finite, nothing written outside the N frames."""
+    pick_tile(monkeypatch, tile, precision)
+    params, prefix, pack, X2, y, Z, g, W, H, rng = setup("M2", 1, N, 11, precision=precision)
+    nit, burnin = 6, 2
+    noise = rng.standard_normal((nit, 16, N)).astype(np.float32)
+    logu = np.log(rng.random((nit, N)).astype(np.float32))
+    Vb = (W @ H).astype(np.float32)
+    Zs_o, tp, ta = mo.sample_posterior(params, prefix, Z, y, g, Vb, X2, noise, logu, burnin, return_trace=True)
+    Zs, Vs, accp, accd = pack.sample(t(Z), t(y), t(g), t(Vb), t(X2), t(noise), t(logu), burnin, trace=True)
+    assert Zs.shape == (N, nit - burnin, 16) and Vs.shape == (nit - burnin, 513, N)
+    np.testing.assert_allclose(accp.cpu().numpy()[0], tp[0], rtol=2e-4, atol=2e-3)
+    assert torch.isfinite(Zs).all() and torch.isfinite(Vs).all() and (Vs > 0).all()
+    first = chains_agree(accd.cpu().numpy().astype(bool), ta)
+    same = first == nit
+    np.testing.assert_allclose(Zs.cpu().numpy()[same], Zs_o[same], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", mc.CASES, ids=[c["name"] for c in mc.CASES])
 def test_full_run_matches_reference_golden(case, precision, tile, monkeypatch):
     """EM.run on the draws recorded from the reference: state after every iteration vs the reference's (exact-fp32 and split-bf16
