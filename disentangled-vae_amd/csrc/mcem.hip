@@ -591,6 +591,16 @@ static int launch_mh(const MhArgs& a, hipStream_t s) {
 
 static unsigned long long* g_mcem_dbg = nullptr;      // set by dvae_mcem_debug_stamps
 
+// Z (16, N) <- the last kept sample of every frame's chain, Zs (N, R, 16): EM.run's `self.Z = Z_sampled_t[:, -1, :].T` (mcem.py:234, 300)
+__global__ __launch_bounds__(256) void last_sample_kernel(const float* __restrict__ Zs, int R, int64_t N, float* __restrict__ Z) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // i = n * 16 + l: coalesced read of the sample, strided 4-byte writes (64 KB in all)
+    if (i >= N * ZD) return;
+    const int64_t n = i / ZD;
+    const int l = (int)(i - n * ZD);
+    Z[(int64_t)l * N + n] = Zs[(n * R + (R - 1)) * ZD + l];
+}
+
+
 static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hipStream_t s) {
     a.dbg = g_mcem_dbg;
     const McemLayout L = mcem_layout(plan->y_dim, plan->precision);
@@ -607,17 +617,28 @@ static int run_mh(const dvae_mcem_plan_t* plan, const void* wcopy, MhArgs& a, hi
     if (!stream_only && resident_chain_supported(plan->precision, L.yp) && (int64_t)XD * a.N * 4 < ((int64_t)1 << 31) &&
         (int64_t)a.nit * ZD * a.N * 4 < ((int64_t)1 << 31))
         return launch_resident_chain(plan->precision, L.yp, a, s);
+    // the streaming kernels do not write the final state themselves
+    struct LastSample {
+        const MhArgs& a; hipStream_t s;
+        int operator()(int rc) const {
+            if (rc == 0 && a.Zlast != nullptr && a.nit > 0) {
+                hipLaunchKernelGGL(last_sample_kernel, dim3((unsigned)((a.N * ZD + 255) / 256)), dim3(256), 0, s, a.Zs, a.R, a.N, a.Zlast);
+                DVAE_LAUNCH_OK("last_sample_kernel");
+            }
+            return rc;
+        }
+    } then{a, s};
     if (plan->precision == DVAE_PREC_BF16X3) {
-        if (L.yp == 0) return launch_mh<PolX3M<0>, 0, 0>(a, s);
-        if (L.yp == 16) return launch_mh<PolX3M<16>, 16, 0>(a, s);
-        if (L.yp == 528) return launch_mh<PolX3M<528>, 528, 0>(a, s);
+        if (L.yp == 0) return then(launch_mh<PolX3M<0>, 0, 0>(a, s));
+        if (L.yp == 16) return then(launch_mh<PolX3M<16>, 16, 0>(a, s));
+        if (L.yp == 528) return then(launch_mh<PolX3M<528>, 528, 0>(a, s));
     }
     // fp32: lean streaming variant (168 VGPRs, 3 workgroups per CU co-resident: 3.2 us per tile and chain at >= 768
     // tiles against 4.3 us with resident layers 1-2 at one workgroup per CU; equal at <= 256 tiles).
     // bf16: layers 1-2 resident (1.11 us per tile against 1.18 us).  Measured with tools/exp_mcem_occupancy.py.
-    if (L.yp == 0) return bf ? launch_mh<PolBF16, 0, 1>(a, s) : launch_mh<PolF32Lean, 0, 0>(a, s);
-    if (L.yp == 16) return bf ? launch_mh<PolBF16, 16, 1>(a, s) : launch_mh<PolF32Lean, 16, 0>(a, s);
-    if (L.yp == 528) return bf ? launch_mh<PolBF16, 528, 1>(a, s) : launch_mh<PolF32Lean, 528, 0>(a, s);
+    if (L.yp == 0) return then(bf ? launch_mh<PolBF16, 0, 1>(a, s) : launch_mh<PolF32Lean, 0, 0>(a, s));
+    if (L.yp == 16) return then(bf ? launch_mh<PolBF16, 16, 1>(a, s) : launch_mh<PolF32Lean, 16, 0>(a, s));
+    if (L.yp == 528) return then(bf ? launch_mh<PolBF16, 528, 1>(a, s) : launch_mh<PolF32Lean, 528, 0>(a, s));
     set_error("mcem: y_dim %d not supported (0, 1..16, 513)", plan->y_dim);
     return DVAE_E_BADARG;
 }
@@ -667,9 +688,9 @@ extern "C" int dvae_mcem_pack(const dvae_mcem_plan_t* plan, const float* W3, int
     return 0;
 }
 
-extern "C" int dvae_mcem_sample(const dvae_mcem_plan_t* plan, const void* weights, const float* Z0, const float* y, const float* g,
-                                const float* Vb, const float* X2, const float* noise, const float* logu, int nit, int burnin,
-                                float var_rw, int64_t N, float* Zs, float* Vs, float* acc_logratio, unsigned char* accepted, void* stream) {
+static int mcem_sample_impl(const dvae_mcem_plan_t* plan, const void* weights, const float* Z0, const float* y, const float* g,
+                            const float* Vb, const float* X2, const float* noise, const float* logu, int nit, int burnin,
+                            float var_rw, int64_t N, float* Zs, float* Vs, float* acc_logratio, unsigned char* accepted, float* Zlast, void* stream) {
     DVAE_CHECK_ARG(plan && weights && Z0 && g && Vb && X2 && noise && logu && Zs, "mcem_sample: null argument");
     DVAE_CHECK_ARG((plan->y_dim == 0) == (y == nullptr), "mcem_sample: y must be given exactly when the plan has y_dim > 0");
     DVAE_CHECK_ARG(N > 0 && nit > 0 && burnin >= 0 && burnin < nit, "mcem_sample: need N > 0 and 0 <= burnin < nit (N=%lld nit=%d burnin=%d)", (long long)N, nit, burnin);
@@ -678,7 +699,14 @@ extern "C" int dvae_mcem_sample(const dvae_mcem_plan_t* plan, const void* weight
     memset(&a, 0, sizeof(a));
     a.Z0 = Z0; a.y = y; a.g = g; a.Vb = Vb; a.X2 = X2; a.noise = noise; a.logu = logu; a.Zs = Zs; a.Vs = Vs; a.accp = acc_logratio; a.accd = accepted;
     a.nit = nit; a.burnin = burnin; a.R = nit - burnin; a.N = N; a.sd = sqrtf(var_rw);
+    a.Zlast = Zlast;
     return run_mh(plan, weights, a, (hipStream_t)stream);
+}
+
+extern "C" int dvae_mcem_sample(const dvae_mcem_plan_t* plan, const void* weights, const float* Z0, const float* y, const float* g,
+                                const float* Vb, const float* X2, const float* noise, const float* logu, int nit, int burnin,
+                                float var_rw, int64_t N, float* Zs, float* Vs, float* acc_logratio, unsigned char* accepted, void* stream) {
+    return mcem_sample_impl(plan, weights, Z0, y, g, Vb, X2, noise, logu, nit, burnin, var_rw, N, Zs, Vs, acc_logratio, accepted, nullptr, stream);
 }
 
 extern "C" int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weights, const float* Zs, const float* y, int R, int64_t N,
@@ -754,28 +782,18 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     return 0;
 }
 
-// Z (16, N) <- the last kept sample of every frame's chain, Zs (N, R, 16): EM.run's `self.Z = Z_sampled_t[:, -1, :].T` (mcem.py:234, 300)
-__global__ __launch_bounds__(256) void last_sample_kernel(const float* __restrict__ Zs, int R, int64_t N, float* __restrict__ Z) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // i = n * 16 + l: coalesced read of the sample, strided 4-byte writes (64 KB in all)
-    if (i >= N * ZD) return;
-    const int64_t n = i / ZD;
-    const int l = (int)(i - n * ZD);
-    Z[(int64_t)l * N + n] = Zs[(n * R + (R - 1)) * ZD + l];
-}
-
 // One EM iteration = the body of EM.run's loop (mcem.py:156-160: E_step, M_step, cost) as ONE host call: the chain launch (with the decoder
-// variances of its kept samples), Z <- last kept sample, the M-step's launches.  Nothing here synchronises or allocates; between two calls
+// variances of its kept samples and Z <- last kept sample), the M-step's launches.  Nothing here synchronises or allocates; between two calls
 // the host only has to point at the next iteration's draws.
 extern "C" int dvae_mcem_em_iteration(const dvae_mcem_plan_t* plan, const void* weights, float* Z, const float* y, float* g, float* Vb,
                                       const float* X2, const float* noise, const float* logu, int nit, int burnin, float var_rw, int64_t N,
                                       int K, int U, const int* seg_start, const int* seg_count, const int* tile_seg, float* W, float* H,
                                       float* Zs, float* Vs, float* cost, void* workspace, void* stream) {
     DVAE_CHECK_ARG(Z && Zs && Vs, "mcem_em_iteration: Z, Zs and Vs are required");
-    int rc = dvae_mcem_sample(plan, weights, Z, y, g, Vb, X2, noise, logu, nit, burnin, var_rw, N, Zs, Vs, nullptr, nullptr, stream);
+    // (Z <- the chain's last kept sample is written by the chain launch itself: Zlast = Z)
+    int rc = mcem_sample_impl(plan, weights, Z, y, g, Vb, X2, noise, logu, nit, burnin, var_rw, N, Zs, Vs, nullptr, nullptr, Z, stream);
     if (rc) return rc;
     const int R = nit - burnin;
-    hipLaunchKernelGGL(last_sample_kernel, dim3((unsigned)((N * ZD + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Zs, R, N, Z);
-    DVAE_LAUNCH_OK("last_sample_kernel");
     return dvae_mcem_m_step_batch(X2, Vs, R, N, K, U, seg_start, seg_count, tile_seg, W, H, g, Vb, cost, workspace, stream);
 }
 

@@ -582,6 +582,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // red / p512 / Zb are next written behind the barriers of the following pass
         }
         if (wave_u == 0) flush_step();
+        if (wave_u == 0 && g.nit > 0 && g.Zlast != nullptr && live) {          // the chain's final state (a frame's Z0 is read by these lanes only: Zlast may be Z0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g.Zlast[(int64_t)(4 * q + j) * g.N + nf] = z[j];
+        }
         if (g.dbg && lane == 0 && g.nit > 0) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + k] = tsum[k];

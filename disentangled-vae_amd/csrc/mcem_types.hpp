@@ -15,6 +15,7 @@ struct MhArgs {
     const float* noise;   // (nit, 16, N)
     const float* logu;    // (nit, N)
     float* Zs;            // (N, R, 16)  MH mode: written (R = nit - burnin); decode mode: read
+    float* Zlast;         // (16, N) or null: the chain's final state = its last kept sample (EM.run's `self.Z = Z_sampled_t[:, -1, :].T`); may be Z0 itself
     float* Vs;            // (R, 513, N) or null
     float* accp;          // (nit, N) log acceptance ratios, optional
     unsigned char* accd;  // (nit, N) decisions, optional
