@@ -107,7 +107,9 @@ static_assert(C8_O_RED % 8 == 0 && C8_LDS <= 160 * 1024, "resident chain: LDS la
 // writes acc scheduled between the bias ds_read and the first MFMA.  Neither shows in the build log; both show as launch-to-launch or
 // policy-to-oracle differences: tests/test_gpu_mcem.py::test_chain_launches_are_bit_identical (every policy and label variant, repeated
 // launches bit for bit) and the oracle / reference-golden tests are the guards, and tools/r05/audit_resident.sh prints the per-kernel
-// spill and v_accvgpr counts to compare after a toolchain change (ROCm 7.2: 0 - 22 spilled VGPRs, all parked in the free AGPRs).
+// register, scratch and v_accvgpr counts of these kernels and of the 16-frame ones to compare after a toolchain change (ROCm 7.2, end of round 5:
+// profiles/r05_mcem_resident_register_audit.txt -- 0 - 140 bytes of scratch per lane here, all of it in the per-tile prologue and epilogue, none
+// between the barriers of a chain step; none at all in the 16-frame kernels).
 template <int I, int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }

@@ -1,16 +1,23 @@
 #!/bin/bash
-# Build container: per-kernel VGPR spill counts and v_accvgpr_write / _read counts of the weight-stationary MCEM chain kernels (csrc/mcem_resident.hip),
-# to compare after a compiler or flag change (the hazard table in that file says what the numbers guard)
+# Build container: per-kernel register counts, spilled VGPRs and v_accvgpr_write / _read counts of the weight-stationary MCEM chain kernels
+# (csrc/mcem_resident.hip: 32-frame tiles, csrc/mcem_resident16.hip: 16-frame tiles), to compare after a compiler or flag change (the hazard
+# table in mcem_resident.hip says what the numbers guard)
 cd "$(dirname "$0")/../.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -S disentangled-vae_amd/csrc/mcem_resident.hip -o /tmp/mcem_resident.s --cuda-device-only 2>/dev/null
-python3 - <<'PY'
-import re
-txt = open("/tmp/mcem_resident.s").read()
-names = re.findall(r"^(_ZN4dvae5fused20mcem_resident_kernel\w+):", txt, re.M)
-for n in names:
-    body = txt[txt.index(n + ":"):]
-    body = body[:body.index("s_endpgm")]
-    meta = txt[txt.index(".name:           " + n):]
-    spill = re.search(r"\.vgpr_spill_count: (\d+)", meta).group(1)
-    print(n[29:60], "spilled VGPRs", spill, "v_accvgpr_write", body.count("v_accvgpr_write"), "v_accvgpr_read", body.count("v_accvgpr_read"), "mfma", body.count("v_mfma"))
+for src in mcem_resident mcem_resident16; do
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -S disentangled-vae_amd/csrc/$src.hip -o /tmp/$src.s --cuda-device-only 2>/dev/null
+python3 - $src <<'PY'
+import re, sys
+txt = open("/tmp/%s.s" % sys.argv[1]).read()
+for m in re.finditer(r"^(_ZN4dvae5fused\d+mcem_resident\w*_kernel\w+):", txt, re.M):
+    n = m.group(1)
+    body = txt[m.end():]
+    end = body.index("s_endpgm")
+    tail = body[end:end + 6000]
+    body = body[:end]
+    g = lambda k: re.search(r"; %s: (\d+)" % k, tail).group(1)
+    pol = re.search(r"Pol\w+?E", n).group(0)[:-1]
+    yp = re.search(r"ELi(\d+)E", n).group(1)
+    print("%-16s %-8s label rows %-4s VGPRs %s AGPRs %s scratch %s B  v_accvgpr_write %d  v_accvgpr_read %d  mfma %d" % (
+        sys.argv[1], pol, yp, g("NumVgprs"), g("NumAgprs"), g("ScratchSize"), body.count("v_accvgpr_write"), body.count("v_accvgpr_read"), body.count("v_mfma")))
 PY
+done
