@@ -6,6 +6,7 @@
 #include <type_traits>
 #include "common.hpp"
 #include "fused_tiles.hpp"
+#include "mcem_types.hpp"
 
 namespace dvae {
 namespace fused {
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
         for (int i = 0; i < M; ++i) {
             if (i < cnt) {
                 float a = v[i];
-                a += __shfl_xor(a, 16, 64);
-                a += __shfl_xor(a, 32, 64);
+                a = xsum16(a);                                      // (v_permlane16/32_swap: mcem_types.hpp; the operands of ds_bpermute's additions)
+                a = xsum32(a);
                 if (lane < 16) wpart[(wave * cnt + i) * 16 + fr] = a;
             }
         }
