@@ -1253,7 +1253,9 @@ static int istft_run(const void* S, int64_t T, int64_t ld, bool tf, const double
         if (tf && getenv("DVAE_ISTFT_STAGED") == nullptr) {                  // A/B switch (read per call): frame-major input through the staged kernel
             // one round of waves (2048 slots, as the forward transform): the shortest walk per wave, ceil(T / 2048) own frames + 3 halo
             // frames (short utterances: 4 transforms for 1 own frame, all waves side by side -- 12 us at 309 frames against 19 us with 4 own)
-            int chunk = (int)cdiv(T, 2048);
+            const char* const slots_s = getenv("DVAE_ISTFT_SLOTS");          // experiment switch: waves the frames are dealt to (default: one round of 2048)
+            const int slots = slots_s && atoi(slots_s) >= 64 ? atoi(slots_s) : 2048;
+            int chunk = (int)cdiv(T, slots);
             chunk = chunk < 1 ? 1 : chunk;
             const int wb = (int)cdiv(cdiv(T, chunk), 4);
             hipLaunchKernelGGL(istft1024_walk_kernel, dim3(wb), dim3(256), 0, s, (const float2*)S, T, ld, window, start, y, out_len, chunk);
