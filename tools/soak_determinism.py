@@ -32,7 +32,9 @@ dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
 m = build_model("M2", dims); m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in gu.make_params("M2", dims, 3).items()}); m.cuda().eval()
 import mcem_cases as mc
 utts = [mc.make_utterance(dict(seed=60 + i, N=n, model="M2")) for i, n in enumerate([300, 257, 64, 311] * 6)]
-for prec in ("fp32", "bf16"):
+all_utts = utts
+# 24 utterances: the chain on 32-frame tiles; 4 utterances: on 16-frame tiles (csrc/mcem_resident16.hip)
+for prec, utts in (("fp32", all_utts), ("bf16", all_utts), ("fp32", all_utts[:4]), ("bf16x3", all_utts[:4]), ("bf16", all_utts[:4])):
     outs = []
     for rep in range(2):
         mb = mcem_dev.McemBatch(m, niter=30, precision=prec)
