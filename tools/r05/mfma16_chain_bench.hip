@@ -78,7 +78,7 @@ template <int W, int NCH> void runf(const char* what) {
 // the epilogue's instruction mix with no dependences between consecutive instructions: per slot NT transcendentals (v_exp_f32 on eight rotating
 // registers) and NF v_fma_f32 (eight rotating registers), with MF = 0 no MFMA, 1 a dependent v_mfma_f32_16x16x32_bf16, 2 a dependent v_mfma_f32_16x16x4_f32
 template <int MF, int NT, int NF>
-__global__ __launch_bounds__(256, 1) void km(unsigned long long* out, float* sink, int rep) {
+__global__ __launch_bounds__(1024, 1) void km(unsigned long long* out, float* sink, int rep) {
     const int lane = threadIdx.x & 63;
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
@@ -105,16 +105,24 @@ __global__ __launch_bounds__(256, 1) void km(unsigned long long* out, float* sin
     for (int i = 0; i < 8; ++i) sm += e[i] + f[i];
     sink[threadIdx.x] = sm;
 }
-template <int MF, int NT, int NF> void runm(const char* what) {
+template <int MF, int NT, int NF> void runm(const char* what, int threads = 256) {
     unsigned long long* out; float* sink;
-    CK(hipMalloc(&out, 64)); CK(hipMalloc(&sink, 4096));
+    CK(hipMalloc(&out, 256)); CK(hipMalloc(&sink, 16384));
     const int rep = 200;
-    hipLaunchKernelGGL((km<MF, NT, NF>), dim3(1), dim3(256), 0, 0, out, sink, rep);
-    hipLaunchKernelGGL((km<MF, NT, NF>), dim3(1), dim3(256), 0, 0, out, sink, rep);
+    hipLaunchKernelGGL((km<MF, NT, NF>), dim3(1), dim3(threads), 0, 0, out, sink, rep);
+    hipLaunchKernelGGL((km<MF, NT, NF>), dim3(1), dim3(threads), 0, 0, out, sink, rep);
     CK(hipDeviceSynchronize());
     unsigned long long h[4];
     CK(hipMemcpy(h, out, 32, hipMemcpyDeviceToHost));
-    printf("m %-70s %.1f s_memtime ticks per 96 slots = %.2f per slot\n", what, (double)h[0] / rep, (double)h[0] / rep / 96.0);
+    printf("m %-70s %.1f s_memtime ticks per 96 slots = %.2f per slot", what, (double)h[0] / rep, (double)h[0] / rep / 96.0);
+    if (threads > 256) {
+        unsigned long long h2[16];
+        CK(hipMemcpy(h2, out, 8 * (threads / 64), hipMemcpyDeviceToHost));
+        printf("  (every wave:");
+        for (int w = 0; w < threads / 64; ++w) printf(" %.1f", (double)h2[w] / rep / 96.0);
+        printf(")");
+    }
+    printf("\n");
     CK(hipFree(out)); CK(hipFree(sink));
 }
 
@@ -149,6 +157,14 @@ int main() {
     runm<2, 1, 2>("fp32 16x16x4 chain + 1 v_exp_f32 + 2 v_fma_f32 (independent) per slot");
     runm<2, 2, 4>("fp32 16x16x4 chain + 2 v_exp_f32 + 4 v_fma_f32 (independent) per slot");
     runm<2, 0, 6>("fp32 16x16x4 chain + 6 v_fma_f32 (independent) per slot");
+    // two waves per SIMD (512 threads): does one wave's VALU work run beside the other's MFMAs?  (time per slot of EACH wave; both do the same work)
+    runm<1, 1, 2>("TWO waves per SIMD: bf16 16x16x32 chain + 1 v_exp_f32 + 2 v_fma_f32 per slot", 512);
+    runm<1, 0, 0>("TWO waves per SIMD: bf16 16x16x32 chain alone", 512);
+    runm<0, 1, 2>("TWO waves per SIMD: 1 v_exp_f32 + 2 v_fma_f32 per slot, no MFMA", 512);
+    runm<2, 1, 2>("TWO waves per SIMD: fp32 16x16x4 chain + 1 v_exp_f32 + 2 v_fma_f32 per slot", 512);
+    runm<1, 1, 2>("FOUR waves per SIMD: bf16 16x16x32 chain + 1 v_exp_f32 + 2 v_fma_f32 per slot", 1024);
+    runm<1, 0, 0>("FOUR waves per SIMD: bf16 16x16x32 chain alone", 1024);
+    runm<0, 1, 2>("FOUR waves per SIMD: 1 v_exp_f32 + 2 v_fma_f32 per slot, no MFMA", 1024);
     runf<0, 1>("v_mfma_f32_16x16x4_f32 (8 passes): dependent chain");
     runf<0, 2>("v_mfma_f32_16x16x4_f32: two chains alternating");
     runf<0, 4>("v_mfma_f32_16x16x4_f32: four chains alternating");
