@@ -5,12 +5,12 @@ O=$PWD/gpurun_out/r05c; mkdir -p $O
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 for what in stft mcem; do
-  if [ $what = stft ]; then CMD="python3 $R/tools/bench_stft.py"; else CMD="python3 $R/tools/bench_mcem.py --no-cpu --batch 25"; fi
+  if [ $what = stft ]; then CMD="python3 $R/tools/bench_stft.py"; else CMD="python3 $R/tools/bench_mcem.py --no-cpu --batch 8 25"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${what}_stats -- $CMD > $O/${what}_stats.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${what}_fetch -- $CMD > $O/${what}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${what}_write -- $CMD > $O/${what}_write.log 2>&1
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mcem_sq -- python3 $R/tools/bench_mcem.py --no-cpu --batch 25 > $O/mcem_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mcem_sq -- python3 $R/tools/bench_mcem.py --no-cpu --batch 8 25 > $O/mcem_sq.log 2>&1
 cd $R
 cp $O/stft_stats/*/*kernel_stats.csv $O/stft_kernel_stats.csv 2>/dev/null
 cp $O/mcem_stats/*/*kernel_stats.csv $O/mcem_kernel_stats.csv 2>/dev/null
