@@ -65,6 +65,21 @@ def test_importing_seeds_the_generators():
     assert a == torch.rand(1).item() and b == np.random.rand()
 
 
+def test_operand_policy_of_unchanged_scripts_comes_from_the_environment():
+    """The reference's evaluate scripts construct MCEM_M2(...) and never set `.precision`: DVAE_MCEM_PRECISION picks the device path's operand
+    policy for them (default: exact fp32 products)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from packages.models import mcem; print(mcem.MCEM_M2(niter=1).precision)"
+    for env_val, want in ((None, "fp32"), ("bf16x3", "bf16x3")):
+        env = {k: v for k, v in os.environ.items() if k != "DVAE_MCEM_PRECISION"}
+        if env_val is not None:
+            env["DVAE_MCEM_PRECISION"] = env_val
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip().splitlines()[-1] == want
+
+
 def test_m1_quirk_counts():
     """MCEM_M1 hands (Z, nsamples, burnin) to sample_posterior(Z, y, nsamples, burnin=30): kept samples = burn-in argument."""
     case = mc.CASES[0]
