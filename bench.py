@@ -242,17 +242,19 @@ def side_kernels(device):
                                         "utterances_per_s": U / dt, "decoder_TFLOP_per_s": flops / dt * 1e-12, "mfma_frac": flops / dt * 1e-12 / peak,
                                         "mfma_peak_TFLOP_per_s": peak,
                                         "note": "whole run incl. M-steps and the Wiener chain; flops = decoder MACs x 2 of the chain / decode passes the kernels execute"}
-    # ONE utterance -- what scripts/evaluate_ntcd_M2.py runs per process: the chain on 16-frame tiles (csrc/mcem_resident16.hip), 20 of 256 CUs busy
-    mb = M.McemBatch(vae, niter=2, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, label_in_encoder=True,
-                     label_in_decoder=True, precision="bf16x3")
-    mb.init_parameters([X], [y]); mb.run()
-    mb.niter = 100
-    mb.init_parameters([X], [y])
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    mb.run()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    out["mcem_single_bf16x3"] = {"utterances": 1, "frames_each": N, "em_iterations": 100, "ms_per_utterance": 1e3 * dt, "ms_per_em_iteration": 10.0 * dt,
-                                 "note": "the reference's settings (100 EM iterations, 10 + 30 chain steps each, final Wiener chain 25 + 75)"}
+    # ONE utterance -- what scripts/evaluate_ntcd_M2.py runs per process: the chain on 4-frame tiles under exact fp32 (csrc/mcem_resident4.hip,
+    # the drop-in classes' default policy), on 16-frame tiles under bf16x3 (csrc/mcem_resident16.hip)
+    for prec in ("fp32", "bf16x3"):
+        mb = M.McemBatch(vae, niter=2, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, label_in_encoder=True,
+                         label_in_decoder=True, precision=prec)
+        mb.init_parameters([X], [y]); mb.run()
+        mb.niter = 100
+        mb.init_parameters([X], [y])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        mb.run()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out["mcem_single_" + prec] = {"utterances": 1, "frames_each": N, "em_iterations": 100, "ms_per_utterance": 1e3 * dt, "ms_per_em_iteration": 10.0 * dt,
+                                      "note": "the reference's settings (100 EM iterations, 10 + 30 chain steps each, final Wiener chain 25 + 75)"}
     return out
 
 

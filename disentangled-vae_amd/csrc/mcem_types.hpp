@@ -73,6 +73,10 @@ int launch_resident_chain(int precision, int yp, const MhArgs& a, hipStream_t s)
 // the 16-frame tiles of the call fit the chip in one round (DVAE_MCEM_TILE=16 / 32 forces either)
 bool resident16_chain_supported(int precision, int yp);
 int launch_resident16_chain(int precision, int yp, const MhArgs& a, hipStream_t s);
+// the exact-fp32 chain on 4-frame tiles (mcem_resident4.hip: v_mfma_f32_4x4x1_16b_f32; a.ntiles counts 4-frame tiles): taken while those fit the
+// chip in two rounds (DVAE_MCEM_TILE=4 forces it)
+bool resident4_chain_supported(int precision, int yp);
+int launch_resident4_chain(int yp, const MhArgs& a, hipStream_t s);
 
 }  // namespace fused
 }  // namespace dvae

@@ -46,8 +46,11 @@ def setup(model, y_dim, N, seed, wscale=1.0, precision="fp32"):
 
 
 def pick_tile(monkeypatch, tile, precision):
-    """Frames per workgroup of the weight-stationary chain: 16 (csrc/mcem_resident16.hip, what chains take by default while their 16-frame
-    tiles fit the chip in one round) or 32 (csrc/mcem_resident.hip)."""
+    """Frames per workgroup of the weight-stationary chain: 4 (csrc/mcem_resident4.hip: exact fp32 only, what short fp32 chains take by
+    default), 16 (csrc/mcem_resident16.hip, what chains take by default while their 16-frame tiles fit the chip in one round) or 32
+    (csrc/mcem_resident.hip)."""
+    if tile == "4" and precision != "fp32":
+        pytest.skip("the 4-frame chain kernel exists for the exact-fp32 policy")
     monkeypatch.setenv("DVAE_MCEM_TILE", tile)
 
 
@@ -58,7 +61,7 @@ def chains_agree(accd, trace_a):
     return first
 
 
-@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("tile", ["4", "16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("model,y_dim,N", [("M1", 0, 45), ("M2", 1, 70), ("M2", 513, 33), ("M2_info", 1, 100)])
 def test_sample_posterior_matches_oracle(model, y_dim, N, precision, tile, monkeypatch):
@@ -114,7 +117,7 @@ def test_m_step_and_wiener_match_oracle(N, R, K):
     np.testing.assert_allclose((WFs + WFn).cpu().numpy(), 1.0, rtol=1e-5)        # the two gains partition the mixture
 
 
-@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("tile", ["4", "16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("N", [1, 15, 16, 17, 31, 33])
 def test_chain_on_tiny_and_ragged_frame_counts(N, precision, tile, monkeypatch):
@@ -136,7 +139,7 @@ def test_chain_on_tiny_and_ragged_frame_counts(N, precision, tile, monkeypatch):
     np.testing.assert_allclose(Zs.cpu().numpy()[same], Zs_o[same], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("tile", ["4", "16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", mc.CASES, ids=[c["name"] for c in mc.CASES])
 def test_full_run_matches_reference_golden(case, precision, tile, monkeypatch):
@@ -172,7 +175,7 @@ def test_full_run_matches_reference_golden(case, precision, tile, monkeypatch):
     assert (np.abs(WFn.cpu().numpy() - fix["WFn"]) > 5e-3).mean() < 0.05
 
 
-@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("tile", ["4", "16", "32"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("model,y_dim,N", [("M2", 1, 300), ("M2", 513, 200), ("M1", 0, 257)])
 def test_chain_launches_are_bit_identical(model, y_dim, N, precision, tile, monkeypatch):

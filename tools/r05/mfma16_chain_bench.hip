@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, 1) void kf(unsigned long long* out, float* sin
 #pragma unroll
         for (int i = 0; i < 96; ++i) {
             if constexpr (W == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c4[i % NCH]) : "v"(a), "v"(b));
+            else if constexpr (W == 2) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(c4[i % NCH]) : "v"(a), "v"(b));
             else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c16[i % NCH]) : "v"(a), "v"(b));
         }
     }
@@ -168,6 +169,9 @@ int main() {
     runf<0, 1>("v_mfma_f32_16x16x4_f32 (8 passes): dependent chain");
     runf<0, 2>("v_mfma_f32_16x16x4_f32: two chains alternating");
     runf<0, 4>("v_mfma_f32_16x16x4_f32: four chains alternating");
+    runf<2, 1>("v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 x 4, K = 1): dependent chain");
+    runf<2, 2>("v_mfma_f32_4x4x1_16b_f32: two chains alternating");
+    runf<2, 4>("v_mfma_f32_4x4x1_16b_f32: four chains alternating");
     runf<1, 1>("v_mfma_f32_32x32x2_f32 (16 passes): dependent chain");
     runf<1, 2>("v_mfma_f32_32x32x2_f32: two chains alternating");
     return 0;

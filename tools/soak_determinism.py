@@ -34,7 +34,8 @@ import mcem_cases as mc
 utts = [mc.make_utterance(dict(seed=60 + i, N=n, model="M2")) for i, n in enumerate([300, 257, 64, 311] * 6)]
 all_utts = utts
 # 24 utterances: the chain on 32-frame tiles; 4 utterances: on 16-frame tiles (csrc/mcem_resident16.hip)
-for prec, utts in (("fp32", all_utts), ("bf16", all_utts), ("fp32", all_utts[:4]), ("bf16x3", all_utts[:4]), ("bf16", all_utts[:4])):
+# (fp32 on 1 and 2 utterances: the 4-frame chain, csrc/mcem_resident4.hip; on 4 utterances -- 932 frames -- as well: 233 tiles)
+for prec, utts in (("fp32", all_utts), ("bf16", all_utts), ("fp32", all_utts[:4]), ("bf16x3", all_utts[:4]), ("bf16", all_utts[:4]), ("fp32", all_utts[:1]), ("fp32", all_utts[:8])):
     outs = []
     for rep in range(2):
         mb = mcem_dev.McemBatch(m, niter=30, precision=prec)

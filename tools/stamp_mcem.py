@@ -14,7 +14,7 @@ mc.DIMS["bench"] = dims
 X, S, y = mc.make_utterance(dict(seed=5, N=300, model="bench"))
 mb = M.McemBatch(m, niter=3, nsamples_E_step=10, burnin_E_step=30, nsamples_WF=25, burnin_WF=75, precision=prec)
 mb.init_parameters([X] * U, [torch.from_numpy(y).cuda()] * U); mb.run()
-ntiles = mb.ntot // 16                                   # room for 16-frame tiles (csrc/mcem_resident16.hip); 32-frame launches fill the first half
+ntiles = mb.ntot // 4                                    # room for 4-frame tiles (csrc/mcem_resident4.hip); 16- / 32-frame launches fill the first quarter / eighth
 buf = torch.zeros(ntiles * 4 * 16, dtype=torch.int64, device="cuda")
 N.load().dvae_mcem_debug_stamps(N.ptr(buf))
 Zs, Vs = mb._chain(10, 30)
