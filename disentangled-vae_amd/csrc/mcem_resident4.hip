@@ -295,17 +295,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // layer 2: h1 -> h2 (the lane halves take 64 of the 128 k each), and this wave's 32 terms of bin 512's pre-activation
         {
             f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            // (the whole activation row of the lane's k half is requested first: four MFMAs -- 33 clocks -- do not cover an LDS round trip, and
+            // with one quad in flight the phase took 1 400 clocks for 525 of matrix work)
             const float* const hr = Ha + j * LDH + (HD / 2) * kh;
-            f32x4_t hv[2];
-            hv[0] = *reinterpret_cast<const f32x4_t*>(hr);
-            hv[1] = *reinterpret_cast<const f32x4_t*>(hr + 4);
+            f32x4_t hv[HD / 8];
+#pragma unroll
+            for (int o = 0; o < HD / 8; ++o) hv[o] = *reinterpret_cast<const f32x4_t*>(hr + 4 * o);
 #pragma unroll
             for (int o = 0; o < HD / 8; ++o) {
-                a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o], hv[o & 1][0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o + 1], hv[o & 1][1], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o + 2], hv[o & 1][2], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o + 3], hv[o & 1][3], a1, 0, 0, 0);
-                if (o + 2 < HD / 8) hv[o & 1] = *reinterpret_cast<const f32x4_t*>(hr + 4 * (o + 2));
+                a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o], hv[o][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o + 1], hv[o][1], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o + 2], hv[o][2], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o + 3], hv[o][3], a1, 0, 0, 0);
             }
             acc = a0 + a1;
         }
@@ -328,18 +329,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         oa[1] = *reinterpret_cast<const f32x4_t*>(Bias + OB5 + 128 * wave_u + 64 + 4 * b);
         {
             const float* const hr = Hb + j * LDH;
-            f32x4_t hv[3];
-            hv[0] = *reinterpret_cast<const f32x4_t*>(hr);
-            hv[1] = *reinterpret_cast<const f32x4_t*>(hr + 4);
-            hv[2] = *reinterpret_cast<const f32x4_t*>(hr + 8);
+            constexpr int RING = 8;                                        // quads of h2 in flight: eight MFMAs (66 clocks) per quad
+            f32x4_t hv[RING];
+#pragma unroll
+            for (int o = 0; o < RING; ++o) hv[o] = *reinterpret_cast<const f32x4_t*>(hr + 4 * o);
             sfor<0, HD / 4>([&](auto oc) {
                 constexpr int o = decltype(oc)::value;
                 sfor<0, 4>([&](auto ec) {
                     constexpr int e = decltype(ec)::value, k = 4 * o + e;
-                    mf4<(k < KAG), false, (k == 0)>(oa[0], w5A[0][k], hv[o % 3][e]);
-                    mf4<(k < KAG), (k == HD - 1), (k == 0)>(oa[1], w5A[1][k], hv[o % 3][e]);
+                    mf4<(k < KAG), false, (k == 0)>(oa[0], w5A[0][k], hv[o % RING][e]);
+                    mf4<(k < KAG), (k == HD - 1), (k == 0)>(oa[1], w5A[1][k], hv[o % RING][e]);
                 });
-                if constexpr (o + 3 < HD / 4) hv[o % 3] = *reinterpret_cast<const f32x4_t*>(hr + 4 * (o + 3));
+                if constexpr (o + RING < HD / 4) hv[o % RING] = *reinterpret_cast<const f32x4_t*>(hr + 4 * (o + RING));
             });
         }
 #pragma unroll
