@@ -523,7 +523,8 @@ __global__ __launch_bounds__(FT) void mstep_frames_kernel(const float* __restric
 namespace mstep { int launch_w_reg(const float* X2, const float* Vs, int R, int64_t N, int U, const float* W, const float* H, const float* g, const float* Vb,
                                   float* Wun, const int* seg_start, const int* seg_count, hipStream_t s);
                   int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
-                                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s); }
+                                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s);
+                  int frames_per_workgroup(int64_t N); }
 
 // per utterance: W = Wun / norm (mcem.py:132), cost = mean over (R, F, N_u) of the tile partials
 __global__ __launch_bounds__(256) void mstep_finish_kernel(const float* __restrict__ Wun, const float* __restrict__ norms, int K, float* __restrict__ W,
@@ -723,7 +724,7 @@ extern "C" int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weight
 static size_t mstep_ws_layout(int64_t N, int K, int U, size_t* o_norms, size_t* o_partial) {
     size_t o = ((size_t)U * XD * K * sizeof(float) + 255) / 256 * 256;
     *o_norms = o; o += ((size_t)U * KMAX * sizeof(float) + 255) / 256 * 256;
-    *o_partial = o; o += ((size_t)((N + 15) / 16) * sizeof(double) + 255) / 256 * 256;      // one cost partial per 16-frame tile
+    *o_partial = o; o += ((size_t)((N + 7) / 8) * sizeof(double) + 255) / 256 * 256;        // one cost partial per workgroup of the frames kernel (8 or 16 frames)
     return o;
 }
 
@@ -763,7 +764,7 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     if (reg_form) {
         const int rcf = mstep::launch_frames_reg(X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, s);
         if (rcf) return rcf;
-        hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost, 16);
+        hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost, mstep::frames_per_workgroup(N));
         DVAE_LAUNCH_OK("mstep_finish_kernel");
         return 0;
     }

@@ -33,21 +33,25 @@ __device__ __forceinline__ float rcp_pos(float x) { return __builtin_amdgcn_rcpf
 #ifndef MSTEP_FLY
 #define MSTEP_FLY 2      // reciprocals in flight per thread inside a bin (more: more temporaries live, see the remark at the loops)
 #endif
-constexpr int FT16 = MSTEP_FT, FG = FT16 / 16, FW = FT16 / 64, FJ16 = (513 + FG - 1) / FG;
-template <int RR, int K>
+// Round 5: FR = 8 frames per workgroup for short frame axes (one utterance of 300 frames = 20 workgroups of 16 frames on 256 CUs: the kernel is
+// per-workgroup latency there): 64 bin groups, 9 bins per thread -- half the loads and half the arithmetic per thread, twice the workgroups.
+constexpr int FT16 = MSTEP_FT, FW = FT16 / 64;
+template <int FR> struct MsGeo { static constexpr int FG = FT16 / FR, FJ = (513 + FG - 1) / FG; };
+template <int RR, int K, int FR = 16>
 __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N, int,
                                                                 const float* __restrict__ Wun_all, float* __restrict__ H, float* __restrict__ g,
                                                                 float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial,
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_count,
                                                                 const int* __restrict__ tile_seg) {
-    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [FW][2K][16], then sums [2K][16]
+    constexpr int FG = MsGeo<FR>::FG, FJ16 = MsGeo<FR>::FJ;         // (FJ16: bins per thread, whatever FR)
+    extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [FW][2K][FR], then sums [2K][FR]
     float* wpart = lw + (XD * K + 3) / 4 * 4;
-    float* sums = wpart + FW * 2 * K * 16;
-    float* x2s = sums + 2 * K * 16;                                  // [j][thread]: X2 of this thread's 17 bins (read in each of the three passes)
+    float* sums = wpart + FW * 2 * K * FR;
+    float* x2s = sums + 2 * K * FR;                                  // [j][thread]: X2 of this thread's 17 bins (read in each of the three passes)
     float* vlast = x2s + FJ16 * FT16;                                // [r][thread]: the sample variances of the LAST bin row (bin 512: one real bin, group 0 only)
     __shared__ float nrm[KMAX];
     __shared__ double redc[FW];
-    const int tid = threadIdx.x, fr = tid & 15, grp = tid >> 4, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, fr = tid & (FR - 1), grp = tid / FR, lane = tid & 63, wave = tid >> 6;
     // A workgroup's 16 frames are HALF of every 128-byte line of the (sample, bin) rows of Vs / X2 / Vb; the other half belongs to the
     // workgroup of the neighbouring 16 frames.  Workgroup i runs on XCD i % 8 (speed only, never correctness), so consecutive frame
     // blocks would pull every line into two L2s (twice the HBM traffic of the 164 MB the sample variances of 25 utterances take).
@@ -56,9 +60,9 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
 #define MSTEP_XCD_PAIRS 1
 #endif
     int bid = blockIdx.x;
-    if (MSTEP_XCD_PAIRS && bid < ((int)gridDim.x & ~15)) { const int w = bid & 15; bid = (bid & ~15) + ((w & 7) << 1) + (w >> 3); }
-    const int u = tile_seg ? tile_seg[bid >> 1] : 0;               // the segment table is per 32 frames
-    const int64_t n0 = (int64_t)bid * 16;
+    if (FR == 16 && MSTEP_XCD_PAIRS && bid < ((int)gridDim.x & ~15)) { const int w = bid & 15; bid = (bid & ~15) + ((w & 7) << 1) + (w >> 3); }
+    const int u = tile_seg ? tile_seg[bid / (32 / FR)] : 0;        // the segment table is per 32 frames
+    const int64_t n0 = (int64_t)bid * FR;
     const int64_t nend = seg_start ? (int64_t)seg_start[u] + seg_count[u] : N;
     const bool live = n0 + fr < nend;
     const bool any_live = n0 < nend;                               // (the second half of a segment's last 32 frames may be all padding)
@@ -150,17 +154,18 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
         for (int i = 0; i < M; ++i) {
             if (i < cnt) {
                 float a = v[i];
+                if constexpr (FR == 8) a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));   // lane ^ 8 (row_ror:8)
                 a = xsum16(a);                                      // (v_permlane16/32_swap: mcem_types.hpp; the operands of ds_bpermute's additions)
                 a = xsum32(a);
-                if (lane < 16) wpart[(wave * cnt + i) * 16 + fr] = a;
+                if (lane < FR) wpart[(wave * cnt + i) * FR + fr] = a;
             }
         }
         __syncthreads();
         if (grp < cnt) {
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < FW; ++w) a += wpart[(w * cnt + grp) * 16 + fr];
-            sums[grp * 16 + fr] = a;
+            for (int w = 0; w < FW; ++w) a += wpart[(w * cnt + grp) * FR + fr];
+            sums[grp * FR + fr] = a;
         }
         __syncthreads();
     };
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     });
     group_sums(acc, 2 * K);
 #pragma unroll
-    for (int k = 0; k < K; ++k) hk[k] = hk[k] * sqrtf(sums[(2 * k) * 16 + fr] / sums[(2 * k + 1) * 16 + fr]);
+    for (int k = 0; k < K; ++k) hk[k] = hk[k] * sqrtf(sums[(2 * k) * FR + fr] / sums[(2 * k + 1) * FR + fr]);
     __syncthreads();
 
     // ---- new Vb = Wun Hnew (mcem.py:126); g update (mcem.py:137-143) ----
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
         __builtin_amdgcn_sched_barrier(0);
     });
     group_sums(gv, 2);
-    const float gnew = gn * sqrtf(sums[fr] / sums[16 + fr]);
+    const float gnew = gn * sqrtf(sums[fr] / sums[FR + fr]);
 
     // ---- cost (mcem.py:69-71) with the updated g; H is stored normalised (mcem.py:134).  log through the hardware log2 (~1 ulp of log2) ----
     double c = 0.0;
@@ -333,18 +338,29 @@ __global__ __launch_bounds__(256) void mstep_w_reg_kernel(const float* __restric
 
 
 namespace mstep {
+// frames per workgroup of the frames kernel = frames per cost partial: 8 while the 8-frame workgroups fit the chip in one round (DVAE_MSTEP_FRAMES=8 / 16 forces)
+int frames_per_workgroup(int64_t N) {
+    const char* e = getenv("DVAE_MSTEP_FRAMES");
+    const int forced = e ? atoi(e) : 0;
+    if (forced == 8 || forced == 16) return forced;
+    return (N + 7) / 8 <= 256 ? 8 : 16;
+}
 int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
-    const int nt16 = (int)((N + 15) / 16);
-    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + FW * 2 * K * 16 + 2 * K * 16 + FJ16 * FT16 + 10 * FT16) * sizeof(float);
+    const int fr = frames_per_workgroup(N);
+    const int nt = (int)((N + fr - 1) / fr);
+    const int FJ = fr == 8 ? MsGeo<8>::FJ : MsGeo<16>::FJ;
+    const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + FW * 2 * K * fr + 2 * K * fr + FJ * FT16 + 10 * FT16) * sizeof(float);
     static bool attr_done16 = false;
     if (!attr_done16) {
-        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + FW * 2 * KMAX * 16 + 2 * KMAX * 16 + FJ16 * FT16 + 10 * FT16) * sizeof(float);
-        hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + FW * 2 * KMAX * 16 + 2 * KMAX * 16 + MsGeo<16>::FJ * FT16 + 10 * FT16) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_reg_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
         attr_done16 = true;
     }
-    hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10>), dim3(nt16), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    if (fr == 8) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 8>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    else hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 16>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
     DVAE_LAUNCH_OK("mstep_frames_reg_kernel");
     return 0;
 }
