@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4_t hv[HD / 8];
 #pragma unroll
             for (int o = 0; o < HD / 8; ++o) hv[o] = *reinterpret_cast<const f32x4_t*>(hr + 4 * o);
+            __builtin_amdgcn_sched_barrier(0);                             // (hipcc otherwise sinks every read to just above its MFMAs, two quads in flight)
 #pragma unroll
             for (int o = 0; o < HD / 8; ++o) {
                 a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4A[4 * o], hv[o][0], a0, 0, 0, 0);
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4_t hv[RING];
 #pragma unroll
             for (int o = 0; o < RING; ++o) hv[o] = *reinterpret_cast<const f32x4_t*>(hr + 4 * o);
+            __builtin_amdgcn_sched_barrier(0);
             sfor<0, HD / 4>([&](auto oc) {
                 constexpr int o = decltype(oc)::value;
                 sfor<0, 4>([&](auto ec) {
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     mf4<(k < KAG), false, (k == 0)>(oa[0], w5A[0][k], hv[o % RING][e]);
                     mf4<(k < KAG), (k == HD - 1), (k == 0)>(oa[1], w5A[1][k], hv[o % RING][e]);
                 });
-                if constexpr (o + RING < HD / 4) hv[o % RING] = *reinterpret_cast<const f32x4_t*>(hr + 4 * (o + RING));
+                if constexpr (o + RING < HD / 4) { hv[o % RING] = *reinterpret_cast<const f32x4_t*>(hr + 4 * (o + RING)); __builtin_amdgcn_sched_barrier(0); }
             });
         }
 #pragma unroll
