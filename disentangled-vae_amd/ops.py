@@ -101,6 +101,91 @@ def linear_act(x0, W, b, act, x1=None):
     return LinearAct.apply(x0, x1, W, b, act)
 
 
+class LinearStack(torch.autograd.Function):
+    """act_L(... act_1([x0 | x1] @ W1.T + b1) ...) @ ... as ONE autograd node: the kernels LinearAct launches per layer, in the same order,
+    with one trip through the interpreter per direction instead of one per layer (models.py:57-63: Classifier; 102-105, 119-122: the tanh
+    stacks of Encoder / Decoder).  The scripts' M2_info step runs three such stacks forward and four times backward; a Python-level
+    Function costs 20 - 30 us of host time per direction, and that loop is host-bound (tools/r05/prof_modules.py)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, acts, *wb):
+        saved, h, h1 = [], x0, x1
+        for i, act in enumerate(acts):
+            out, x0_, x1_, W_ = linear_act_fwd(h, h1, wb[2 * i], wb[2 * i + 1], act)
+            saved += [x0_, W_, out]
+            if i == 0:
+                saved.append(x1_ if x1_ is not None else torch.empty(0))
+            h, h1 = out, None
+        ctx.acts = tuple(acts)
+        ctx.has_x1 = x1 is not None
+        ctx.has_bias = tuple(wb[2 * i + 1] is not None for i in range(len(acts)))
+        ctx.lead0 = x0.shape[:-1]
+        ctx.lead1 = None if x1 is None else x1.shape[:-1]
+        ctx.save_for_backward(*saved)
+        return h.reshape(*x0.shape[:-1], h.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = N.load()
+        sv = ctx.saved_tensors
+        L = len(ctx.acts)
+        # layer 0 saved (x0, W, out, x1); layer i > 0 saved (x0, W, out)
+        def layer(i):
+            o = 0 if i == 0 else 4 + 3 * (i - 1)
+            return sv[o], sv[o + 1], sv[o + 2]
+        x1_ = sv[3] if ctx.has_x1 else None
+        s = N.stream()
+        grads = [None] * (2 * L)
+        d = N.as_f32_2d(dout, "linear_stack backward: grad")
+        dx0 = dx1 = None
+        for i in range(L - 1, -1, -1):
+            x0_, W_, out = layer(i)
+            B, Nout = out.shape
+            k0 = x0_.shape[1]
+            xe = x1_ if i == 0 else None
+            k1 = 0 if xe is None else xe.shape[1]
+            act = ctx.acts[i]
+            if act == N.ACT_NONE:
+                dpre = d
+            else:
+                dpre = _new((B, Nout), out)
+                N.check(lib.dvae_act_bwd(N.ptr(d), N.ld(d), N.ptr(out), Nout, N.ptr(dpre), Nout, B, Nout, act, s), "dvae_act_bwd")
+            need_w = ctx.needs_input_grad[3 + 2 * i]
+            need_b = ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]
+            if need_w or need_b:
+                dW = _new((Nout, k0 + k1), out)
+                db = _new((Nout,), out) if ctx.has_bias[i] else None
+                nws = lib.dvae_linear_bwd_weight_workspace_bytes(B, Nout, k0 + k1, 0)
+                ws = torch.empty(nws, dtype=torch.uint8, device=out.device) if nws else None
+                N.check(lib.dvae_linear_bwd_weight_det(N.ptr(dpre), N.ld(dpre), N.ptr(x0_), k0, N.ld(x0_), N.ptr(xe), k1,
+                                                       0 if xe is None else N.ld(xe), N.ptr(dW), k0 + k1, N.ptr(db), B, Nout, 0, N.ptr(ws), s),
+                        "dvae_linear_bwd_weight_det")
+                grads[2 * i] = dW if need_w else None
+                grads[2 * i + 1] = db if need_b else None
+            if i > 0 or ctx.needs_input_grad[0]:
+                dx = _new((B, k0), out)
+                N.check(lib.dvae_linear_bwd_data(N.ptr(dpre), N.ld(dpre), N.ptr(W_), N.ld(W_), 0, N.ptr(dx), k0, B, Nout, k0, 0, s),
+                        "dvae_linear_bwd_data")
+                if i > 0:
+                    d = dx
+                else:
+                    dx0 = dx.reshape(*ctx.lead0, k0)
+            if i == 0 and xe is not None and ctx.needs_input_grad[1]:
+                dx1 = _new((B, k1), out)
+                N.check(lib.dvae_linear_bwd_data(N.ptr(dpre), N.ld(dpre), N.ptr(W_), N.ld(W_), k0, N.ptr(dx1), k1, B, Nout, k1, 0, s),
+                        "dvae_linear_bwd_data")
+                dx1 = dx1.reshape(*ctx.lead1, k1)
+        return (dx0, dx1, None, *grads)
+
+
+def linear_stack(x0, layers, acts, x1=None):
+    """layers: [(weight, bias), ...]; acts: activation codes, one per layer."""
+    wb = []
+    for W, b in layers:
+        wb += [W, b]
+    return LinearStack.apply(x0, x1, tuple(acts), *wb)
+
+
 class Reparam(torch.autograd.Function):
     """z = mu + exp(0.5 * log_var) * epsilon   (models.py:9-22)."""
 

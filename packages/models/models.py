@@ -47,8 +47,21 @@ def _linear_stack(widths):
     return [nn.Linear(widths[i - 1], widths[i]) for i in range(1, len(widths))]
 
 
+def _stack_ok(layers, x):
+    import os
+    return (x.is_cuda and x.dtype == torch.float32 and len(layers) > 1 and all(isinstance(l, nn.Linear) for l in layers)
+            and os.environ.get("DVAE_LINEAR_STACK", "1") != "0")
+
+
+def _run_stack(layers, acts, x, extra=None):
+    """The Linear + activation layers `layers` as ONE autograd node on the device (the same kernels as layer by layer: `ops.LinearStack`)."""
+    return _native.ops().linear_stack(x, [(l.weight, l.bias) for l in layers], [_ACT_CODE[a] for a in acts], extra)
+
+
 def _run_hidden(hidden, x, act, extra=None):
     """`for layer in self.hidden: x = act(layer(x))` (reference models.py:59-60, 103-104, 120-121)."""
+    if _stack_ok(list(hidden), x):
+        return _run_stack(list(hidden), [act] * len(hidden), x, extra)
     for layer in hidden:
         if isinstance(layer, nn.Linear):
             x = _dense(layer, x, act, extra)
@@ -128,6 +141,9 @@ class Classifier(nn.Module):
         self.output_layer = nn.Linear(h_dim[-1], y_dim)
 
     def forward(self, x):
+        layers = [*self.hidden, self.output_layer]
+        if _stack_ok(layers, x):
+            return _run_stack(layers, ["relu"] * len(self.hidden) + ["sigmoid"], x)
         x = _run_hidden(self.hidden, x, "relu")
         return _dense(self.output_layer, x, "sigmoid")
 
@@ -179,6 +195,9 @@ class Decoder(nn.Module):
         self.reconstruction = nn.Linear(h_dim[-1], x_dim)
 
     def forward(self, x, extra=None):
+        layers = [*self.hidden, self.reconstruction]
+        if _stack_ok(layers, x):
+            return _run_stack(layers, ["tanh"] * len(self.hidden) + ["exp"], x, extra)
         return _dense(self.reconstruction, _run_hidden(self.hidden, x, "tanh", extra), "exp")
 
 

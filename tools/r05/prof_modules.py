@@ -7,10 +7,11 @@ import bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+model = sys.argv[3] if len(sys.argv) > 3 else "M2"
 synth = importlib.import_module("disentangled-vae_amd.synth")
-dims = dict(x_dim=513, y_dim=513, z_dim=16, h_dim=[128, 128])
+dims = dict(x_dim=513, y_dim=513 if model == "M2" else 1, z_dim=16, h_dim=[128, 128])
 dev = torch.device("cuda", 0)
-impl = bench.ModulesImpl("M2", dims, dev, 1)
+impl = bench.ModulesImpl(model, dims, dev, 1)
 batches = synth.device_batches(dims, B, 4, 1234, dev)
 
 def loop(n, item):
@@ -25,6 +26,12 @@ for item in (False, True):
     t0 = time.perf_counter(); loop(steps, item); torch.cuda.synchronize()
     print("drop-in modules, B %d, loss.item() every step: %s -> %.1f us / step" % (B, item, (time.perf_counter() - t0) / steps * 1e6), flush=True)
 
+if model != "M2":
+    pr = cProfile.Profile(); pr.enable(); loop(steps, True); pr.disable(); torch.cuda.synchronize()
+    for key, n in (("tottime", 45), ("cumulative", 60)):
+        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(key).print_stats(n)
+        print("\n".join(l[:200] for l in s.getvalue().splitlines()))
+    sys.exit(0)
 # plain torch modules of the same shapes, same loop (PyTorch's own floor on this host)
 import torch.nn as nn
 class Plain(nn.Module):
