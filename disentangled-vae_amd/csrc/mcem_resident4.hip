@@ -48,7 +48,8 @@ constexpr size_t O_BIAS = O_C1 + (size_t)T4 * LDC * sizeof(float);
 constexpr size_t O_W512 = O_BIAS + (size_t)(2 * HD + NO) * sizeof(float);
 constexpr size_t O_P512 = O_W512 + (size_t)HD * sizeof(float);
 constexpr size_t O_RED = O_P512 + (size_t)4 * T4 * sizeof(float);
-constexpr size_t LDS = O_RED + (size_t)4 * T4 * sizeof(double);
+constexpr size_t O_ACC = O_RED + (size_t)4 * T4 * sizeof(double);         // [frame]: the last step's accept decision, for the other waves
+constexpr size_t LDS = O_ACC + (size_t)T4 * sizeof(int);
 static_assert(O_X2 % 16 == 0 && O_C1 % 16 == 0 && O_BIAS % 16 == 0 && O_W512 % 16 == 0 && O_RED % 8 == 0, "4-frame chain: LDS layout");
 static_assert((size_t)T4 * LDY * sizeof(float) <= O_C1 - O_X2, "the label image fits the X2 / Vb area");
 
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* const w512s = reinterpret_cast<float*>(smem + O_W512);
     float* const p512 = reinterpret_cast<float*>(smem + O_P512);          // [wave][frame]
     double* const red = reinterpret_cast<double*>(smem + O_RED);          // [wave][frame]
+    int* const accf = reinterpret_cast<int*>(smem + O_ACC);
 
     // eight consecutive tiles = one 128-byte line of every (bin, N) row: on ONE XCD (workgroup i runs on XCD i % 8)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -358,6 +360,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stamp(6);
     };
 
+    // The decoder variances of the kept samples (compute_Vs, mcem.py:280-290) are those of the chain's STATE at the kept steps, and a state's
+    // variances were computed by the pass that proposed it: every lane keeps exp(pre-activation) of its eight bins for the current state
+    // (vcur) and for the last proposal (vprop), takes the proposal's when wave 0 has accepted it (flag through LDS, read behind the next
+    // barrier) and writes vcur out at the kept steps -- the same bits a decoder pass over the stored sample returns (tested), without the
+    // ten extra passes per chain that were a fifth of its time.
+    const bool want_vs = g.Vs != nullptr && g.nit > 0;
+    float vprop[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, vcur[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float vprop512 = 0.f, vcur512 = 0.f;
+    auto settle = [&](int md) __attribute__((always_inline)) {             // md: the step whose decision `accf` holds (-1: the evaluation of the initial state)
+        if (accf[j] != 0) {
+#pragma unroll
+            for (int R = 0; R < 2; ++R)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vcur[R][i] = vprop[R][i];
+            vcur512 = vprop512;
+        }
+        if (md >= g.burnin && live) {
+            float* const vs_r = g.Vs + (int64_t)(md - g.burnin) * XD * g.N;
+            const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(vs_r, 0, fn_bytes, 0x00020000);
+#pragma unroll
+            for (int R = 0; R < 2; ++R)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vcur[R][i]), rs_vs, voff, soff(R, i), 0);
+            if (wave_u == 3 && b == 0) vs_r[(int64_t)512 * g.N + nf] = vcur512;
+        }
+    };
     const int mstart = g.nit > 0 ? -1 : 0;
     const int mend = g.nit > 0 ? g.nit : 0;
     // the draws of chain step m + 1 are requested while step m runs (wave 0)
@@ -404,16 +432,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stamp(0);
         __syncthreads();                                                   // B0
         stamp(1);
+        if (want_vs && m > mstart) settle(m - 1);
         double ll = 0.0;
         float slog = 0.f, sdiv = 0.f;                                      // sums of log2(vx) and x2 / vx over the lane's eight bins
         pass(
-            [&](int, int, float a, float x2, float vb) {
-                const float vx = fmaf(g_n, exp_(a), vb);                                          // mcem.py:248-249
+            [&](int R, int i, float a, float x2, float vb) {
+                const float ea = exp_(a);
+                vprop[R][i] = ea;
+                const float vx = fmaf(g_n, ea, vb);                                               // mcem.py:248-249
                 slog += __builtin_amdgcn_logf(vx);                                                // mcem.py:252-253: log(vx) + x2 / vx
                 sdiv = fmaf(x2, __builtin_amdgcn_rcpf(vx), sdiv);
             },
             [&](float a) {
-                const float vx = fmaf(g_n, exp_(a), vb_512);
+                const float ea = exp_(a);
+                vprop512 = ea;
+                const float vx = fmaf(g_n, ea, vb_512);
                 const float term = log_(vx) + div_(x2_512, vx);
                 if (b == 0) ll += (double)term;
             });
@@ -427,10 +460,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const double ll_p = red[j] + red[T4 + j] + red[2 * T4 + j] + red[3 * T4 + j];
             if (m < 0) {
                 ll_cur = ll_p; prior_cur = prior_p;
+                if (b == 0) accf[j] = 1;
             } else {
                 const float acc_prob = (float)(ll_cur - ll_p) + 0.5f * (prior_cur - prior_p);       // mcem.py:252-254
                 const bool is_acc = lu_cur < acc_prob;                                               // mcem.py:257 (the same bits in the frame's sixteen lanes)
                 if (is_acc) { ll_cur = ll_p; prior_cur = prior_p; z = zp; }
+                if (b == 0) accf[j] = is_acc ? 1 : 0;
                 pend_m = m; pend_prob = acc_prob; pend_acc = is_acc;                                 // stored behind the next proposal (flush_step)
             }
         }
@@ -444,8 +479,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         g.dbg[((size_t)tile * 4 + wave_u) * 16 + 9] = (unsigned long long)(mend - mstart);
     }
 
-    // ---- speech variances of the kept samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
-    if (g.Vs != nullptr) {
+    if (want_vs) {                                                         // the last step's decision
+        __syncthreads();
+        settle(mend - 1);
+    }
+    // ---- decode mode (dvae_mcem_decode): Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
+    if (g.Vs != nullptr && g.nit == 0) {
         for (int r_s = 0; r_s < g.R; ++r_s) {
             __syncthreads();
             if (wave_u == 0) Zb[j * LDZ + b] = g.Zs[((int64_t)nf * g.R + r_s) * ZD + b];
