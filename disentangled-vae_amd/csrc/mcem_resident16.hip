@@ -73,7 +73,9 @@ constexpr size_t S_O_BIAS = S_O_C1 + (size_t)T16 * S_LDC * sizeof(float);
 constexpr size_t S_O_W512 = S_O_BIAS + (size_t)(2 * HD + NO) * sizeof(float);
 constexpr size_t S_O_P512 = S_O_W512 + (size_t)HD * sizeof(float);
 constexpr size_t S_O_RED = S_O_P512 + (size_t)4 * T16 * sizeof(float);
-constexpr size_t S_LDS = S_O_RED + (size_t)4 * T16 * sizeof(double);
+constexpr size_t S_O_ACC = S_O_RED + (size_t)4 * T16 * sizeof(double);           // [frame]: the last step's accept decision, for the other waves
+constexpr size_t S_O_VC = (S_O_ACC + (size_t)T16 * sizeof(int) + 15) / 16 * 16;     // decoder variances of the chain's current state: [row tile 0..31][lane][4]
+constexpr size_t S_LDS = S_O_VC + (size_t)32 * 64 * 4 * sizeof(float);
 static_assert(S_O_X2 % 16 == 0 && S_O_C1 % 16 == 0 && S_O_BIAS % 16 == 0 && S_O_RED % 8 == 0 && S_LDS <= 160 * 1024, "resident chain (16 frames): LDS layout");
 static_assert((size_t)T16 * SL<__bf16>::ldy * 2 * sizeof(__bf16) <= S_O_C1 - S_O_X2 && (size_t)T16 * SL<float>::ldy * sizeof(float) <= S_O_C1 - S_O_X2,
               "the label image fits the X2 / Vb area");
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* const w512s = reinterpret_cast<float*>(smem + S_O_W512);
     float* const p512 = reinterpret_cast<float*>(smem + S_O_P512);        // [wave][frame]
     double* const red = reinterpret_cast<double*>(smem + S_O_RED);        // [wave][frame]
+    int* const accf = reinterpret_cast<int*>(smem + S_O_ACC);
+    f32x4_t* const Vcs = reinterpret_cast<f32x4_t*>(smem + S_O_VC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -482,6 +486,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stamp(6);
         };
 
+        // The decoder variances of the kept samples (compute_Vs, mcem.py:280-290) are those of the chain's STATE at the kept steps, and a state's
+        // variances were computed by the pass that proposed it: a lane keeps exp(pre-activation) of its 32 bins of the last proposal in
+        // registers, moves them to the state's copy in LDS when wave 0 has accepted the proposal (flag through LDS, read behind the next
+        // barrier) and writes that copy out at the kept steps -- the bits a decoder pass over the stored sample returns (tested), without
+        // the ten extra passes per chain that were a fifth of its time.
+        const bool want_vs = g.Vs != nullptr && g.nit > 0;
+        float vprop[NTW][4];
+        float vprop512 = 0.f, vcur512 = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vprop[tt][j] = 0.f;
+        auto settle = [&](int md) __attribute__((always_inline)) {         // md: the step whose decision `accf` holds (-1: the evaluation of the initial state)
+            if (accf[f16] != 0) {
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) Vcs[(NTW * wave_u + tt) * 64 + lane] = f32x4_t{vprop[tt][0], vprop[tt][1], vprop[tt][2], vprop[tt][3]};
+                vcur512 = vprop512;
+            }
+            if (md >= g.burnin && live) {
+                float* const vs_r = g.Vs + (int64_t)(md - g.burnin) * XD * g.N;
+                const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(vs_r, 0, fn_bytes, 0x00020000);
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) {
+                    const f32x4_t v = Vcs[(NTW * wave_u + tt) * 64 + lane];
+                    const float vj[4] = {v[0], v[1], v[2], v[3]};          // (indexing the vector with the loop variable made hipcc store element 0 four times)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vj[j]), rs_vs, voff, soff(NTW * wave_u + tt, j), 0);
+                }
+                if (wave_u == 3 && q == 0) vs_r[(int64_t)512 * g.N + nf] = vcur512;
+            }
+        };
         const int mstart = g.nit > 0 ? -1 : 0;
         const int mend = g.nit > 0 ? g.nit : 0;
         // the draws of chain step m + 1 are requested while step m runs (wave 0)
@@ -542,19 +577,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stamp(0);
             __syncthreads();                                               // B0
             stamp(1);
+            if (want_vs && m > mstart) settle(m - 1);
             double ll = 0.0;
             float slog = 0.f, sdiv = 0.f, vx = 0.f;                        // sums of log2(vx) and x2 / vx over one tile
             pass(
                 [&](auto) { slog = 0.f; sdiv = 0.f; },
-                [&](auto, int, auto, auto part, float a, float x2, float vb) {
+                [&](auto tc, int, auto rc, auto part, float a, float x2, float vb) {
                     constexpr int pt = decltype(part)::value;
-                    if constexpr (pt == 0) vx = fmaf(g_n, P::exp_(a), vb);                         // mcem.py:248-249
-                    else if constexpr (pt == 1) slog += __builtin_amdgcn_logf(vx);                 // mcem.py:252-253: log(vx) + x2 / vx
+                    if constexpr (pt == 0) {
+                        const float ea = P::exp_(a);
+                        vprop[decltype(tc)::value][decltype(rc)::value] = ea;
+                        vx = fmaf(g_n, ea, vb);                                                    // mcem.py:248-249
+                    } else if constexpr (pt == 1) slog += __builtin_amdgcn_logf(vx);              // mcem.py:252-253: log(vx) + x2 / vx
                     else sdiv = fmaf(x2, __builtin_amdgcn_rcpf(vx), sdiv);
                 },
                 [&](auto) { ll += (double)fmaf(slog, 0.693147180559945309f, sdiv); },
                 [&](float a) {
-                    const float vx = fmaf(g_n, P::exp_(a), vb_512);
+                    const float ea = P::exp_(a);
+                    vprop512 = ea;
+                    const float vx = fmaf(g_n, ea, vb_512);
                     const float term = P::log_(vx) + P::div_(x2_512, vx);
                     if (q == 0) ll += (double)term;
                 });
@@ -568,6 +609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const double ll_p = red[f16] + red[T16 + f16] + red[2 * T16 + f16] + red[3 * T16 + f16];
                 if (m < 0) {
                     ll_cur = ll_p; prior_cur = prior_p;
+                    if (q == 0) accf[f16] = 1;
                 } else {
                     const float acc_prob = (float)(ll_cur - ll_p) + 0.5f * (prior_cur - prior_p);   // mcem.py:252-254
                     const bool is_acc = lu_cur < acc_prob;                                           // mcem.py:257
@@ -576,6 +618,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                         for (int j = 0; j < 4; ++j) z[j] = zp[j];
                     }
+                    if (q == 0) accf[f16] = is_acc ? 1 : 0;
                     pend_m = m; pend_prob = acc_prob; pend_acc = is_acc;                             // stored behind the next proposal (flush_step)
                 }
             }
@@ -592,8 +635,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 9] = (unsigned long long)(mend - mstart);
         }
 
-        // ---- speech variances of the kept samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
-        if (g.Vs != nullptr) {
+        if (want_vs) {                                                     // the last step's decision
+            __syncthreads();
+            settle(mend - 1);
+        }
+        // ---- decode mode (dvae_mcem_decode): Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
+        if (g.Vs != nullptr && g.nit == 0) {
             for (int r_s = 0; r_s < g.R; ++r_s) {
                 __syncthreads();
                 if (wave_u == 0) {
