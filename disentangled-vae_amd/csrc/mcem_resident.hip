@@ -66,8 +66,10 @@ constexpr size_t C8_O_BIAS = C8_O_C1 + (size_t)TB * C8_LDC * sizeof(float);
 constexpr size_t C8_O_W512 = C8_O_BIAS + (size_t)(2 * HD + NO) * sizeof(float);
 constexpr size_t C8_O_P512 = C8_O_W512 + (size_t)HD * sizeof(float);
 constexpr size_t C8_O_RED = C8_O_P512 + (size_t)4 * TB * sizeof(float);
-constexpr size_t C8_LDS = C8_O_RED + (size_t)4 * TB * sizeof(double);
-static_assert(C8_O_RED % 8 == 0 && C8_LDS <= 160 * 1024, "resident chain: LDS layout");
+constexpr size_t C8_O_REJ = C8_O_RED + (size_t)4 * TB * sizeof(double);       // [frame]: bit r = kept step r rejected its proposal
+constexpr size_t C8_O_ZSV = C8_O_REJ + (size_t)TB * sizeof(unsigned long long);  // [lane of wave 0][8]: the state at the end of the burn-in
+constexpr size_t C8_LDS = C8_O_ZSV + (size_t)64 * 8 * sizeof(float);
+static_assert(C8_O_RED % 8 == 0 && C8_O_ZSV % 16 == 0 && C8_LDS <= 160 * 1024, "resident chain: LDS layout");
 
 // acc = W(resident fragments, hi / lo planes) * act^T over NSTEPS k-steps of 16, the weight operand read straight from ACCUMULATION registers.
 // hipcc never assigns an AGPR to an MFMA source by itself (it parks the fragments there and copies them to VGPRs in front of every MFMA: 340
@@ -198,6 +200,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* const w512s = reinterpret_cast<float*>(smem + C8_O_W512);      // row 512 of the output layer, fp32 (hi + lo)
     float* const p512 = reinterpret_cast<float*>(smem + C8_O_P512);       // [wave][frame]: partial pre-activation of bin 512
     double* const red = reinterpret_cast<double*>(smem + C8_O_RED);       // [wave][frame]: partial likelihood sums
+    unsigned long long* const rejs = reinterpret_cast<unsigned long long*>(smem + C8_O_REJ);
+    float* const zsv = reinterpret_cast<float*>(smem + C8_O_ZSV);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -248,7 +252,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const T* const Har = Ha + l31 * LDH + h * E;
     const T* const Hbr = Hb + l31 * LDH + h * E;
 
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    // (one tile per workgroup -- the launcher's grid is the tile count: the resident fragments are dead behind the chain, their registers
+    // hold the rows the fix-up below moves)
+    if (const int tile = blockIdx.x; tile < g.ntiles) {
         const int64_t n0 = (int64_t)tile * TB;
         const bool live = n0 + l31 < g.N;
         const int64_t nf = live ? n0 + l31 : g.N - 1;                      // clamped frame index of this lane
@@ -465,8 +471,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 pend_m = -1;
             }
         };
+        // The decoder variances of the kept samples (compute_Vs, mcem.py:280-290) are those of the chain's STATE at the kept steps, and a
+        // state's variances were computed by the pass that proposed it.  Neither registers nor LDS have room for a second set of 64 values
+        // per lane here, so a kept step r stores exp(pre-activation) of its PROPOSAL to Vs[r] as it computes it; where the proposal was
+        // rejected the state is that of step r - 1, and the lane copies its own values Vs[r - 1] -> Vs[r] behind the chain (runs of
+        // rejections: one load, several stores); the state at the end of the burn-in takes ONE decoder pass.  42 passes per chain of
+        // 30 + 10 steps instead of 51, the same bits (tested against the decode mode).
+        // Exact fp32 only: a copied row costs its HBM bytes (4.5 - 6.4 us per kept sample at 25 utterances, measured), a pass 12.6 us under
+        // fp32 but 5.2 / 4 us under the bf16 policies -- those keep the decoder passes (chain launch, 25 utterances, 30 + 10 steps:
+        // fp32 748 -> 680 us; bf16x3 370 -> 361, with 75 + 25 steps 771 -> 795: profiles/r05_mcem_tile32_no_decode_ab.txt)
+        const bool want_vs = sizeof(T) == 4 && g.Vs != nullptr && g.nit > 0 && g.R >= 1 && g.R <= 64;
+        constexpr int OOR = 0x7fffffff;                                    // a per-lane offset behind every buffer: the access is dropped
+        if (wave_u == 0 && h == 0) rejs[l31] = 0ull;                       // (touched by these lanes only until the chain has ended)
         if (g.dbg) tlast = __builtin_amdgcn_s_memtime();
         for (int m = mstart; m < mend; ++m) {
+            const bool keepst = want_vs && m >= g.burnin;
             float prior_p = 0.f, lu_cur = 0.f;
             if (wave_u == 0) {
                 if (m >= 0) {
@@ -493,19 +512,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stamp(1);
             double ll = 0.0;
             float slog = 0.f, sdiv = 0.f;                                  // sums of log2(vx) and x2 / vx over one tile
-            pass(
-                [&](auto) { slog = 0.f; sdiv = 0.f; },
-                [&](auto, int, auto, float a, float x2, float vb) {
-                    const float vx = fmaf(g_n, P::exp_(a), vb);                                   // mcem.py:248-249
-                    slog += __builtin_amdgcn_logf(vx);                                            // mcem.py:252-253: log(vx) + x2 / vx
-                    sdiv = fmaf(x2, __builtin_amdgcn_rcpf(vx), sdiv);
-                },
-                [&](auto) { ll += (double)fmaf(slog, 0.693147180559945309f, sdiv); },
-                [&](float a) {
-                    const float vx = fmaf(g_n, P::exp_(a), vb_512);
-                    const float term = P::log_(vx) + P::div_(x2_512, vx);
-                    if (h == 0) ll += (double)term;
-                });
+            auto epi_begin = [&](auto) { slog = 0.f; sdiv = 0.f; };
+            auto epi_end = [&](auto) { ll += (double)fmaf(slog, 0.693147180559945309f, sdiv); };
+            // (two instances of the pass: the stores of the kept steps cost registers the other steps do not have to pay for)
+            if (keepst) {
+                const int voff_st = live ? voff : OOR;
+                float* const vs_m = g.Vs + (int64_t)(m - g.burnin) * XD * g.N;
+                const __amdgpu_buffer_rsrc_t rs_vsm = __builtin_amdgcn_make_buffer_rsrc(vs_m, 0, fn_bytes, 0x00020000);
+                pass(
+                    epi_begin,
+                    [&](auto, int t, auto rc, float a, float x2, float vb) {
+                        const float ea = P::exp_(a);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ea), rs_vsm, voff_st, soff(t, decltype(rc)::value), 0);
+                        const float vx = fmaf(g_n, ea, vb);                                       // mcem.py:248-249
+                        slog += __builtin_amdgcn_logf(vx);                                        // mcem.py:252-253: log(vx) + x2 / vx
+                        sdiv = fmaf(x2, __builtin_amdgcn_rcpf(vx), sdiv);
+                    },
+                    epi_end,
+                    [&](float a) {
+                        const float ea = P::exp_(a);
+                        if (live && h == 0) vs_m[(int64_t)512 * g.N + nf] = ea;
+                        const float vx = fmaf(g_n, ea, vb_512);
+                        const float term = P::log_(vx) + P::div_(x2_512, vx);
+                        if (h == 0) ll += (double)term;
+                    });
+            } else {
+                pass(
+                    epi_begin,
+                    [&](auto, int, auto, float a, float x2, float vb) {
+                        const float vx = fmaf(g_n, P::exp_(a), vb);                               // mcem.py:248-249
+                        slog += __builtin_amdgcn_logf(vx);                                        // mcem.py:252-253: log(vx) + x2 / vx
+                        sdiv = fmaf(x2, __builtin_amdgcn_rcpf(vx), sdiv);
+                    },
+                    epi_end,
+                    [&](float a) {
+                        const float vx = fmaf(g_n, P::exp_(a), vb_512);
+                        const float term = P::log_(vx) + P::div_(x2_512, vx);
+                        if (h == 0) ll += (double)term;
+                    });
+            }
             ll = xsum32(ll);
             if (h == 0) red[wave_u * TB + l31] = ll;
             stamp(7);
@@ -523,7 +568,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                         for (int r = 0; r < 8; ++r) z[r] = zp[r];
                     }
+                    if (!is_acc && m >= g.burnin && h == 0) rejs[l31] |= 1ull << ((m - g.burnin) & 63);
                     pend_m = m; pend_prob = acc_prob; pend_acc = is_acc;                             // stored behind the next proposal (flush_step)
+                }
+                if (m == g.burnin - 1) {                                                             // the state the kept steps start from
+                    *reinterpret_cast<f32x4*>(zsv + lane * 8) = f32x4{z[0], z[1], z[2], z[3]};
+                    *reinterpret_cast<f32x4*>(zsv + lane * 8 + 4) = f32x4{z[4], z[5], z[6], z[7]};
                 }
             }
             // red / p512 / Zb are next written behind the barriers of the following pass
@@ -539,8 +589,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 9] = (unsigned long long)(mend - mstart);
         }
 
-        // ---- speech variances of the kept samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
-        if (g.Vs != nullptr) {
+        if (want_vs) {
+            if (wave_u == 0) {
+                float zv[16];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { zv[r] = zsv[lane * 8 + r]; zv[r + 8] = 0.f; }
+                put_lds<P>(zv, Zb, LDZ, 0, l31, h);
+            }
+            __syncthreads();
+            const unsigned long long myrej = rejs[l31];
+            // Vs[0] of the frames whose first kept step was rejected: the state at the end of the burn-in
+            if (__builtin_amdgcn_ballot_w64((myrej & 1ull) != 0ull) != 0ull) {
+                const bool st0 = live && (myrej & 1ull) != 0ull;
+                const int voff0 = st0 ? voff : OOR;
+                const __amdgpu_buffer_rsrc_t rs_v0 = __builtin_amdgcn_make_buffer_rsrc(g.Vs, 0, fn_bytes, 0x00020000);
+                pass(
+                    [](auto) {},
+                    [&](auto, int t, auto rc, float a, float, float) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, P::exp_(a)), rs_v0, voff0, soff(t, decltype(rc)::value), 0);
+                    },
+                    [](auto) {},
+                    [&](float a) { if (st0 && h == 0) g.Vs[(int64_t)512 * g.N + nf] = P::exp_(a); });
+            }
+            // rejected kept steps r >= 1: Vs[r] <- Vs[r - 1], lane by lane (a lane reads what it stored itself)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float buf[NTW][16], buf512 = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) buf[tt][r] = 0.f;
+            bool have = false;
+            const bool own512 = wave_u == 3 && h == 0;
+            for (int rk = 1; rk < g.R; ++rk) {
+                const bool rj = ((myrej >> rk) & 1ull) != 0ull;
+                if (__builtin_amdgcn_ballot_w64(rj) == 0ull) { have = false; continue; }
+                const bool need = rj && !have && live;
+                float* const src = g.Vs + (int64_t)(rk - 1) * XD * g.N;
+                float* const dst = g.Vs + (int64_t)rk * XD * g.N;
+                if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(src, 0, fn_bytes, 0x00020000);
+                    const int vo = need ? voff : OOR;
+#pragma unroll
+                    for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_src, vo, soff(NTW * wave_u + tt, r), 16));
+                            buf[tt][r] = need ? x : buf[tt][r];
+                        }
+                    if (own512 && need) buf512 = __builtin_nontemporal_load(src + (int64_t)512 * g.N + nf);
+                }
+                have = rj;
+                const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(dst, 0, fn_bytes, 0x00020000);
+                const int vs = (rj && live) ? voff : OOR;
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, buf[tt][r]), rs_dst, vs, soff(NTW * wave_u + tt, r), 0);
+                if (own512 && rj && live) dst[(int64_t)512 * g.N + nf] = buf512;
+                // (no wait for these stores: a lane that stored slot rk holds its values -- it never reads them back)
+            }
+        }
+        // ---- decode mode (dvae_mcem_decode), and chains keeping more than 64 samples: Vs[r] = decoder([Zs[:, r, :] | y])  (mcem.py:280-290) ----
+        if (g.Vs != nullptr && !want_vs) {
             for (int r_s = 0; r_s < g.R; ++r_s) {
                 __syncthreads();
                 if (wave_u == 0) {
