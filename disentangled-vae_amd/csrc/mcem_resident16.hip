@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const T* const Har = Ha + f16 * S_LDH + q * E;
     const T* const Hbr = Hb + f16 * S_LDH + q * E;
 
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    // (one tile per workgroup -- the launcher's grid is the tile count: nothing of the chain has to stay live for a next tile)
+    if (const int tile = blockIdx.x; tile < g.ntiles) {
         const int64_t n0 = (int64_t)tile * T16;
         const bool live = n0 + f16 < g.N;
         const int64_t nf = live ? n0 + f16 : g.N - 1;                      // clamped frame index of this lane
