@@ -93,6 +93,36 @@ def test_sample_posterior_matches_oracle(model, y_dim, N, precision, tile, monke
     np.testing.assert_array_equal(Vs2, Vs)
 
 
+@pytest.mark.parametrize("tile", ["4", "16", "32"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("decisions", ["mixed", "accept", "reject"])
+@pytest.mark.parametrize("nit,burnin", [(1, 0), (4, 0), (5, 4), (12, 5), (70, 2)])
+def test_kept_variances_are_those_of_a_decoder_pass(nit, burnin, decisions, precision, tile, monkeypatch):
+    """The chain kernels take the kept samples' decoder variances from their own passes (4- and 16-frame tiles: the state's copy on chip;
+    32-frame tiles under exact fp32: the proposal's row stored by the kept step, rejected rows copied behind the chain, one pass for the
+    state at the end of the burn-in; more than 64 kept samples: decoder passes).  Whatever the chain did -- no burn-in, one kept sample,
+    every proposal accepted, every one rejected -- Vs is bit for bit what `dvae_mcem_decode` returns for the stored samples."""
+    pick_tile(monkeypatch, tile, precision)
+    N = 70
+    params, prefix, pack, X2, y, Z, g, W, H, rng = setup("M2", 1, N, 21, precision=precision)
+    noise = rng.standard_normal((nit, 16, N)).astype(np.float32)
+    logu = np.log(rng.random((nit, N)).astype(np.float32))
+    if decisions == "accept":
+        logu[:] = -1e30
+    elif decisions == "reject":
+        logu[:] = 1e30
+    Vb = (W @ H).astype(np.float32)
+    Zs, Vs, accp, accd = pack.sample(t(Z), t(y), t(g), t(Vb), t(X2), t(noise), t(logu), burnin, trace=True)
+    accd = accd.cpu().numpy().astype(bool)
+    if decisions != "mixed":
+        assert accd.all() == (decisions == "accept") and accd.any() == (decisions == "accept")
+    if decisions == "reject":                              # the chain never left its initial state
+        np.testing.assert_array_equal(Zs.cpu().numpy(), np.broadcast_to(Z.T[:, None, :], (N, nit - burnin, 16)))
+    Vs2 = pack.decode(Zs, t(y))
+    assert Vs.shape == (nit - burnin, 513, N)
+    np.testing.assert_array_equal(Vs.cpu().numpy(), Vs2.cpu().numpy())
+
+
 @pytest.mark.parametrize("N,R,K", [(45, 3, 10), (300, 10, 10), (32, 1, 4), (1, 2, 16)])
 def test_m_step_and_wiener_match_oracle(N, R, K):
     rng = np.random.default_rng(N + R)
