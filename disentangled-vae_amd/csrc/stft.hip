@@ -981,6 +981,140 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (src >= start) y[src - start] = 0.f;
 }
 
+// The same walk in the arithmetic of istft_pytorch (packages/processing/stft.py:154-190: torch.istft of a complex64 tensor with
+// torch.hann_window): inverse FFT, window product, overlap-add and the division by the window envelope in float32 (the kernel above
+// computes in double whatever the input: the arithmetic of istft(), where librosa transforms with numpy's double FFT).  What the narrower
+// type buys: a point is ONE 8-byte LDS slot, packed float32 VALU instead of fp64 (ten minutes of audio: 73 -> 57-61 us).  Two waves per
+// SIMD as the double walk: a round of 2048 waves is two per SIMD whatever the kernel allows, more and shorter chunks transform more halo
+// frames and measured slower at every occupancy (profiles/r05_istft_f32_ab.txt; at three waves per SIMD the kernel spills: 72 us; the next
+// row by LDS-direct loads instead of 32 registers, spill-free at three and four: 63-75 us at every occupancy -- the walk is bound by its
+// VALU / LDS work per transform, not by latency).
+#ifndef ISTFT_F32_OCC
+#define ISTFT_F32_OCC 2
+#endif
+__global__ __launch_bounds__(256, ISTFT_F32_OCC) void istft1024_walk_f32_kernel(const float2* __restrict__ S, int64_t T, int64_t ld,
+                                                                                const float* __restrict__ window, int64_t start,
+                                                                                float* __restrict__ y, int64_t out_len, int chunk) {
+    constexpr int M = 512, HOP = 256, NF = 1024;
+    __shared__ __attribute__((aligned(8))) cf lz[4][M + 64];
+    // tw[k] = exp(+2 pi i k / 1024); wn[k] = (window[2 k], -window[2 k + 1]) / M  (conj and 1/M folded into the window: exact scalings)
+    __shared__ float2 tw[M], wn[M];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cf* z = lz[wave];
+    for (int k = threadIdx.x; k < M; k += 256) {
+        double sn, cs;
+        sincospi(2.0 * (double)k / 1024.0, &sn, &cs);
+        tw[k] = float2{(float)cs, (float)sn};
+        wn[k] = float2{window[2 * k] * (1.0f / M), -(window[2 * k + 1] * (1.0f / M))};
+    }
+    __syncthreads();                                              // the only workgroup barrier
+    const int64_t nchunks = (T + chunk - 1) / chunk;
+    const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+    if (c >= nchunks) return;
+    Fft512F fft;
+    fft.init(lane);
+    // window envelope of a sample covered by four frames, at the positions this lane emits (frames in ascending order)
+    float w4[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float w = 0.f;
+#pragma unroll
+            for (int f = 3; f >= 0; --f) { const float ww = window[2 * lane + 128 * j + e + f * HOP]; w = fmaf(ww, ww, w); }
+            w4[j][e] = w;
+        }
+    const int64_t ntot = (int64_t)NF + (int64_t)HOP * (T - 1);
+    const int64_t t0 = c * chunk;
+    const int64_t te = t0 + chunk < T ? t0 + chunk : T;
+    const bool last = c == nchunks - 1;
+    const int64_t t_emit_end = last ? T + 3 : te;                 // the last chunk also flushes the three hops behind frame T - 1
+    float2 ra[8], rb[8], na[8], nb[8];                            // X[k] and X[512 - k] of the current / the next frame
+    // one descriptor, two per-lane offsets, the frame's row as the scalar offset, the bin group as the instruction offset (sixteen 64-bit
+    // addresses per frame cost 32 registers); the launcher checks T * ld * 8 < 2^31
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(S), 0, (int)(T * ld * 8), 0x00020000);
+    const int va = lane * 8, vb = (64 - lane) * 8;
+    auto fetch = [&](int64_t t, float2 (&a)[8], float2 (&b)[8]) __attribute__((always_inline)) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const int so = (int)(t * ld * 8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            a[r] = __builtin_bit_cast(float2, (u2)__builtin_amdgcn_raw_buffer_load_b64(rs_s, va + 512 * r, so, 0));
+            b[r] = __builtin_bit_cast(float2, (u2)__builtin_amdgcn_raw_buffer_load_b64(rs_s, vb + 512 * (7 - r), so, 0));
+        }
+    };
+    float acc[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; }
+    int64_t t = t0 - 3 < 0 ? 0 : t0 - 3;
+    if (t < T) fetch(t, ra, rb);
+    for (; t < t_emit_end; ++t) {
+        if (t < T) {
+            if (t + 1 < te) fetch(t + 1, na, nb);                 // in flight under this frame's transform
+            cf v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                cf xk = cf{ra[r].x, ra[r].y}, xc = cf{rb[r].x, -rb[r].y};                        // X[k], conj(X[M-k])
+                if (k == 0) { xk.y = 0.f; xc.y = 0.f; }                                           // C2R ignores imag of DC / Nyquist
+                const cf e = cf{0.5f * (xk.x + xc.x), 0.5f * (xk.y + xc.y)};
+                const float2 w = tw[k];
+                const cf o = cfmulc(cf{0.5f * (xk.x - xc.x), 0.5f * (xk.y - xc.y)}, w.x, w.y);
+                v[r] = cf{e.x - o.y, -(e.y + o.x)};               // conj(E + i O)
+            }
+            fft.run(v, z, lane);
+            __builtin_amdgcn_wave_barrier();                      // the next frame's first exchange writes come after every lane's last reads
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float2 w = wn[lane + 64 * r];
+                acc[r][0] = fmaf(w.x, v[r].x, acc[r][0]);
+                acc[r][1] = fmaf(w.y, v[r].y, acc[r][1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { ra[r] = na[r]; rb[r] = nb[r]; }
+        }
+        if (t >= t0) {
+            // samples [256 t, 256 t + 256) are complete
+            const bool inner = t >= 3 && t <= T - 1;              // covered by four frames: the envelope depends on the position in the hop only
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float o[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int64_t src = t * HOP + 2 * lane + 128 * j + e;
+                    float a = acc[j][e], wss = 0.f;
+                    if (inner) wss = w4[j][e];
+                    else {
+                        int64_t tlo = (src - NF + HOP) / HOP;
+                        if (src < NF) tlo = 0;
+                        int64_t thi = src / HOP;
+                        if (thi > T - 1) thi = T - 1;
+                        for (int64_t tt = tlo; tt <= thi; ++tt) {
+                            const float ww = window[(int)(src - tt * HOP)];
+                            wss = fmaf(ww, ww, wss);
+                        }
+                    }
+                    if (wss > 1e-11f) a = a / wss;                // torch.istft: window_envelop.abs() > 1e-11 is asserted over the kept range
+                    o[e] = a;
+                }
+                const int64_t i = t * HOP + 2 * lane + 128 * j - start;
+                if (i >= 0 && i + 1 < out_len && ((start & 1) == 0)) *reinterpret_cast<float2*>(y + i) = float2{o[0], o[1]};
+                else {
+                    if (i >= 0 && i < out_len) y[i] = o[0];
+                    if (i + 1 >= 0 && i + 1 < out_len) y[i + 1] = o[1];
+                }
+            }
+        }
+        // advance one hop: two registers down, zeros in behind
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { acc[r][0] = acc[r + 2][0]; acc[r][1] = acc[r + 2][1]; }
+        acc[6][0] = acc[6][1] = acc[7][0] = acc[7][1] = 0.f;
+    }
+    if (last)                                                      // behind the signal: zeros up to out_len
+        for (int64_t src = ntot + lane; src < start + out_len; src += 64)
+            if (src >= start) y[src - start] = 0.f;
+}
+
 // [513][ld] (bin-major rows, the legacy layout) -> [T][513] frame rows for the walk kernel: 64 x 64 tiles through LDS, 512-byte runs both ways
 constexpr int64_t ISTFT_TR_MIN_T = 1024;      // shorter spectrograms go through the staged kernel directly (a second launch costs more than it saves)
 __global__ __launch_bounds__(256) void c64_transpose_kernel(const float2* __restrict__ S, int64_t T, int64_t ld, float2* __restrict__ out) {
@@ -1320,4 +1454,33 @@ extern "C" int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* w
 extern "C" int dvae_istft_frames(const void* S, int64_t T, int64_t ldF, const double* window, int nfft, int hop,
                                  int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
     return istft_run(S, T, ldF, true, window, nfft, hop, start, y, out_len, ws, stream);
+}
+
+// float32-arithmetic inverse transform (istft_pytorch): S bin-major ([513][ld], frames = 0: transposed into ws first, T * 513 complex64)
+// or frame-major ([T][ld], frames = 1: read in place, ws unused)
+extern "C" int dvae_istft_f32(const void* S, int64_t T, int64_t ld, int frames, const float* window, int nfft, int hop,
+                              int64_t start, float* y, int64_t out_len, void* ws, void* stream) {
+    DVAE_CHECK_ARG(S && window && y && T > 0 && start >= 0 && out_len >= 0, "istft_f32: bad argument");
+    DVAE_CHECK_ARG(nfft == 1024 && hop == 256, "istft_f32: window length 1024 / hop 256 only (got %d / %d): use dvae_istft", nfft, hop);
+    DVAE_CHECK_ARG(ld >= (frames ? (int64_t)513 : T), "istft_f32: leading dimension %lld too small", (long long)ld);
+    DVAE_CHECK_ARG(frames || ws, "istft_f32: bin-major input needs the workspace (T * 513 complex64)");
+    DVAE_CHECK_ARG(T * (frames ? ld : (int64_t)513) * 8 < ((int64_t)1 << 31), "istft_f32: spectrograms of 2 GB and more are not addressed (use dvae_istft)");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_len == 0) return 0;
+    const float2* Sf = (const float2*)S;
+    int64_t ldf = ld;
+    if (!frames) {
+        hipLaunchKernelGGL(c64_transpose_kernel, dim3((unsigned)cdiv(T, 64), 9), dim3(256), 0, s, (const float2*)S, T, ld, (float2*)ws);
+        DVAE_LAUNCH_OK("c64_transpose_kernel");
+        Sf = (const float2*)ws;
+        ldf = 513;
+    }
+    const char* const slots_s = getenv("DVAE_ISTFT_SLOTS");          // experiment switch, as in the double walk
+    const int slots = slots_s && atoi(slots_s) >= 64 ? atoi(slots_s) : 2048;
+    int chunk = (int)cdiv(T, slots);                               // one round of waves, as the double walk
+    chunk = chunk < 1 ? 1 : chunk;
+    const int wb = (int)cdiv(cdiv(T, chunk), 4);
+    hipLaunchKernelGGL(istft1024_walk_f32_kernel, dim3(wb), dim3(256), 0, s, Sf, T, ldf, window, start, y, out_len, chunk);
+    DVAE_LAUNCH_OK("istft1024_walk_f32_kernel");
+    return 0;
 }

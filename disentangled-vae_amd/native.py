@@ -54,6 +54,7 @@ SIGNATURES = {
     "dvae_istft_workspace_bytes_hop": (c_sz, [c_i64, c_i, c_i]),
     "dvae_istft": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dvae_istft_frames": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dvae_istft_f32": (c_i, [c_vp, c_i64, c_i64, c_i, c_vp, c_i, c_i, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dvae_transpose": (c_i, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "dvae_gather_rows": (c_i, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i, c_vp, c_i64, c_vp, c_vp]),
     "dvae_vad_workspace_bytes": (c_sz, [c_i64]),

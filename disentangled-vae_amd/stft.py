@@ -128,6 +128,33 @@ def istft_device(S_dev, window, nfft, hop, n_frames, start, out_len):
     return y
 
 
+def f32_inverse_covers(S_dev, nfft, hop):
+    """dvae_istft_f32: nfft 1024 / hop 256, complex64 [513, T], 32-bit byte offsets."""
+    return (nfft == 1024 and hop == 256 and S_dev.dtype == torch.complex64 and S_dev.dim() == 2 and S_dev.shape[0] == 513
+            and max(S_dev.shape[1] * 513, S_dev.shape[1] * S_dev.stride(1) if S_dev.stride(0) == 1 else 0) * 8 < 2 ** 31
+            and os.environ.get("DVAE_ISTFT_F32", "1") != "0")
+
+
+def istft_device_f32(S_dev, nfft, hop, n_frames, start, out_len):
+    """The float32-ARITHMETIC inverse transform (torch.istft's on a complex64 tensor: packages/processing/stft.py:154-190): S_dev
+    complex64 [513, >= n_frames] CUDA tensor -> float32 [out_len].  Frame-major memory (the `.T` view of a contiguous [T, 513] tensor,
+    what stft_pytorch returns) is read in place; a row-contiguous tensor is transposed on the device first."""
+    lib = N.load()
+    if not S_dev.is_cuda or S_dev.dtype != torch.complex64 or S_dev.dim() != 2 or S_dev.shape[0] != nfft // 2 + 1:
+        raise TypeError("istft_device_f32: complex64 [nfft/2+1, T] CUDA tensor required")
+    y = torch.empty((out_len,), dtype=torch.float32, device=S_dev.device)
+    w = window_f32(nfft, S_dev.device)
+    if S_dev.shape[1] > 1 and S_dev.stride(0) == 1 and S_dev.stride(1) >= S_dev.shape[0]:
+        N.check(lib.dvae_istft_f32(N.ptr(S_dev), n_frames, S_dev.stride(1), 1, N.ptr(w), nfft, hop, start, N.ptr(y), out_len, None, N.stream()),
+                "dvae_istft_f32")
+        return y
+    S_dev = S_dev.contiguous()
+    ws = torch.empty((n_frames, nfft // 2 + 1), dtype=torch.complex64, device=S_dev.device)
+    N.check(lib.dvae_istft_f32(N.ptr(S_dev), n_frames, S_dev.shape[1], 0, N.ptr(w), nfft, hop, start, N.ptr(y), out_len, N.ptr(ws), N.stream()),
+            "dvae_istft_f32")
+    return y
+
+
 def stft_numpy(x, fs, wlen_sec, win, hop_percent, center, pad_mode, pad_at_end, dtype, layout=0):
     """numpy in / numpy out body of packages.processing.stft.stft."""
     nfft, hop = sizes(fs, wlen_sec, hop_percent, "STFT")

@@ -190,6 +190,14 @@ int dvae_istft(const void* S, int64_t T, int64_t ldT, const double* window, int 
 int dvae_istft_frames(const void* S, int64_t T, int64_t ldF, const double* window, int nfft, int hop,
                       int64_t start, float* y, int64_t out_len, void* ws, void* stream);
 
+/* The inverse transform of istft_pytorch (packages/processing/stft.py:154-190: torch.istft of a complex64 tensor with
+ * torch.hann_window, center handled by `start` / `out_len` as above) in ITS arithmetic: inverse FFT, window product, overlap-add and
+ * the division by the window envelope in float32 (dvae_istft computes in double -- the arithmetic of istft(), librosa's).  nfft 1024 /
+ * hop 256 only; window: nfft floats (device).  frames = 0: S is [513][ld] (bin-major, ld >= T), transposed into ws (T * 513
+ * complex64) first; frames = 1: S is [T][ld] (frame-major, ld >= 513), read in place, ws may be null.  Any other size: DVAE_E_ARG. */
+int dvae_istft_f32(const void* S, int64_t T, int64_t ld, int frames, const float* window, int nfft, int hop,
+                   int64_t start, float* y, int64_t out_len, void* ws, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fused train step (the build's own harness; mirrors scripts/training_M1.py:134-139,
  * scripts/training_M2.py:142-147, scripts/training_M2_info_vad.py:159-198).

@@ -85,14 +85,24 @@ def istft_pytorch(Sxx,
     nfft, hop = H.sizes(fs, wlen_sec, hop_percent, "iSTFT")
     if win != 'hann':
         raise ValueError("istft_pytorch: only win='hann' is defined (as in the reference)")
-    S = Sxx if torch.is_complex(Sxx) else torch.view_as_complex(Sxx.contiguous())
+    if torch.is_complex(Sxx):
+        S = Sxx
+    elif Sxx.dim() == 3 and Sxx.shape[2] == 2 and Sxx.stride(2) == 1 and Sxx.stride(0) % 2 == 0 and Sxx.stride(1) % 2 == 0:
+        S = torch.view_as_complex(Sxx)                     # e.g. the real view stft_pytorch returned: frame-major memory, read in place
+    else:
+        S = torch.view_as_complex(Sxx.contiguous())
     dev = S.device if S.is_cuda else H._device()
-    window = torch.hann_window(window_length=nfft).to(torch.float64).to(dev)
     T = S.shape[1]
     ntot = nfft + hop * (T - 1)
     start = nfft // 2 if center else 0
     out_len = ntot - 2 * (nfft // 2) if center else ntot
-    y = H.istft_device(S.to(dev).to(torch.complex64), window, nfft, hop, T, start, out_len)
+    S = S.to(dev).to(torch.complex64)
+    if H.f32_inverse_covers(S, nfft, hop):
+        # torch.istft's own arithmetic for a complex64 spectrogram (inverse FFT, window, overlap-add, envelope division: float32)
+        y = H.istft_device_f32(S, nfft, hop, T, start, out_len)
+    else:
+        window = torch.hann_window(window_length=nfft).to(torch.float64).to(dev)
+        y = H.istft_device(S, window, nfft, hop, T, start, out_len)
     if max_len:
         y = y[:int(max_len * fs)]
     return y if Sxx.is_cuda else y.cpu()

@@ -146,6 +146,73 @@ def test_float32_arithmetic_transform_matches_torch_stft(n):
     assert torch.equal(torch.view_as_complex(out.contiguous()), got.T)
 
 
+@pytest.mark.parametrize("T,center", [(1, False), (3, False), (4, True), (5, True), (117, False), (1024, True), (2049, True), (18760, True)])
+def test_float32_arithmetic_inverse_matches_torch_istft(T, center):
+    """dvae_istft_f32 -- the transform behind istft_pytorch for complex64 spectrograms (packages/processing/stft.py:154-190: torch.istft
+    with torch.hann_window; inverse FFT, window product, overlap-add and envelope division in float32) -- against torch.istft itself on
+    the host at 5e-6 of the signal's maximum (one frame up to ten frames per wave; centre trimming on and off), against the
+    double-arithmetic path (DVAE_ISTFT_F32=0) at the same bound, frame-major memory read in place = row-contiguous input transposed on
+    the device (bits), and istft_pytorch takes it for both layouts."""
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    rng = np.random.default_rng(T)
+    S = torch.from_numpy((rng.standard_normal((513, T)) + 1j * rng.standard_normal((513, T))).astype(np.complex64))
+    S[0].imag = 0; S[512].imag = 0
+    ntot = 1024 + 256 * (T - 1)
+    start = 512 if center else 0
+    out_len = ntot - 1024 if center else ntot
+    if out_len <= 0:
+        pytest.skip("nothing left after the centre trim")
+    y_bin = H.istft_device_f32(S.cuda(), 1024, 256, T, start, out_len)                      # row-contiguous [513, T]
+    rows = S.T.contiguous().cuda()                                                         # [T, 513]
+    y_fr = H.istft_device_f32(rows.T, 1024, 256, T, start, out_len)                        # frame-major memory, in place
+    assert y_bin.shape == (out_len,) and y_bin.dtype == torch.float32 and torch.equal(y_bin, y_fr)
+    dbl = H.istft_device(rows.T, H.window_f64("hann", 1024, "cuda"), 1024, 256, T, start, out_len)
+    # where the window envelope is small (the first and last hop of an uncentred signal) the division amplifies the float32 rounding of
+    # the overlap-add by 1 / envelope, in torch.istft as here: the bound is held where the envelope is above 1 % of its plateau (1.5)
+    w2 = torch.hann_window(1024, dtype=torch.float64).numpy() ** 2
+    env = np.zeros(ntot)
+    for tt in range(T):
+        env[256 * tt:256 * tt + 1024] += w2
+    ok = torch.from_numpy(env[start:start + out_len] > 0.015).cuda()
+    assert bool(ok.any())
+    scale = float(dbl[ok].abs().max())
+    assert float((y_fr - dbl)[ok].abs().max()) <= 5e-6 * scale
+    assert bool(torch.isfinite(y_fr).all())
+    if center or T >= 4:
+        # torch.istft refuses envelopes that touch zero (the first and last hop of an uncentred signal): compare the interior
+        if center:
+            ref = torch.istft(S, 1024, 256, window=torch.hann_window(1024), center=True)
+            assert ref.shape == (out_len,)
+            assert float((y_fr.cpu() - ref).abs().max()) <= 5e-6 * scale
+        got = ps.istft_pytorch(torch.view_as_real(rows.T), fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=center)
+        assert torch.equal(got, y_fr)
+        got_c = ps.istft_pytorch(torch.view_as_real(S).cuda(), fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=center)
+        assert torch.equal(got_c, y_fr)
+
+
+def test_float32_arithmetic_inverse_can_be_switched_off_and_rejects_other_sizes(monkeypatch):
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    N = importlib.import_module("disentangled-vae_amd.native")
+    lib = N.load()
+    rng = np.random.default_rng(9)
+    S = torch.from_numpy((rng.standard_normal((513, 40)) + 1j * rng.standard_normal((513, 40))).astype(np.complex64)).cuda()
+    a = ps.istft_pytorch(S, fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=True)
+    monkeypatch.setenv("DVAE_ISTFT_F32", "0")
+    b = ps.istft_pytorch(S, fs=16000, wlen_sec=64e-3, hop_percent=0.25, center=True)          # the double-arithmetic walk
+    assert a.shape == b.shape and not torch.equal(a, b) and float((a - b).abs().max()) <= 5e-6 * float(b.abs().max())
+    w = H.window_f32(1024, S.device)
+    y = torch.empty(1024 + 256 * 39, dtype=torch.float32, device="cuda")
+    ws = torch.empty((40, 513), dtype=torch.complex64, device="cuda")
+    call = lambda nfft, hop, ld, frames, wsp: lib.dvae_istft_f32(N.ptr(S), 40, ld, frames, N.ptr(w), nfft, hop, 0, N.ptr(y), y.numel(), wsp, N.stream())
+    assert call(1024, 256, 40, 0, N.ptr(ws)) == 0
+    assert call(1024, 128, 40, 0, N.ptr(ws)) != 0 and "hop" in lib.dvae_last_error().decode()       # hop
+    assert call(512, 128, 40, 0, N.ptr(ws)) != 0                                                     # window length
+    assert call(1024, 256, 39, 0, N.ptr(ws)) != 0                                                    # leading dimension
+    assert call(1024, 256, 40, 0, None) != 0                                                         # bin-major input without the workspace
+
+
 def test_float32_arithmetic_transform_rejects_what_it_does_not_cover():
     import importlib
     H = importlib.import_module("disentangled-vae_amd.stft")

@@ -32,7 +32,12 @@ def main():
             # float32 ARITHMETIC (stft_pytorch's transform, dvae_stft_f32): bytes = 256 new fp32 samples in + 513 complex64 (or float32) out
             t_cf = timeit(lambda: H.stft_device_f32(x, 1024, 256, T, 2))
             t_pf = timeit(lambda: H.stft_device_f32(x, 1024, 256, T, 1))
-            extra = dict(stft_f32arith_us=t_cf * 1e6, stft_f32arith_power_us=t_pf * 1e6, stft_f32arith_GBs=T * (1024 + 4104) / t_cf / 1e9,
+            # ... and back (istft_pytorch's transform, dvae_istft_f32): 513 complex64 in + 256 fp32 samples out per frame
+            t_if = timeit(lambda: H.istft_device_f32(Sr, 1024, 256, T, 0, n))
+            t_if0 = timeit(lambda: H.istft_device_f32(S, 1024, 256, T, 0, n))
+            extra = dict(istft_f32arith_us=t_if * 1e6, istft_f32arith_bin_major_us=t_if0 * 1e6, istft_f32arith_GBs=T * (4104 + 1024) / t_if / 1e9,
+                         istft_f32arith_hbm_frac=T * (4104 + 1024) / t_if / 8e12,
+                         stft_f32arith_us=t_cf * 1e6, stft_f32arith_power_us=t_pf * 1e6, stft_f32arith_GBs=T * (1024 + 4104) / t_cf / 1e9,
                          stft_f32arith_power_GBs=T * (1024 + 2052) / t_pf / 1e9, stft_f32arith_hbm_frac=T * (1024 + 4104) / t_cf / 8e12,
                          stft_f32arith_power_hbm_frac=T * (1024 + 2052) / t_pf / 8e12)
         inb = 256 * x.element_size()
