@@ -17,7 +17,7 @@ t, cost = bm.run(em, m, X, S, y, "cuda", 100)
 print("seconds per utterance", t)
 PY
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /tmp/mcem_one1.py bf16x3 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /tmp/mcem_one1.py ${1:-bf16x3} > $OUT/run.log 2>&1
 tail -2 $OUT/run.log
 f=$(find $OUT -name "*kernel_stats.csv" | head -1); head -14 $f | cut -c1-150
 cp $f $OUT/../mcem_single_kernel_stats.csv
