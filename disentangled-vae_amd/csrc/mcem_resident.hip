@@ -207,11 +207,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int l31 = lane & 31, h = lane >> 5;                             // the lane is the frame, h the k half / feature half
     const int fb = 32 * wave_u;
+    const unsigned long long t_entry = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic stamps: slots 10-12 = prologue, chain, tail in shader clocks)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
     auto ld16 = [&](unsigned byteoff) __attribute__((always_inline)) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)byteoff, 0, 0);
         return __builtin_bit_cast(Frag, v);
     };
+
+    // X2 of the wave's four output tiles and Vb of the last two go HBM -> LDS by LDS-direct loads (`buffer_load ... lds`: wave-uniform
+    // destination + lane * 4 = the [tile][r][lane] layout), requested before anything else: through registers -- all 512 of a lane hold
+    // resident fragments under bf16x3 / fp32 -- a few of the 96 loads were in flight at a time, 35 of the 58 us a launch spends outside
+    // its passes (25 utterances; profiles/r05_mcem_tile32_prologue_ab.txt).  (Label images of 513 rows use the area first: requested behind them.)
+    auto request_x2vb = [&](int voff_, unsigned rowb_) __attribute__((always_inline)) {
+        const int fnb = (int)((int64_t)XD * g.N * 4);
+        const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X2), 0, fnb, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Vb), 0, fnb, 0x00020000);
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+            const int t = NTW * wave_u + tt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (int)((unsigned)(32 * t + (r & 3) + 8 * (r >> 2)) * rowb_);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x2, (__attribute__((address_space(3))) void*)(X2s + (t * 16 + r) * 64), 4, voff_, so, 0, 0);
+                if (tt >= 2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vb, (__attribute__((address_space(3))) void*)(Vbs + ((wave_u * 2 + tt - 2) * 16 + r) * 64), 4, voff_, so, 0, 0);
+            }
+        }
+    };
+    if constexpr (YP != C8_YP) {
+        if ((int)blockIdx.x < g.ntiles && g.X2) {
+            const int64_t n0_ = (int64_t)blockIdx.x * TB;
+            const int64_t nf_ = n0_ + l31 < g.N ? n0_ + l31 : g.N - 1;
+            request_x2vb((int)(((int64_t)(4 * h) * g.N + nf_) * 4), (unsigned)g.N * 4u);
+        }
+    }
 
     // ---- resident weight fragments (once per launch); copies: [k-step of 16][32-row tile][lane][8] ----
     Frag w3zR[ZD / KS][NP], w4R[NK][NP], w5R[NTW][NK][NP];
@@ -247,6 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     if (tid < HD) w512s[tid] = welem(g.oW5, NT_OUT, 512, tid);           // row 512 of the output layer
     __syncthreads();
+    const unsigned long long t_w = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     const float b512 = Bias[OB5 + 512];
     const T* const Zbr = Zb + l31 * LDZ + h * E;
     const T* const Har = Ha + l31 * LDH + h * E;
@@ -298,14 +328,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < 16; ++j) wy[j] = welem(g.oW3, 4, f, ZD + j);          // W3[f][16 + j]
             }
             const float b3 = Bias[f];
+            if constexpr (YP > 0) {
+                // the tile's labels through LDS ([frame][16], in the area the burn-in state takes later): read one by one through wave-uniform
+                // addresses they were sixteen scalar loads in a row, each waited for -- most of a launch's 18 us before its first pass
+                for (int idx = tid; idx < 16 * TB; idx += 256) {
+                    const int j = idx >> 5, fr = idx & 31;
+                    zsv[fr * 16 + j] = (j < g.ydim && n0 + fr < g.N) ? g.y[(int64_t)j * g.N + n0 + fr] : 0.f;
+                }
+                __syncthreads();
+            }
+#pragma unroll 4
             for (int fr = 16 * fg; fr < 16 * fg + 16; ++fr) {
                 float c = b3;
                 if constexpr (YP > 0) {
-                    const bool in = n0 + fr < g.N;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float yv = (j < g.ydim && in) ? g.y[(int64_t)j * g.N + n0 + fr] : 0.f;
-                        c = fmaf(wy[j], yv, c);
+                    for (int jq = 0; jq < 4; ++jq) {
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(zsv + fr * 16 + 4 * jq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c = fmaf(wy[4 * jq + e], yv[e], c);
                     }
                 }
                 c1s[fr * LDC + f] = c;
@@ -320,19 +360,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float vbR[2][16];
         float x2_512 = 0.f, vb_512 = 0.f;
         if (g.X2) {
-            const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X2), 0, fn_bytes, 0x00020000);
+            if constexpr (YP == C8_YP) request_x2vb(voff, rowb);            // (the other label forms: requested at the top of the kernel)
             const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Vb), 0, fn_bytes, 0x00020000);
 #pragma unroll
-            for (int tt = 0; tt < NTW; ++tt) {
+            for (int tt = 0; tt < 2; ++tt) {
                 const int t = NTW * wave_u + tt;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    X2s[(t * 16 + r) * 64 + lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, soff(t, r), 0));
-                    const float vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vb, voff, soff(t, r), 0));
-                    if (tt < 2) vbR[tt][r] = vb; else Vbs[((wave_u * 2 + tt - 2) * 16 + r) * 64 + lane] = vb;
-                }
+                for (int r = 0; r < 16; ++r) vbR[tt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vb, voff, soff(t, r), 0));
             }
             if (wave_u == 3) { x2_512 = g.X2[(int64_t)512 * g.N + nf]; vb_512 = g.Vb[(int64_t)512 * g.N + nf]; }
+            // the LDS-direct loads have landed before the first pass reads X2s / Vbs (the wave that requested a slot is the one that reads it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -484,6 +522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int OOR = 0x7fffffff;                                    // a per-lane offset behind every buffer: the access is dropped
         if (wave_u == 0 && h == 0) rejs[l31] = 0ull;                       // (touched by these lanes only until the chain has ended)
         if (g.dbg) tlast = __builtin_amdgcn_s_memtime();
+        const unsigned long long t_loop = tlast;
         for (int m = mstart; m < mend; ++m) {
             const bool keepst = want_vs && m >= g.burnin;
             float prior_p = 0.f, lu_cur = 0.f;
@@ -583,10 +622,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int r = 0; r < 8; ++r) g.Zlast[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * h) * g.N + nf] = z[r];
         }
+        const unsigned long long t_chain_end = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
         if (g.dbg && lane == 0 && g.nit > 0) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + k] = tsum[k];
             g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 9] = (unsigned long long)(mend - mstart);
+            g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 10] = t_loop - t_entry;
+            g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 13] = t_w - t_entry;
+            g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 11] = t_chain_end - t_loop;
         }
 
         if (want_vs) {
@@ -677,6 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         __syncthreads();
+        if (g.dbg && lane == 0 && g.nit > 0) g.dbg[((size_t)blockIdx.x * 4 + wave_u) * 16 + 12] = __builtin_amdgcn_s_memtime() - t_chain_end;
     }
 }
 
