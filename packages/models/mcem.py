@@ -5,8 +5,8 @@ scripts/evaluate_ntcd_*.py run unchanged (`mcem.init_parameters(...)`, `mcem.run
 
   * CUDA tensors -> the kernels of include/dvae_mcem.h: one persistent launch per Metropolis-Hastings
     chain (the whole E-step), three small launches per M-step, one for the Wiener gains.  No fallback:
-    a missing library raises.  The random draws come from torch's device generator, one call per
-    chain instead of two per iteration.
+    a missing library raises.  The random draws come from torch's device generator: one call per
+    chain instead of two per iteration, the E-step's chains drawn up to sixteen at a time.
   * host tensors -> ATen, drawing from the global generator in the reference's order (randn(L,N),
     rand(N) per iteration), so a seeded CPU run reproduces the reference's.  Selected by the tensors'
     device only.
@@ -198,6 +198,29 @@ class _MCEM(EM):
         self.X_abs_2_t = self.X_abs_2.clone()
         self._pack = None
         self._cached = None
+        self._draw_buf = {}
+
+    def _draws(self, nit, L, N, dev):
+        """(noise (nit, L, N), log u (nit, N)) of one chain from the device generator.  The E-step's chain runs `niter` times on one shape:
+        its draws are made for up to 16 chains per generator call (three small launches per chain were 15 of an iteration's 190 us on one
+        utterance); the stepwise loop and run() take their chains from the same blocks in the same order, so equal seeds give equal
+        results either way.  Any other chain (the final Wiener chain: once) draws for itself."""
+        e_nit = sum(self._e_counts())
+        if nit != e_nit:
+            return torch.randn(nit, L, N, device=dev), torch.log(torch.rand(nit, N, device=dev))
+        buf = getattr(self, "_draw_buf", None)
+        if buf is None:
+            buf = self._draw_buf = {}
+        blk = buf.get((nit, L, N))
+        if blk is None or blk[2] >= blk[0].shape[0]:
+            served = blk[3] if blk is not None else 0
+            per_chain = nit * (L + 1) * N * 4
+            B = max(1, min(16, int(self.niter) - served, (64 << 20) // max(per_chain, 1)))      # never more chains than the loop has left
+            blk = buf[(nit, L, N)] = [torch.randn(B, nit, L, N, device=dev), torch.log(torch.rand(B, nit, N, device=dev)), 0, served]
+        i = blk[2]
+        blk[2] = i + 1
+        blk[3] += 1
+        return blk[0][i], blk[1][i]
 
     def _decoder_pack(self):
         if self._pack is None:
@@ -216,8 +239,7 @@ class _MCEM(EM):
         N = self.X.shape[1]
         nit = nsamples + burnin
         if Z.is_cuda:
-            noise = torch.randn(nit, L, N, device=Z.device)
-            logu = torch.log(torch.rand(nit, N, device=Z.device))
+            noise, logu = self._draws(nit, L, N, Z.device)
             Zs, Vs = self._decoder_pack().sample(Z, y if self._label_in_decoder else None, self.g, self.Vb, self.X_abs_2_t,
                                                  noise, logu, burnin, var_rw=float(self.var_RW))
             self._cached_vs = Vs
@@ -285,9 +307,8 @@ class _MCEM(EM):
         tail = (Nn.ptr(self.W), Nn.ptr(self.H), Nn.ptr(Zs), Nn.ptr(Vs))
         cptr, wptr, stream = cost.data_ptr(), Nn.ptr(ws), Nn.stream()
         for it in range(self.niter):
-            # the draws of _chain, in its order (one generator stream for this loop and the stepwise one: equal results on equal seeds)
-            noise = torch.randn(nit, L, N, device=dev)
-            logu = torch.log(torch.rand(nit, N, device=dev))
+            # the draws of _chain, from its blocks in its order (one generator stream for this loop and the stepwise one: equal results on equal seeds)
+            noise, logu = self._draws(nit, L, N, dev)
             Nn.check(lib.dvae_mcem_em_iteration(*args, Nn.ptr(noise), Nn.ptr(logu), nit, b_e, float(self.var_RW), N, K, 1,
                                                 None, None, None, *tail, cptr + 4 * it, wptr, stream), "dvae_mcem_em_iteration")
         self.Vs = Vs

@@ -97,8 +97,18 @@ class FeedDraws:
         self._rand, self._randn = torch.rand, torch.randn
 
     def _next(self, kind, shape, device):
-        k, arr = self.q.pop(0)
-        assert k == kind and tuple(arr.shape) == tuple(shape), (k, kind, arr.shape, shape)
+        k, arr = self.q[0]
+        if k == kind and tuple(arr.shape) == tuple(shape):
+            self.q.pop(0)
+        else:
+            # the drop-in draws for up to sixteen E-step chains in one generator call ((B, nit, L, N) normals, then (B, nit, N) uniforms):
+            # chain i of the block takes the i-th recorded draw of that kind still in the queue, as one call per chain would have
+            idx = [i for i, (kk, _) in enumerate(self.q) if kk == kind][:shape[0]]
+            parts = [self.q[i][1] for i in idx]
+            assert len(parts) == shape[0] and all(tuple(p.shape) == tuple(shape[1:]) for p in parts), (kind, shape, [p.shape for p in parts])
+            for i in reversed(idx):
+                self.q.pop(i)
+            arr = np.stack(parts)
         return torch.from_numpy(np.ascontiguousarray(arr)).to(device if device is not None else "cpu")
 
     def __enter__(self):
