@@ -211,6 +211,10 @@ def side_kernels(device):
         us = t_us(fn)
         out[name] = {"us": us, "frames": T, "Mframes_per_s": T / us, "algorithmic_GB_per_s": byts / us * 1e-3, "hbm_frac": byts / us * 1e-3 / 8000.0,
                      "note": "float32 signal, float32 arithmetic: the transform of stft_pytorch (torch.stft on a float32 tensor), dvae_stft_f32"}
+    us = t_us(lambda: H.istft_device_f32(Sr, 1024, 256, T, 0, n))
+    byts = T * (513 * 8 + 256 * 4)
+    out["istft_f32arith"] = {"us": us, "frames": T, "Mframes_per_s": T / us, "algorithmic_GB_per_s": byts / us * 1e-3, "hbm_frac": byts / us * 1e-3 / 8000.0,
+                             "note": "complex64 spectrogram, float32 arithmetic: the transform of istft_pytorch (torch.istft on a complex64 tensor), dvae_istft_f32"}
     out["stft_note"] = "600 s of float64 audio at 16 kHz, nfft 1024, hop 256; bytes = new samples in + spectrogram out (float32 samples out for istft); stft_complex / istft: the frame-major spectrogram memory of packages.processing.stft (a Fortran-ordered [513, T] array, as librosa's), *_bin_major: the row-contiguous [513, T] form (stft_pytorch / device tensors)"
     # MCEM: scripts/evaluate_ntcd_M2.py settings (10 + 30 samples per E-step, rank 10), 25 utterances x 300 frames, 20 EM iterations
     dims = dict(x_dim=513, y_dim=1, z_dim=16, h_dim=(128, 128))
