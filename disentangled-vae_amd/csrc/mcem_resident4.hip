@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool bit2 = (lane & 4) != 0;
     const int b7 = b & 7, kh = b >> 3;                                    // layers 1 / 2: the lane's block of rows, its half of k
     const int fb = 32 * wave_u;
+    const unsigned long long t_entry = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic stamps: slots 10 / 11 = prologue / chain in shader clocks)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wcopy), 0, (int)g.wcopy_bytes, 0x00020000);
     // four consecutive k (quad o) of row `row` of an fp32 copy with nt 32-row tiles per k-step of 8: [k-step][row tile][half * 32 + row % 32][4]
     auto ldq = [&](int64_t base_elems, int nt, int row, int o) __attribute__((always_inline)) {
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     if (g.dbg) tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_loop = tlast;
     for (int m = mstart; m < mend; ++m) {
         float prior_p = 0.f, lu_cur = 0.f;
         if (wave_u == 0) {
@@ -477,6 +479,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int k = 0; k < 9; ++k) g.dbg[((size_t)tile * 4 + wave_u) * 16 + k] = tsum[k];
         g.dbg[((size_t)tile * 4 + wave_u) * 16 + 9] = (unsigned long long)(mend - mstart);
+        g.dbg[((size_t)tile * 4 + wave_u) * 16 + 10] = t_loop - t_entry;
+        g.dbg[((size_t)tile * 4 + wave_u) * 16 + 11] = __builtin_amdgcn_s_memtime() - t_loop;
     }
 
     if (want_vs) {                                                         // the last step's decision

@@ -25,9 +25,10 @@ steps = r[:, :, 9:10]
 per = r[:, :, :9] / np.maximum(steps, 1)
 names = ["P4+P0 (accept, next proposal)", "wait B0", "L1 + tanh + put", "wait B1", "L2 + tanh + put + bin-512 terms", "wait B2", "output layer + likelihood", "reduce + red write", "wait B3"]
 print(f"{prec}, {U} utterances ({ntiles} tiles): shader clocks per chain step, mean over tiles; total {per.sum(axis=2).mean():.0f}")
-if r[:, :, 10].max() > 0:      # the 32-frame kernel also stamps the launch's parts
+if r[:, :, 10].max() > 0:      # the 32- and 4-frame kernels also stamp the launch's parts (the 4-frame kernel: prologue and chain)
     print("  launch, shader clocks (mean over tiles and waves): prologue (weights, label terms, X2 / Vb tiles) %.0f  chain %.0f  tail (decoder passes / slot copies, stores) %.0f"
           % (r[:, :, 10].mean(), r[:, :, 11].mean(), r[:, :, 12].mean()))
-    print("    of the prologue: resident fragments + bias tables landed after %.0f" % r[:, :, 13].mean())
+    if r[:, :, 13].max() > 0:
+        print("    of the prologue: resident fragments + bias tables landed after %.0f" % r[:, :, 13].mean())
 for w in range(4):
     print(f"  wave {w}: " + "  ".join(f"{n}={per[:, w, i].mean():.0f}" for i, n in enumerate(names)))
