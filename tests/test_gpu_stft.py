@@ -179,6 +179,16 @@ def test_float32_arithmetic_inverse_matches_torch_istft(T, center):
     scale = float(dbl[ok].abs().max())
     assert float((y_fr - dbl)[ok].abs().max()) <= 5e-6 * scale
     assert bool(torch.isfinite(y_fr).all())
+    if ntot > 20:
+        # an odd first sample (the paired stores fall back to single ones) and a length past the signal (zeros behind it)
+        y_odd = H.istft_device_f32(rows.T, 1024, 256, T, 3, ntot + 5)
+        full = H.istft_device_f32(rows.T, 1024, 256, T, 0, ntot)
+        assert torch.equal(y_odd[:ntot - 3], full[3:]) and bool((y_odd[ntot - 3:] == 0).all())
+        # a sliced spectrogram (frames 1 .. T - 1 of the same memory: leading dimension 513, first row one frame in)
+        if T > 2:
+            part = H.istft_device_f32(rows[1:].T, 1024, 256, T - 1, 0, 1024 + 256 * (T - 2))
+            ref_part = H.istft_device_f32(rows[1:].contiguous().T, 1024, 256, T - 1, 0, 1024 + 256 * (T - 2))
+            assert torch.equal(part, ref_part)
     if center or T >= 4:
         # torch.istft refuses envelopes that touch zero (the first and last hop of an uncentred signal): compare the interior
         if center:
