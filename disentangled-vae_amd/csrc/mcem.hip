@@ -724,7 +724,7 @@ extern "C" int dvae_mcem_decode(const dvae_mcem_plan_t* plan, const void* weight
 static size_t mstep_ws_layout(int64_t N, int K, int U, size_t* o_norms, size_t* o_partial) {
     size_t o = ((size_t)U * XD * K * sizeof(float) + 255) / 256 * 256;
     *o_norms = o; o += ((size_t)U * KMAX * sizeof(float) + 255) / 256 * 256;
-    *o_partial = o; o += ((size_t)((N + 7) / 8) * sizeof(double) + 255) / 256 * 256;        // one cost partial per workgroup of the frames kernel (8 or 16 frames)
+    *o_partial = o; o += ((size_t)((N + 3) / 4) * sizeof(double) + 255) / 256 * 256;        // one cost partial per workgroup of the frames kernel (4, 8 or 16 frames)
     return o;
 }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ float rcp_pos(float x) { return __builtin_amdgcn_rcpf
 #ifndef MSTEP_FLY
 #define MSTEP_FLY 2      // reciprocals in flight per thread inside a bin (more: more temporaries live, see the remark at the loops)
 #endif
-// Round 5: FR = 8 frames per workgroup for short frame axes (one utterance of 300 frames = 20 workgroups of 16 frames on 256 CUs: the kernel is
+// Round 5: FR = 8 (and 4: 128 bin groups, 5 bins per thread) frames per workgroup for short frame axes (one utterance of 300 frames = 20 workgroups of 16 frames on 256 CUs: the kernel is
 // per-workgroup latency there): 64 bin groups, 9 bins per thread -- half the loads and half the arithmetic per thread, twice the workgroups.
 constexpr int FT16 = MSTEP_FT, FW = FT16 / 64;
 template <int FR> struct MsGeo { static constexpr int FG = FT16 / FR, FJ = (513 + FG - 1) / FG; };
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
         for (int i = 0; i < M; ++i) {
             if (i < cnt) {
                 float a = v[i];
-                if constexpr (FR == 8) a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));   // lane ^ 8 (row_ror:8)
+                if constexpr (FR == 4) a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x124, 0xf, 0xf, false));   // lanes 4 apart (row_ror:4)
+                if constexpr (FR <= 8) a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));   // lanes 8 apart (row_ror:8)
                 a = xsum16(a);                                      // (v_permlane16/32_swap: mcem_types.hpp; the operands of ds_bpermute's additions)
                 a = xsum32(a);
                 if (lane < FR) wpart[(wave * cnt + i) * FR + fr] = a;
@@ -338,28 +339,31 @@ __global__ __launch_bounds__(256) void mstep_w_reg_kernel(const float* __restric
 
 
 namespace mstep {
-// frames per workgroup of the frames kernel = frames per cost partial: 8 while the 8-frame workgroups fit the chip in one round (DVAE_MSTEP_FRAMES=8 / 16 forces)
+// frames per workgroup of the frames kernel = frames per cost partial: 4 / 8 while the 4- / 8-frame workgroups fit the chip in one round
+// (DVAE_MSTEP_FRAMES=4 / 8 / 16 forces)
 int frames_per_workgroup(int64_t N) {
     const char* e = getenv("DVAE_MSTEP_FRAMES");
     const int forced = e ? atoi(e) : 0;
-    if (forced == 8 || forced == 16) return forced;
-    return (N + 7) / 8 <= 256 ? 8 : 16;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
+    return (N + 3) / 4 <= 256 ? 4 : ((N + 7) / 8 <= 256 ? 8 : 16);
 }
 int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
     const int fr = frames_per_workgroup(N);
     const int nt = (int)((N + fr - 1) / fr);
-    const int FJ = fr == 8 ? MsGeo<8>::FJ : MsGeo<16>::FJ;
+    const int FJ = fr == 4 ? MsGeo<4>::FJ : (fr == 8 ? MsGeo<8>::FJ : MsGeo<16>::FJ);
     const size_t lds = ((size_t)(XD * K + 3) / 4 * 4 + FW * 2 * K * fr + 2 * K * fr + FJ * FT16 + 10 * FT16) * sizeof(float);
     static bool attr_done16 = false;
     if (!attr_done16) {
         const size_t lds_max = ((size_t)(XD * KMAX + 3) / 4 * 4 + FW * 2 * KMAX * 16 + 2 * KMAX * 16 + MsGeo<16>::FJ * FT16 + 10 * FT16) * sizeof(float);
         hipError_t e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mstep_frames_reg_kernel<10, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_reg_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
         attr_done16 = true;
     }
-    if (fr == 8) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 8>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    if (fr == 4) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 4>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    else if (fr == 8) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 8>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
     else hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 16>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
     DVAE_LAUNCH_OK("mstep_frames_reg_kernel");
     return 0;
