@@ -521,9 +521,9 @@ __global__ __launch_bounds__(FT) void mstep_frames_kernel(const float* __restric
 
 // (the register-resident form of this kernel, mstep_frames_reg_kernel, lives in mcem_mstep.hip: it is compiled without SLP vectorisation)
 namespace mstep { int launch_w_reg(const float* X2, const float* Vs, int R, int64_t N, int U, const float* W, const float* H, const float* g, const float* Vb,
-                                  float* Wun, const int* seg_start, const int* seg_count, hipStream_t s);
+                                  float* Wun, const int* seg_start, const int* seg_count, const double* partial_prev, float* cost_prev, hipStream_t s);
                   int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
-                                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s);
+                                       float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, float* Wout, hipStream_t s);
                   int frames_per_workgroup(int64_t N); }
 
 // per utterance: W = Wun / norm (mcem.py:132), cost = mean over (R, F, N_u) of the tile partials
@@ -537,12 +537,17 @@ __global__ __launch_bounds__(256) void mstep_finish_kernel(const float* __restri
     const int64_t nbeg = seg_start ? seg_start[u] : 0, cnt = seg_count ? seg_count[u] : N;
     const int t0 = (int)(nbeg / tile_frames), t1 = (int)((nbeg + cnt + tile_frames - 1) / tile_frames);
     __shared__ double red[4];
-    double c = 0.0;
-    for (int i = t0 + threadIdx.x; i < t1; i += 256) c += partial[i];
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0 && cost) cost[u] = (float)((red[0] + red[1] + red[2] + red[3]) / ((double)R * XD * (double)cnt));
+    if (cost) mstep_cost_of_partials(partial, t0, t1, (double)R * XD * (double)cnt, cost + u, red);
+}
+
+// the cost alone (dvae_mcem_cost_flush: the last iteration of a loop of dvae_mcem_em_iteration_lazy calls)
+__global__ __launch_bounds__(256) void mstep_cost_kernel(const double* __restrict__ partial, int R, int64_t N, const int* __restrict__ seg_start,
+                                                         const int* __restrict__ seg_count, float* __restrict__ cost, int tile_frames) {
+    const int u = blockIdx.x;
+    const int64_t nbeg = seg_start ? seg_start[u] : 0, cnt = seg_count ? seg_count[u] : N;
+    const int t0 = (int)(nbeg / tile_frames), t1 = (int)((nbeg + cnt + tile_frames - 1) / tile_frames);
+    __shared__ double red[4];
+    mstep_cost_of_partials(partial, t0, t1, (double)R * XD * (double)cnt, cost + u, red);
 }
 
 // Wiener gains (compute_WF, mcem.py:321-327)
@@ -733,9 +738,11 @@ extern "C" size_t dvae_mcem_m_step_workspace_bytes(int64_t N, int K, int U) {
     return mstep_ws_layout(N, K, U < 1 ? 1 : U, &a, &b);
 }
 
-extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, int64_t N, int K, int U, const int* seg_start,
-                                      const int* seg_count, const int* tile_seg, float* W, float* H, float* g, float* Vb,
-                                      float* cost, void* workspace, void* stream) {
+// lazy: W normalised by the frames kernel, no finish launch; the cost stays in the workspace's partial sums until the next lazy call (which
+// writes it to cost_prev from its W update) or dvae_mcem_cost_flush
+static int m_step_impl(const float* X2, const float* Vs, int R, int64_t N, int K, int U, const int* seg_start,
+                       const int* seg_count, const int* tile_seg, float* W, float* H, float* g, float* Vb,
+                       float* cost, bool lazy, float* cost_prev, void* workspace, void* stream) {
     DVAE_CHECK_ARG(X2 && Vs && W && H && g && Vb && workspace, "mcem_m_step: null argument");
     DVAE_CHECK_ARG(R > 0 && N > 0 && K > 0 && K <= KMAX && U > 0, "mcem_m_step: need R > 0, N > 0, U > 0, 0 < K <= %d", KMAX);
     DVAE_CHECK_ARG((seg_start != nullptr) == (seg_count != nullptr) && (seg_start != nullptr) == (tile_seg != nullptr),
@@ -754,16 +761,18 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     // ranks other than 10 always take them
     const char* mk = getenv("DVAE_MSTEP");
     const bool reg_form = R <= 10 && K == 10 && (int64_t)R * XD * N * 4 < (int64_t)0x7fffffff && !(mk && strcmp(mk, "3pass") == 0);      // (rank 10: mcem.py / scripts/evaluate_ntcd_M2.py:66)
+    if (lazy && !reg_form) { set_error("mcem_em_iteration_lazy: exists for the register-resident M-step only (R <= 10 samples, rank 10): use dvae_mcem_em_iteration"); return DVAE_E_UNSUPPORTED; }
     if (reg_form) {
-        const int rcw = mstep::launch_w_reg(X2, Vs, R, N, U, W, H, g, Vb, Wun, seg_start, seg_count, s);
+        const int rcw = mstep::launch_w_reg(X2, Vs, R, N, U, W, H, g, Vb, Wun, seg_start, seg_count, lazy ? partial : nullptr, lazy ? cost_prev : nullptr, s);
         if (rcw) return rcw;
     } else {
         hipLaunchKernelGGL(mstep_w_kernel, dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, K, W, H, g, Vb, Wun, seg_start, seg_count);
         DVAE_LAUNCH_OK("mstep_w_kernel");
     }
     if (reg_form) {
-        const int rcf = mstep::launch_frames_reg(X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, s);
+        const int rcf = mstep::launch_frames_reg(X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, lazy ? W : nullptr, s);
         if (rcf) return rcf;
+        if (lazy) return 0;
         hipLaunchKernelGGL(mstep_finish_kernel, dim3(U), dim3(256), 0, s, Wun, norms, K, W, partial, R, N, seg_start, seg_count, cost, mstep::frames_per_workgroup(N));
         DVAE_LAUNCH_OK("mstep_finish_kernel");
         return 0;
@@ -783,6 +792,12 @@ extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, i
     return 0;
 }
 
+extern "C" int dvae_mcem_m_step_batch(const float* X2, const float* Vs, int R, int64_t N, int K, int U, const int* seg_start,
+                                      const int* seg_count, const int* tile_seg, float* W, float* H, float* g, float* Vb,
+                                      float* cost, void* workspace, void* stream) {
+    return m_step_impl(X2, Vs, R, N, K, U, seg_start, seg_count, tile_seg, W, H, g, Vb, cost, false, nullptr, workspace, stream);
+}
+
 // One EM iteration = the body of EM.run's loop (mcem.py:156-160: E_step, M_step, cost) as ONE host call: the chain launch (with the decoder
 // variances of its kept samples and Z <- last kept sample), the M-step's launches.  Nothing here synchronises or allocates; between two calls
 // the host only has to point at the next iteration's draws.
@@ -796,6 +811,31 @@ extern "C" int dvae_mcem_em_iteration(const dvae_mcem_plan_t* plan, const void* 
     if (rc) return rc;
     const int R = nit - burnin;
     return dvae_mcem_m_step_batch(X2, Vs, R, N, K, U, seg_start, seg_count, tile_seg, W, H, g, Vb, cost, workspace, stream);
+}
+
+// The same iteration with two launches of the M-step instead of three: W is normalised by the frames kernel (its workgroups share the rows
+// out), and the iteration's cost stays in the workspace as the frames kernel's partial sums -- the NEXT lazy call forms it in its W update
+// (cost_prev, U floats, or NULL in the first call), dvae_mcem_cost_flush after the last.  Same arithmetic, same bits as
+// dvae_mcem_em_iteration; one utterance of 300 frames: 6.5 us of an iteration's 170.  The workspace must not be touched between the calls.
+extern "C" int dvae_mcem_em_iteration_lazy(const dvae_mcem_plan_t* plan, const void* weights, float* Z, const float* y, float* g, float* Vb,
+                                           const float* X2, const float* noise, const float* logu, int nit, int burnin, float var_rw, int64_t N,
+                                           int K, int U, const int* seg_start, const int* seg_count, const int* tile_seg, float* W, float* H,
+                                           float* Zs, float* Vs, float* cost_prev, void* workspace, void* stream) {
+    DVAE_CHECK_ARG(Z && Zs && Vs, "mcem_em_iteration_lazy: Z, Zs and Vs are required");
+    int rc = mcem_sample_impl(plan, weights, Z, y, g, Vb, X2, noise, logu, nit, burnin, var_rw, N, Zs, Vs, nullptr, nullptr, Z, stream);
+    if (rc) return rc;
+    return m_step_impl(X2, Vs, nit - burnin, N, K, U, seg_start, seg_count, tile_seg, W, H, g, Vb, nullptr, true, cost_prev, workspace, stream);
+}
+
+extern "C" int dvae_mcem_cost_flush(int R, int64_t N, int K, int U, const int* seg_start, const int* seg_count, float* cost, void* workspace, void* stream) {
+    DVAE_CHECK_ARG(cost && workspace && R > 0 && N > 0 && U > 0 && K > 0 && K <= KMAX, "mcem_cost_flush: bad argument");
+    DVAE_CHECK_ARG((seg_start != nullptr) == (seg_count != nullptr) && (seg_start != nullptr || U == 1), "mcem_cost_flush: U > 1 needs the segment tables");
+    size_t o_norms, o_partial;
+    mstep_ws_layout(N, K, U, &o_norms, &o_partial);
+    hipLaunchKernelGGL(mstep_cost_kernel, dim3(U), dim3(256), 0, (hipStream_t)stream, (const double*)((char*)workspace + o_partial), R, N, seg_start, seg_count, cost,
+                       mstep::frames_per_workgroup(N));
+    DVAE_LAUNCH_OK("mstep_cost_kernel");
+    return 0;
 }
 
 extern "C" int dvae_mcem_m_step(const float* X2, const float* Vs, int R, int64_t N, int K, float* W, float* H, float* g, float* Vb,

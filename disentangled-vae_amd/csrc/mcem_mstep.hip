@@ -42,7 +42,7 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
                                                                 const float* __restrict__ Wun_all, float* __restrict__ H, float* __restrict__ g,
                                                                 float* __restrict__ Vb, float* __restrict__ norms_out, double* __restrict__ partial,
                                                                 const int* __restrict__ seg_start, const int* __restrict__ seg_count,
-                                                                const int* __restrict__ tile_seg) {
+                                                                const int* __restrict__ tile_seg, float* __restrict__ Wout) {
     constexpr int FG = MsGeo<FR>::FG, FJ16 = MsGeo<FR>::FJ;         // (FJ16: bins per thread, whatever FR)
     extern __shared__ __attribute__((aligned(16))) float lw[];     // Wun [513][K], then wave partials [FW][2K][FR], then sums [2K][FR]
     float* wpart = lw + (XD * K + 3) / 4 * 4;
@@ -253,6 +253,17 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < K; ++k) H[(int64_t)k * N + n] = hk[k] * nrm[k];
     }
+    if (Wout != nullptr && any_live) {
+        // W = Wun / norm (mcem.py:132) here instead of in mstep_finish_kernel (dvae_mcem_em_iteration_lazy): every workgroup holds Wun and
+        // its column norms; the utterance's workgroups share the 513 rows out (the operands of the finish kernel's division: the same bits)
+        const int64_t seg0 = seg_start ? (int64_t)seg_start[u] : 0;
+        const int lt = (int)((n0 - seg0) / FR), ntl = (int)((nend - seg0 + FR - 1) / FR);
+        float* const Wu = Wout + (int64_t)u * XD * K;
+        for (int i = tid; i < XD * K; i += FT16) {
+            const int f = i / K;
+            if (f % ntl == lt) Wu[i] = lw[i] / nrm[i - f * K];
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
@@ -271,11 +282,19 @@ template <int RR, int K>
 __global__ __launch_bounds__(256) void mstep_w_reg_kernel(const float* __restrict__ X2, const float* __restrict__ Vs, int R, int64_t N,
                                                           const float* __restrict__ W, const float* __restrict__ H, const float* __restrict__ g,
                                                           const float* __restrict__ Vb, float* __restrict__ Wun,
-                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_count) {
+                                                          const int* __restrict__ seg_start, const int* __restrict__ seg_count,
+                                                          const double* __restrict__ partial_prev, float* __restrict__ cost_prev, int tile_frames) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = blockIdx.x * 4 + wave, u = blockIdx.y;
-    if (f >= XD) return;
     const int64_t nbeg = seg_start ? seg_start[u] : 0, cnt = seg_count ? seg_count[u] : N, nend = nbeg + cnt;
+    if (cost_prev != nullptr && blockIdx.x == 0) {
+        // the cost of the PREVIOUS iteration from the partial sums its frames kernel left (the frames kernel of this iteration overwrites
+        // them behind this launch): what mstep_finish_kernel does, without its launch (dvae_mcem_em_iteration_lazy)
+        __shared__ double redc[4];
+        const int t0 = (int)(nbeg / tile_frames), t1 = (int)((nbeg + cnt + tile_frames - 1) / tile_frames);
+        mstep_cost_of_partials(partial_prev, t0, t1, (double)R * XD * (double)cnt, cost_prev + u, redc);
+    }
+    if (f >= XD) return;
     const int64_t FN = (int64_t)XD * N;
     const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, (int)((int64_t)R * FN * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2), 0, (int)(FN * 4), 0x00020000);
@@ -348,7 +367,7 @@ int frames_per_workgroup(int64_t N) {
     return (N + 3) / 4 <= 256 ? 4 : ((N + 7) / 8 <= 256 ? 8 : 16);
 }
 int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K, const float* Wun, float* H, float* g, float* Vb,
-                      float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, hipStream_t s) {
+                      float* norms, double* partial, const int* seg_start, const int* seg_count, const int* tile_seg, float* Wout, hipStream_t s) {
     const int fr = frames_per_workgroup(N);
     const int nt = (int)((N + fr - 1) / fr);
     const int FJ = fr == 4 ? MsGeo<4>::FJ : (fr == 8 ? MsGeo<8>::FJ : MsGeo<16>::FJ);
@@ -362,15 +381,16 @@ int launch_frames_reg(const float* X2, const float* Vs, int R, int64_t N, int K,
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(mstep_frames_reg_kernel, %zu B LDS): %s", lds_max, hipGetErrorString(e)); return (int)e; }
         attr_done16 = true;
     }
-    if (fr == 4) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 4>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
-    else if (fr == 8) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 8>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
-    else hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 16>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg);
+    if (fr == 4) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 4>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, Wout);
+    else if (fr == 8) hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 8>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, Wout);
+    else hipLaunchKernelGGL((mstep_frames_reg_kernel<10, 10, 16>), dim3(nt), dim3(FT16), lds, s, X2, Vs, R, N, K, Wun, H, g, Vb, norms, partial, seg_start, seg_count, tile_seg, Wout);
     DVAE_LAUNCH_OK("mstep_frames_reg_kernel");
     return 0;
 }
 int launch_w_reg(const float* X2, const float* Vs, int R, int64_t N, int U, const float* W, const float* H, const float* g, const float* Vb,
-                 float* Wun, const int* seg_start, const int* seg_count, hipStream_t s) {
-    hipLaunchKernelGGL((mstep_w_reg_kernel<10, 10>), dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, W, H, g, Vb, Wun, seg_start, seg_count);
+                 float* Wun, const int* seg_start, const int* seg_count, const double* partial_prev, float* cost_prev, hipStream_t s) {
+    hipLaunchKernelGGL((mstep_w_reg_kernel<10, 10>), dim3((XD + 3) / 4, U), dim3(256), 0, s, X2, Vs, R, N, W, H, g, Vb, Wun, seg_start, seg_count,
+                       partial_prev, cost_prev, frames_per_workgroup(N));
     DVAE_LAUNCH_OK("mstep_w_reg_kernel");
     return 0;
 }

@@ -2,9 +2,23 @@
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
+#include "common.hpp"
 
 namespace dvae {
 namespace fused {
+
+// cost of one utterance = mean over (R, F, N_u) of its tiles' partial sums (mcem.py:69-71): ONE form for mstep_finish_kernel (mcem.hip) and for
+// the W update that forms the previous iteration's cost (dvae_mcem_em_iteration_lazy) -- the same additions in the same order, the same bits.
+// 256 threads; red: four doubles of LDS.
+__device__ __forceinline__ void mstep_cost_of_partials(const double* __restrict__ partial, int t0, int t1, double denom, float* out, double* red) {
+    double c = 0.0;
+    for (int i = t0 + (int)threadIdx.x; i < t1; i += 256) c += partial[i];
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (float)((red[0] + red[1] + red[2] + red[3]) / denom);
+}
+
 
 struct MhArgs {
     const float* Z0;      // (16, N)            initial latents                       [MH mode]

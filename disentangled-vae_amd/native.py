@@ -98,6 +98,9 @@ SIGNATURES = {
     "dvae_mcem_m_step": (c_i, [c_vp, c_vp, c_i, c_i64, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_em_iteration": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp,
                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dvae_mcem_em_iteration_lazy": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_f, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                     c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dvae_mcem_cost_flush": (c_i, [c_i, c_i64, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dvae_mcem_wiener": (c_i, [c_vp, c_i, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

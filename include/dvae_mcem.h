@@ -85,6 +85,17 @@ int dvae_mcem_em_iteration(const dvae_mcem_plan_t* plan, const void* weights, fl
                            int K, int U, const int* seg_start, const int* seg_count, const int* tile_seg, float* W, float* H,
                            float* Zs, float* Vs, float* cost, void* workspace, void* stream);
 
+/* dvae_mcem_em_iteration with TWO launches of the M-step instead of three (EM.run's loop, mcem.py:156-160, for callers that read the cost
+ * after the loop, as the drop-in classes' run() does): W is normalised inside the frames kernel, and the iteration's cost stays in the
+ * workspace (the frames kernel's partial sums) until the NEXT lazy call writes it to cost_prev (U floats; NULL in the first call) from
+ * its W update, or dvae_mcem_cost_flush after the last.  Same arithmetic and bits as dvae_mcem_em_iteration.  Register-resident M-step only
+ * (at most 10 kept samples, rank 10): DVAE_E_UNSUPPORTED otherwise.  The workspace must stay untouched between the calls. */
+int dvae_mcem_em_iteration_lazy(const dvae_mcem_plan_t* plan, const void* weights, float* Z, const float* y, float* g, float* Vb,
+                                const float* X2, const float* noise, const float* logu, int nit, int burnin, float var_rw, int64_t N,
+                                int K, int U, const int* seg_start, const int* seg_count, const int* tile_seg, float* W, float* H,
+                                float* Zs, float* Vs, float* cost_prev, void* workspace, void* stream);
+int dvae_mcem_cost_flush(int R, int64_t N, int K, int U, const int* seg_start, const int* seg_count, float* cost, void* workspace, void* stream);
+
 /* compute_WF (mcem.py:321-327): WFs = mean_r(g Vs / Vx), WFn = mean_r(Vb / Vx), both (F, N). */
 int dvae_mcem_wiener(const float* Vs, int R, int64_t N, const float* g, const float* Vb, float* WFs, float* WFn, void* stream);
 

@@ -306,11 +306,22 @@ class _MCEM(EM):
         args = (ctypes.byref(pk.plan), Nn.ptr(pk.weights), Nn.ptr(self.Z), Nn.ptr(y), Nn.ptr(self.g), Nn.ptr(self.Vb), Nn.ptr(self.X_abs_2_t))
         tail = (Nn.ptr(self.W), Nn.ptr(self.H), Nn.ptr(Zs), Nn.ptr(Vs))
         cptr, wptr, stream = cost.data_ptr(), Nn.ptr(ws), Nn.stream()
+        # two launches per M-step instead of three where the library offers it (at most 10 kept samples, rank 10): W normalised by the frames
+        # kernel, the cost of iteration i formed by the W update of iteration i + 1 and by one flush after the loop -- the same bits
+        lazy = (n_e <= 10 and K == 10 and n_e * F * N * 4 < 2 ** 31 - 1 and os.environ.get("DVAE_MSTEP") != "3pass"
+                and os.environ.get("DVAE_MCEM_LAZY", "1") != "0")
         for it in range(self.niter):
             # the draws of _chain, from its blocks in its order (one generator stream for this loop and the stepwise one: equal results on equal seeds)
             noise, logu = self._draws(nit, L, N, dev)
-            Nn.check(lib.dvae_mcem_em_iteration(*args, Nn.ptr(noise), Nn.ptr(logu), nit, b_e, float(self.var_RW), N, K, 1,
-                                                None, None, None, *tail, cptr + 4 * it, wptr, stream), "dvae_mcem_em_iteration")
+            if lazy:
+                Nn.check(lib.dvae_mcem_em_iteration_lazy(*args, Nn.ptr(noise), Nn.ptr(logu), nit, b_e, float(self.var_RW), N, K, 1,
+                                                         None, None, None, *tail, (cptr + 4 * (it - 1)) if it else None, wptr, stream),
+                         "dvae_mcem_em_iteration_lazy")
+            else:
+                Nn.check(lib.dvae_mcem_em_iteration(*args, Nn.ptr(noise), Nn.ptr(logu), nit, b_e, float(self.var_RW), N, K, 1,
+                                                    None, None, None, *tail, cptr + 4 * it, wptr, stream), "dvae_mcem_em_iteration")
+        if lazy and self.niter > 0:
+            Nn.check(lib.dvae_mcem_cost_flush(n_e, N, K, 1, None, None, cptr + 4 * (self.niter - 1), wptr, stream), "dvae_mcem_cost_flush")
         self.Vs = Vs
         self._Vs_scaled = None
         self._Vx = None

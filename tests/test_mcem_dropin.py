@@ -165,14 +165,18 @@ def test_gpu_fused_run_equals_the_stepwise_loop(case, precision, monkeypatch):
     loop structure (E_step / M_step / cost through Python, mcem.py:156-160).  Same generator seed -> the same draws in the same order
     -> the same kernels on the same operands: costs, factors and estimates are equal bit for bit."""
     res = {}
-    for mode in ("fused", "steps"):
-        monkeypatch.setenv("DVAE_MCEM_RUN", mode)
+    # "fused": two M-step launches per iteration (dvae_mcem_em_iteration_lazy: W normalised by the frames kernel, the cost formed one
+    # iteration later and flushed after the loop); "fused3": the three-launch iteration (DVAE_MCEM_LAZY=0)
+    for mode in ("fused", "fused3", "steps"):
+        monkeypatch.setenv("DVAE_MCEM_RUN", "steps" if mode == "steps" else "fused")
+        monkeypatch.setenv("DVAE_MCEM_LAZY", "0" if mode == "fused3" else "1")
         em, kw, X = make_em(dict(case, niter=5), "cuda")
         em.precision = precision
         torch.manual_seed(7)
         em.init_parameters(**kw)
         cost = em.run()
         res[mode] = (np.asarray(cost, np.float64), em.W.cpu().numpy(), em.H.cpu().numpy(), em.g.cpu().numpy(), em.Z.cpu().numpy(), em.S_hat, em.N_hat)
-    for a, b in zip(res["fused"], res["steps"]):
-        assert a.shape == b.shape and np.array_equal(a, b)
+    for other in ("steps", "fused3"):
+        for a, b in zip(res["fused"], res[other]):
+            assert a.shape == b.shape and np.array_equal(a, b), other
     assert res["fused"][0].shape == (5,) and np.all(np.isfinite(res["fused"][0]))
