@@ -175,6 +175,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             w3A[4 * o] = v[0]; w3A[4 * o + 1] = v[1]; w3A[4 * o + 2] = v[2]; w3A[4 * o + 3] = v[3];
         }
     }
+    // the tile's own operands -- X2 / Vb rows, gain, start latents, the labels of the 16-row label forms -- are requested HERE, behind the
+    // resident fragments and in front of the first barrier (which waits for every load): one memory round trip for the whole prologue
+    // instead of four in a row (fragments -> label weights -> labels -> X2 / Vb: 12.9k clocks per launch before)
+    const int64_t n0 = (int64_t)tile * T4;
+    const bool live = n0 + j < g.N;
+    const int64_t nf = live ? n0 + j : g.N - 1;                            // clamped frame index of this lane
+    const float g_n = g.g ? g.g[nf] : 1.f;
+    // (F, N) matrices through buffer descriptors: bin 128 w + 64 R + 4 b + i of frame nf = ONE per-lane byte offset (bin 4 b) + a wave-uniform offset
+    const int fn_bytes = (int)((int64_t)XD * g.N * 4);                     // < 2^31: checked by the launcher
+    const int voff = (int)(((int64_t)(4 * b) * g.N + nf) * 4);
+    const unsigned rowb = (unsigned)g.N * 4u;
+    auto soff = [&](int R, int i) __attribute__((always_inline)) { return (int)((unsigned)(128 * wave_u + 64 * R + i) * rowb); };
+    float x2_512 = 0.f, vb_512 = 0.f;
+    f32x4_t xvR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, vvR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (g.X2) {
+        const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X2), 0, fn_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Vb), 0, fn_bytes, 0x00020000);
+#pragma unroll
+        for (int R = 0; R < 2; ++R) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xvR[R][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, soff(R, i), 0));
+                vvR[R][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vb, voff, soff(R, i), 0));
+            }
+        }
+        if (wave_u == 3) { x2_512 = g.X2[(int64_t)512 * g.N + nf]; vb_512 = g.Vb[(int64_t)512 * g.N + nf]; }
+    }
+    float z = 0.f, zp = 0.f;                                               // chain state (wave 0): lane (b, j) holds latent b of frame j
+    if (wave_u == 0 && g.nit > 0) z = g.Z0[(int64_t)b * g.N + nf];
+    float yv2[2][16];                                                      // (label forms of up to 16 rows) the labels of the thread's two frames
+    if constexpr (YP > 0 && YP != NO) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int fr = 2 * (tid >> 7) + e;
+            const bool in = n0 + fr < g.N;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) yv2[e][q] = (q < g.ydim && in) ? g.y[(int64_t)q * g.N + n0 + fr] : 0.f;
+        }
+    }
     for (int i = tid; i < 2 * HD + NO; i += 256) Bias[i] = g.bias[i];
     // element (row, column k) of a copy: k-step k / 8, lane' = (k % 8) / 4 * 32 + row % 32, element k % 4
     const float* const wc = reinterpret_cast<const float*>(g.wcopy);
@@ -182,13 +221,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return wc[base + ((int64_t)((k / 8) * nt + (row >> 5)) * 64 + ((k % 8) / 4) * 32 + (row & 31)) * 4 + (k % 4)];
     };
     if (tid < HD) w512s[tid] = welem(g.oW5, NT_OUT, 512, tid);            // row 512 of the output layer
+    float wy[16];                                                          // (label forms of up to 16 rows) W3[f][16 + q] of the thread's feature
+    if constexpr (YP > 0 && YP != NO) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wy[q] = welem(g.oW3, 4, tid & (HD - 1), ZD + q);
+    }
     __syncthreads();
     const float b512 = Bias[OB5 + 512];
-
-    const int64_t n0 = (int64_t)tile * T4;
-    const bool live = n0 + j < g.N;
-    const int64_t nf = live ? n0 + j : g.N - 1;                            // clamped frame index of this lane
-    const float g_n = g.g ? g.g[nf] : 1.f;
 
     // ---- per tile: label part of decoder layer 1 (fp32, constant along the chain), X2 / Vb -> LDS ----
     if constexpr (YP == NO) {
@@ -220,54 +259,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();                                                   // the label image is consumed: its area is X2 / Vb from here on
     } else {
         const int f = tid & (HD - 1), fg = tid >> 7;                       // feature, pair of frames
-        float wy[16];
-        if constexpr (YP > 0) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) wy[q] = welem(g.oW3, 4, f, ZD + q);              // W3[f][16 + q]
-        }
         const float b3 = Bias[f];
-        for (int fr = 2 * fg; fr < 2 * fg + 2; ++fr) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
             float c = b3;
             if constexpr (YP > 0) {
-                const bool in = n0 + fr < g.N;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float yv = (q < g.ydim && in) ? g.y[(int64_t)q * g.N + n0 + fr] : 0.f;
-                    c = fmaf(wy[q], yv, c);
-                }
+                for (int q = 0; q < 16; ++q) c = fmaf(wy[q], yv2[e][q], c);
             }
-            c1s[fr * LDC + f] = c;
+            c1s[(2 * fg + e) * LDC + f] = c;
         }
     }
-    // (F, N) matrices through buffer descriptors: bin 128 w + 64 R + 4 b + i of frame nf = ONE per-lane byte offset (bin 4 b) + a wave-uniform offset
-    const int fn_bytes = (int)((int64_t)XD * g.N * 4);                     // < 2^31: checked by the launcher
-    const int voff = (int)(((int64_t)(4 * b) * g.N + nf) * 4);
-    const unsigned rowb = (unsigned)g.N * 4u;
-    auto soff = [&](int R, int i) __attribute__((always_inline)) { return (int)((unsigned)(128 * wave_u + 64 * R + i) * rowb); };
-    float x2_512 = 0.f, vb_512 = 0.f;
-    if (g.X2) {
-        const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X2), 0, fn_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Vb), 0, fn_bytes, 0x00020000);
+    if (g.X2) {                                                            // (requested in front of the first barrier)
 #pragma unroll
         for (int R = 0; R < 2; ++R) {
-            f32x4_t xv, vv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x2, voff, soff(R, i), 0));
-                vv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_vb, voff, soff(R, i), 0));
-            }
-            X2s[(wave_u * 2 + R) * 64 + lane] = xv;
-            Vbs[(wave_u * 2 + R) * 64 + lane] = vv;
+            X2s[(wave_u * 2 + R) * 64 + lane] = xvR[R];
+            Vbs[(wave_u * 2 + R) * 64 + lane] = vvR[R];
         }
-        if (wave_u == 3) { x2_512 = g.X2[(int64_t)512 * g.N + nf]; vb_512 = g.Vb[(int64_t)512 * g.N + nf]; }
     }
 
-    // chain state (wave 0): lane (b, j) holds latent b of frame j
-    float z = 0.f, zp = 0.f;
     float prior_cur = 0.f;
     double ll_cur = 0.0;
     const int zoff = (int)(((int64_t)b * g.N + nf) * 4);                   // element (latent b, frame nf) of a (16, N) matrix
-    if (wave_u == 0 && g.nit > 0) z = g.Z0[(int64_t)b * g.N + nf];
 
     unsigned long long tlast = 0ull, tsum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int k) __attribute__((always_inline)) {
