@@ -229,13 +229,22 @@ class McemBatch:
                           torch.empty(lib.dvae_mcem_m_step_workspace_bytes(self.ntot, self.K, len(self.counts)), dtype=torch.uint8, device=dev))
         return self._bufs
 
-    def _iteration(self, noise_ptr, logu_ptr, cost_ptr):
+    def _iteration(self, noise_ptr, logu_ptr, cost_ptr, lazy=False):
         """One EM iteration (mcem.py:156-160) = ONE call into the library (dvae_mcem_em_iteration): chain + decoder variances of the kept
         samples, last kept sample -> Z in place, the M-step's launches, cost (U) to cost_ptr.  Draws and cost are raw device addresses: the
         loop does no tensor arithmetic between iterations (it was bound by the interpreter, not by its kernels: ~150 of 590 us per
         iteration at 25 utterances were gaps between ten launches issued from Python, profiles/r04_mcem_kernel_stats.csv)."""
         Zs, Vs, ws = self._loop_buffers()
         pk = self._pack
+        if lazy:
+            # two M-step launches instead of three (dvae_mcem_em_iteration_lazy): cost_ptr is where the PREVIOUS iteration's cost goes (None
+            # in the first iteration); run() flushes the last one
+            N.check(pk.lib.dvae_mcem_em_iteration_lazy(ctypes.byref(pk.plan), N.ptr(pk.weights), N.ptr(self.Z), N.ptr(self.y), N.ptr(self.g), N.ptr(self.Vb),
+                                                       N.ptr(self.X2), noise_ptr, logu_ptr, self.n_e + self.b_e, self.b_e, float(self.var_RW), self.ntot,
+                                                       self.K, len(self.counts), N.ptr(self.seg_start), N.ptr(self.seg_count), N.ptr(self.tile_seg),
+                                                       N.ptr(self.W), N.ptr(self.H), N.ptr(Zs), N.ptr(Vs), cost_ptr, N.ptr(ws), N.stream()),
+                    "dvae_mcem_em_iteration_lazy")
+            return
         N.check(pk.lib.dvae_mcem_em_iteration(ctypes.byref(pk.plan), N.ptr(pk.weights), N.ptr(self.Z), N.ptr(self.y), N.ptr(self.g), N.ptr(self.Vb),
                                               N.ptr(self.X2), noise_ptr, logu_ptr, self.n_e + self.b_e, self.b_e, float(self.var_RW), self.ntot,
                                               self.K, len(self.counts), N.ptr(self.seg_start), N.ptr(self.seg_count), N.ptr(self.tile_seg),
@@ -261,11 +270,16 @@ class McemBatch:
             if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
                 raise RuntimeError(f"McemBatch.run: {nm} must be a contiguous float32 CUDA tensor")
         cptr = cost.data_ptr()
+        # eager loops: two M-step launches per iteration where the library offers it (at most 10 kept samples, rank 10); the cost of
+        # iteration i is written by iteration i + 1, the last one by a flush -- the same bits as the three-launch iteration
+        lazy = (not graph and self.n_e <= 10 and self.K == 10 and self.n_e * F_BINS * self.ntot * 4 < 2 ** 31 - 1
+                and os.environ.get("DVAE_MSTEP") != "3pass" and os.environ.get("DVAE_MCEM_LAZY", "1") != "0")
+        cost_at = (lambda it: (cptr + 4 * U * (it - 1)) if it else None) if lazy else (lambda it: cptr + 4 * U * it)
         if draws is not None and not graph:
             for it in range(self.niter):
                 noise, logu = (_f32c(a, nm) for a, nm in zip(draws[it], ("noise", "logu")))
                 assert noise.shape == (nit, Z_DIM, self.ntot) and logu.shape == (nit, self.ntot)
-                self._iteration(noise.data_ptr(), logu.data_ptr(), cptr + 4 * U * it)
+                self._iteration(noise.data_ptr(), logu.data_ptr(), cost_at(it), lazy)
         elif not graph or self.niter < 2:
             # the generator's draws for as many iterations at a time as fit 256 MB (the reference draws inside the loop, mcem.py:244, 257:
             # the same distributions, fewer launches); the iterations themselves are one library call each
@@ -277,7 +291,7 @@ class McemBatch:
                 logu = torch.rand(c, nit, self.ntot, device=dev).log_()
                 nptr, lptr = noise.data_ptr(), logu.data_ptr()
                 for j in range(c):
-                    self._iteration(nptr + 4 * nit * Z_DIM * self.ntot * j, lptr + 4 * nit * self.ntot * j, cptr + 4 * U * (it0 + j))
+                    self._iteration(nptr + 4 * nit * Z_DIM * self.ntot * j, lptr + 4 * nit * self.ntot * j, cost_at(it0 + j), lazy)
         else:
             static = (torch.empty((nit, Z_DIM, self.ntot), dtype=torch.float32, device=dev), torch.empty((nit, self.ntot), dtype=torch.float32, device=dev))
             c = torch.empty(U, dtype=torch.float32, device=dev)
@@ -301,6 +315,9 @@ class McemBatch:
                 cost[it].copy_(c)
             torch.cuda.synchronize(dev)
             del g
+        if lazy and self.niter > 0:
+            N.check(self._pack.lib.dvae_mcem_cost_flush(self.n_e, self.ntot, self.K, U, N.ptr(self.seg_start), N.ptr(self.seg_count),
+                                                        cptr + 4 * U * (self.niter - 1), N.ptr(self._loop_buffers()[2]), N.stream()), "dvae_mcem_cost_flush")
         Zs, Vs = self._chain(self.n_wf, self.b_wf, None if draws is None else draws[self.niter])
         self.WFs, self.WFn = wiener(Vs, self.g, self.Vb)
         WFs, WFn = self.WFs.cpu().numpy(), self.WFn.cpu().numpy()
