@@ -184,6 +184,10 @@ def test_float32_arithmetic_inverse_matches_torch_istft(T, center):
         y_odd = H.istft_device_f32(rows.T, 1024, 256, T, 3, ntot + 5)
         full = H.istft_device_f32(rows.T, 1024, 256, T, 0, ntot)
         assert torch.equal(y_odd[:ntot - 3], full[3:]) and bool((y_odd[ntot - 3:] == 0).all())
+        # rows with padding behind the 513 bins (leading dimension 520)
+        wide = torch.zeros((T, 520), dtype=torch.complex64, device="cuda")
+        wide[:, :513] = rows
+        assert torch.equal(H.istft_device_f32(wide[:, :513].T, 1024, 256, T, 0, ntot), full)
         # a sliced spectrogram (frames 1 .. T - 1 of the same memory: leading dimension 513, first row one frame in)
         if T > 2:
             part = H.istft_device_f32(rows[1:].T, 1024, 256, T - 1, 0, 1024 + 256 * (T - 2))
