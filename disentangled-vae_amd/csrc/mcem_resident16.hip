@@ -572,7 +572,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 prior_p = xsum16(prior_p);
                 prior_p = xsum32(prior_p);
                 __builtin_amdgcn_sched_barrier(0);
-                flush_step();
                 if (m >= 0) load_draws(m + 1);
             }
             stamp(0);
@@ -603,6 +602,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ll = xsum16(ll);
             ll = xsum32(ll);
             if (q == 0) red[wave_u * T16 + f16] = ll;
+            if (wave_u == 0) flush_step();                                 // (the last step's kept sample and trace: in front of B3, where wave 0 waits for wave 3's bin 512 -- not in the serial section)
             stamp(7);
             __syncthreads();                                               // B3
             stamp(8);

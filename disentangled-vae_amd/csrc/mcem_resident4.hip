@@ -441,7 +441,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             Zb[j * LDZ + b] = zp;
             prior_p = bsum<16>(zp * zp, bit2);
             __builtin_amdgcn_sched_barrier(0);
-            flush_step();
             if (m >= 0) load_draws(m + 1);
         }
         stamp(0);
@@ -468,6 +467,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ll += (double)fmaf(slog, 0.693147180559945309f, sdiv);
         ll = bsum16d(ll, bit2);
         if (b == 0) red[wave_u * T4 + j] = ll;
+        if (wave_u == 0) flush_step();                                     // (the last step's kept sample and trace: in wave 0's wait for wave 3's bin 512, not in the serial section)
         stamp(7);
         __syncthreads();                                                   // B3
         stamp(8);
