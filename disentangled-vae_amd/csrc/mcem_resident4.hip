@@ -288,11 +288,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // one decoder pass over the latents in Zb: EPI(row group R, bin offset i, pre-activation incl. bias, x2, vb) for the lane's eight bins
     // (bin 128 w + 64 R + 4 b + i of frame j), EPI512(pre-activation) on wave 3; ends BEHIND the output layer (no trailing barrier)
-    auto pass = [&](auto&& epi, auto&& epi512) __attribute__((always_inline)) {
+    // (PRE runs behind the requests of the latents and in front of the first MFMA: work that needs no MFMA result fills the LDS round trip)
+    auto pass = [&](auto&& pre, auto&& epi, auto&& epi512) __attribute__((always_inline)) {
         // layer 1: z -> h1 (the lane halves take eight latents each)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         {
             const f32x4_t z0 = *reinterpret_cast<const f32x4_t*>(Zb + j * LDZ + 8 * kh), z1 = *reinterpret_cast<const f32x4_t*>(Zb + j * LDZ + 8 * kh + 4);
+            pre();
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w3A[e], z0[e], acc, 0, 0, 0);
 #pragma unroll
@@ -446,10 +448,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stamp(0);
         __syncthreads();                                                   // B0
         stamp(1);
-        if (want_vs && m > mstart) settle(m - 1);
         double ll = 0.0;
         float slog = 0.f, sdiv = 0.f;                                      // sums of log2(vx) and x2 / vx over the lane's eight bins
         pass(
+            [&]() { if (want_vs && m > mstart) settle(m - 1); },          // (its flag travels beside the latents: at the top of the step the read was waited for on the spot)
             [&](int R, int i, float a, float x2, float vb) {
                 const float ea = exp_(a);
                 vprop[R][i] = ea;
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float* const vs_r = g.Vs + (int64_t)r_s * XD * g.N;
             const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(vs_r, 0, fn_bytes, 0x00020000);
             pass(
+                []() {},
                 [&](int R, int i, float a, float, float) {
                     if (live) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, exp_(a)), rs_vs, voff, soff(R, i), 0);
                 },
