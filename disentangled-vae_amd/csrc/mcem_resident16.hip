@@ -389,12 +389,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // one decoder pass over the latents in Zb: EPI_BEGIN(tt) / EPI(tt, tile t, bin r, part, pre-activation incl. bias, x2, vb) / EPI_END(tt) for this
         // wave's output tiles -- a bin's work comes in three parts, one behind each MFMA of the k-step it shares -- EPI512(pre-activation) on
         // wave 3; ends BEHIND the output layer (no trailing barrier)
-        auto pass = [&](auto&& epi_begin, auto&& epi, auto&& epi_end, auto&& epi512) __attribute__((always_inline)) {
+        // (PRE runs behind the requests of the latents and in front of the first MFMA: work that needs no MFMA result fills the LDS round trip)
+        auto pass = [&](auto&& pre, auto&& epi_begin, auto&& epi, auto&& epi_end, auto&& epi512) __attribute__((always_inline)) {
             f32x4_t a2[2], v2[2];
             // layer 1: [z | 0] -> h1
             {
                 Frag b[NP];
                 bloadp<P>(b, Zbr);
+                pre();
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     a2[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -577,10 +579,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stamp(0);
             __syncthreads();                                               // B0
             stamp(1);
-            if (want_vs && m > mstart) settle(m - 1);
             double ll = 0.0;
             float slog = 0.f, sdiv = 0.f, vx = 0.f;                        // sums of log2(vx) and x2 / vx over one tile
             pass(
+                [&]() { if (want_vs && m > mstart) settle(m - 1); },      // (its flag travels beside the latents)
                 [&](auto) { slog = 0.f; sdiv = 0.f; },
                 [&](auto tc, int, auto rc, auto part, float a, float x2, float vb) {
                     constexpr int pt = decltype(part)::value;
@@ -653,6 +655,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float* const vs_r = g.Vs + (int64_t)r_s * XD * g.N;
                 const __amdgpu_buffer_rsrc_t rs_vs = __builtin_amdgcn_make_buffer_rsrc(vs_r, 0, fn_bytes, 0x00020000);
                 pass(
+                    []() {},
                     [](auto) {},
                     [&](auto, int t, auto jc, auto part, float a, float, float) {
                         constexpr int j = decltype(jc)::value;
