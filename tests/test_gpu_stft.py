@@ -205,6 +205,29 @@ def test_float32_arithmetic_inverse_matches_torch_istft(T, center):
         assert torch.equal(got_c, y_fr)
 
 
+def test_float32_arithmetic_round_trip_at_the_benchmarked_length():
+    """Ten minutes of audio (37 497 frames, the length bench.py and tools/bench_stft.py time): dvae_stft_f32 followed by dvae_istft_f32
+    on the frame-major spectrogram returns the signal wherever four frames overlap (the Hann window's squares at hop 256 sum to 1.5, the
+    envelope division undoes them): float32 round-off of two transforms, 2e-5 of the signal's maximum; the first and last three hops
+    (fewer frames) are held to the same bound relative to their smaller envelope."""
+    import importlib
+    H = importlib.import_module("disentangled-vae_amd.stft")
+    n = 16000 * 600
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x = torch.randn(n, device="cuda", generator=g) * torch.exp(0.5 * torch.randn(n, device="cuda", generator=g))
+    T = H.frame_count(n, 1024, 256)
+    S = H.stft_device_f32(x, 1024, 256, T, 2)                                             # [T, 513]
+    covered = 1024 + 256 * (T - 1)
+    y = H.istft_device_f32(S.T, 1024, 256, T, 0, covered)
+    scale = float(x.abs().max())
+    inner = slice(768, covered - 768)
+    assert float((y[inner] - x[:covered][inner]).abs().max()) <= 2e-5 * scale
+    assert bool(torch.isfinite(y).all())
+    # the power layout of the same transform carries the same energy (Parseval per frame is not exact under a window: compare the layouts)
+    P = H.stft_device_f32(x, 1024, 256, T, 1)
+    torch.testing.assert_close(P.sum(dtype=torch.float64), (torch.view_as_real(S) ** 2).sum(dtype=torch.float64), rtol=1e-6, atol=0.0)
+
+
 def test_float32_arithmetic_inverse_can_be_switched_off_and_rejects_other_sizes(monkeypatch):
     import importlib
     H = importlib.import_module("disentangled-vae_amd.stft")
