@@ -336,14 +336,26 @@ __global__ __launch_bounds__(256) void mstep_w_reg_kernel(const float* __restric
         for (int k = 0; k < K; ++k) { num[k] = fmaf(p2, q.hk[k], num[k]); den[k] = fmaf(a1, q.hk[k], den[k]); }
     };
     const int64_t nch = (cnt + 63) / 64;
-    Set A, B;
-    if (nch > 0) load(A, 0);
-    for (int64_t c = 0; c < nch; c += 2) {
-        if (c + 1 < nch) load(B, c + 1);
-        compute(A);
-        if (c + 1 < nch) {
-            if (c + 2 < nch) load(A, c + 2);
-            compute(B);
+    constexpr int NALL = 5;
+    if (nch > 0 && nch <= NALL) {
+        // one utterance of up to 320 frames: every step's operands requested at once, straight-line (steps past the end load the last
+        // valid column with weight 0 -- load() clamps -- and add zeros: the sums of the loop below, bit for bit)
+        Set S[NALL];
+#pragma unroll
+        for (int c = 0; c < NALL; ++c) load(S[c], c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NALL; ++c) compute(S[c]);
+    } else {
+        Set A, B;
+        if (nch > 0) load(A, 0);
+        for (int64_t c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) load(B, c + 1);
+            compute(A);
+            if (c + 1 < nch) {
+                if (c + 2 < nch) load(A, c + 2);
+                compute(B);
+            }
         }
     }
 #pragma unroll
