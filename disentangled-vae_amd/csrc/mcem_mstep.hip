@@ -139,11 +139,13 @@ __global__ __launch_bounds__(FT16) void mstep_frames_reg_kernel(const float* __r
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (tid < 16 * K) {                                            // column norms of the un-normalised W (mcem.py:130): 16 threads per column
-        const int k = tid >> 4, q = tid & 15;
+    if (tid < 32 * K) {                                            // column norms of the un-normalised W (mcem.py:130): 32 threads per column
+        // (these waves also run pass 1 and everyone meets at its barrier: sixteen threads per column walked 33 dependent LDS reads)
+        const int k = tid >> 5, q = tid & 31;
         float s = 0.f;
-        for (int f = q; f < XD; f += 16) s += fabsf(lw[f * K + k]);
-        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+#pragma unroll
+        for (int i = 0; i < (XD + 31) / 32; ++i) { const int f = q + 32 * i; s += f < XD ? fabsf(lw[f * K + k]) : 0.f; }
+        s += __shfl_xor(s, 16, 32); s += __shfl_xor(s, 8, 32); s += __shfl_xor(s, 4, 32); s += __shfl_xor(s, 2, 32); s += __shfl_xor(s, 1, 32);
         if (q == 0) { nrm[k] = s; if (n0 == (seg_start ? seg_start[u] : 0)) norms_out[u * KMAX + k] = s; }
     }
 
